@@ -1,0 +1,92 @@
+"""Deterministic synthetic weights / views / model configs.
+
+There is no network (no released checkpoint, no dataset), so the benchmark, the
+smoke test and the parity tests all run on synthetic data of the real shapes
+(BASELINE.md section 3).  Everything here is a pure function of its seed so the
+build container (where the reference can be imported) and the GPU box (where it
+cannot) regenerate bit-identical tensors: torch's CPU generator is the only
+source of randomness.
+"""
+import math
+import zlib
+
+import torch
+
+
+def vit_large_args(img_size=512, attn_implementation="flash_attention", random_image_idx_embedding=True,
+                   attn_bias_for_inference_enabled=True):
+    """The (inferred) released `Fast3R_ViT_Large_512` constructor args."""
+    encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls="PatchEmbedDust3R",
+                        embed_dim=1024, num_heads=16, depth=24, mlp_ratio=4, pos_embed="RoPE100",
+                        attn_implementation=attn_implementation)
+    decoder_args = dict(decoder_type="fast3r", random_image_idx_embedding=random_image_idx_embedding,
+                        enc_embed_dim=1024, embed_dim=1024, num_heads=16, depth=24, mlp_ratio=4.0, qkv_bias=True,
+                        drop=0.0, attn_drop=0.0, attn_implementation=attn_implementation,
+                        attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)
+    head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=False,
+                     depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],
+                     patch_size=16, with_local_head=True)
+    return encoder_args, decoder_args, head_args
+
+
+def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64, with_local_head=True,
+              random_image_idx_embedding=True, attn_implementation="pytorch_naive",
+              attn_bias_for_inference_enabled=True):
+    """Small model of the same family (head_dim stays 64; decoder depth must be > 9, fast3r.py:137)."""
+    encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls="PatchEmbedDust3R",
+                        embed_dim=embed_dim, num_heads=num_heads, depth=enc_depth, mlp_ratio=4, pos_embed="RoPE100",
+                        attn_implementation=attn_implementation)
+    decoder_args = dict(decoder_type="fast3r", random_image_idx_embedding=random_image_idx_embedding,
+                        enc_embed_dim=embed_dim, embed_dim=embed_dim, num_heads=num_heads, depth=dec_depth,
+                        mlp_ratio=4.0, qkv_bias=True, drop=0.0, attn_drop=0.0,
+                        attn_implementation=attn_implementation,
+                        attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)
+    head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=False,
+                     depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],
+                     patch_size=16, with_local_head=with_local_head)
+    return encoder_args, decoder_args, head_args
+
+
+def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
+    """One tensor of a synthetic state_dict; a pure function of (key, shape, seed).
+
+    Weights (ndim >= 2) ~ N(0, 1/fan_in) so activations stay O(1) through 48 blocks;
+    LayerNorm weights ~ 1 + 0.1 N(0,1); biases ~ 0.02 N(0,1).
+    """
+    g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    if len(shape) >= 2:
+        if key.endswith("act_postprocess.0.1.weight") or key.endswith("act_postprocess.1.1.weight"):
+            fan_in = shape[0]  # ConvTranspose2d weight is (Cin, Cout, k, k); k == stride -> one tap per output
+        else:
+            fan_in = math.prod(shape[1:])
+        gain = 0.1 if key.endswith("dpt.head.4.weight") else 1.0  # keeps |xyz| = O(1) ahead of expm1 / exp
+        return torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+    if key.endswith("weight"):  # LayerNorm gamma
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    return 0.02 * torch.randn(shape, generator=g)
+
+
+def synth_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """shapes: {key: shape} (e.g. from `model.state_dict()`) -> deterministic fp32 state_dict.
+
+    `scratch.layer_rn.{i}` aliases `scratch.layer{i+1}_rn` (dpt_block.py:79-86); aliases get equal values.
+    """
+    out = {}
+    for k, shp in shapes.items():
+        canon = k
+        for i in range(4):
+            canon = canon.replace(f"scratch.layer_rn.{i}.", f"scratch.layer{i + 1}_rn.")
+        out[k] = synth_tensor(canon, shp, seed)
+    return out
+
+
+def make_views(n_views: int, height: int = 512, width: int = 512, batch: int = 1, seed: int = 1000):
+    """BASELINE.md section 3 inputs: img ~ U(-1,1) from Generator(seed+i); true_shape int32 [[H,W]]."""
+    views = []
+    for i in range(n_views):
+        g = torch.Generator().manual_seed(seed + i)
+        img = torch.rand((batch, 3, height, width), generator=g) * 2.0 - 1.0
+        views.append(dict(img=img, true_shape=torch.tensor([[height, width]] * batch, dtype=torch.int32),
+                          idx=i, instance=str(i), dataset="syn", label=f"syn/{i}"))
+    return views
