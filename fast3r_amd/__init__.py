@@ -1,0 +1,5 @@
+"""fast3r_amd: the Fast3R single-forward-pass inference hot path, MI355X-native (hand-written HIP for gfx950 behind
+the reference's Python API).  See DESIGN.md."""
+from .fast3r import Fast3R  # noqa: F401
+from .inference_multiview import inference  # noqa: F401
+from .multiview_dust3r_module import MultiViewDUSt3RLitModule  # noqa: F401

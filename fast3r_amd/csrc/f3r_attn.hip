@@ -1,0 +1,236 @@
+// f3r_attn_fwd: O = softmax(scale * Q K^T) V for head_dim 64 on gfx950 -- the fusion transformer's
+// multi-view self-attention (all N*P tokens attend to all N*P tokens) and the encoder's per-view
+// attention.  Flash style: the T x T score matrix never exists; fp32 online softmax.
+//
+// Workgroup = 512 threads = 8 waves; a wave owns 32 query rows (256 per workgroup), the workgroup
+// streams the keys in tiles of 64 through a double-buffered LDS image (K tile [64 key][64 d] and V^T
+// tile [64 d][64 key], 8 KB each, 16-byte chunks XOR-swizzled by (row >> 1) & 7 so each ds_read_b128
+// lane group covers the 64 banks once).  A tile is fetched global -> registers right before the MFMAs of
+// the previous tile and written to the other LDS buffer right after them (one barrier per tile).
+//
+// Per wave and tile: S^T = K Q^T as two 32(key) x 32(query) v_mfma_f32_32x32x16 blocks ("swapped" QK^T):
+// in the C layout lane l holds query column q = l & 31, i.e. every softmax statistic is lane-local apart
+// from one exchange with lane l ^ 32.  The K rows are fed to the MFMA through the permutation
+// pi = (swap bits 2 and 3 of the row index): with it, the 8 accumulator registers r = 8h .. 8h+7 of
+// lane (q, g = l >> 5) are exactly keys 16 ks + 8 g + 0..7 -- the B-operand fragment of the P V product
+// O^T[d][q] += V^T[d][key] P^T[key][q].  So P goes from the QK^T accumulators to the PV operand with a
+// pack and no cross-lane traffic, and V^T (written by the QKV GEMM epilogue) is read from LDS as
+// ordinary 16-byte A-operand fragments: no transpose anywhere.
+//
+// K/V arrive as segments (f3r_attn_args.k_seg / vt_seg): the single-GPU path uses one segment, the
+// view-sharded multi-GPU path passes the local shard plus the all-gathered remote shards.
+#include "f3r_common.h"
+
+namespace {
+
+constexpr int AT_NT = 512;
+constexpr int AT_QB = 256;  // queries per workgroup
+constexpr int AT_KB = 64;   // keys per tile
+constexpr int AT_TILE = 64 * 64;
+
+__device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <class T>
+__global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];  // [buf][K | Vt][64][64] = 32 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int lq = lane & 31;
+  const int g = lane >> 5;
+
+  const int head = blockIdx.y;
+  const int b = blockIdx.z;
+  const int64_t q0 = (int64_t)blockIdx.x * AT_QB + wid * 32;
+
+  // ---- Q fragments (B operand of K Q^T): lane (q, g) holds Q[q][ds*16 + g*8 .. +7]
+  const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
+  int64_t qrow = q0 + lq;
+  const bool q_ok = qrow < p.tq;
+  if (!q_ok) qrow = p.tq - 1;
+  typename T::vec8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds)
+    qf[ds] = as_vec8<T>(*(const u32x4*)(Qg + qrow * p.ldq + head * 64 + ds * 16 + g * 8));
+
+  // ---- staging role: one 16 B chunk of the K tile and one of the V^T tile per thread
+  const int srow = tid >> 3;  // key row (K) / d row (V^T)
+  const int sch = tid & 7;
+
+  // flattened (segment, tile) iteration
+  int seg_ld = 0;
+  int64_t tile_ld = 0;  // next tile to load inside seg_ld
+  while (seg_ld < p.n_seg && p.seg_len[seg_ld] <= 0) ++seg_ld;
+
+  u32x4 rk, rv;
+  int valid_ld = 0;  // valid keys of the tile held in (rk, rv)
+  auto load_next = [&]() -> bool {
+    if (seg_ld >= p.n_seg) return false;
+    const int64_t len = p.seg_len[seg_ld];
+    const int64_t key0 = tile_ld * AT_KB;
+    const int64_t rem = len - key0;
+    valid_ld = rem < AT_KB ? (int)rem : AT_KB;
+    const uint16_t* Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld];
+    const uint16_t* Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld];
+    u32x4 z = {0u, 0u, 0u, 0u};
+    rk = z;
+    if (srow < valid_ld) rk = *(const u32x4*)(Kg + (key0 + srow) * p.ldk + head * 64 + sch * 8);
+    // V^T rows are padded to ldvt (multiple of 64, pad zeroed by the host), so the chunk is always in bounds
+    rv = *(const u32x4*)(Vg + ((int64_t)head * 64 + srow) * p.ldvt[seg_ld] + key0 + sch * 8);
+    // advance
+    ++tile_ld;
+    if (tile_ld * AT_KB >= len) {
+      tile_ld = 0;
+      ++seg_ld;
+      while (seg_ld < p.n_seg && p.seg_len[seg_ld] <= 0) ++seg_ld;
+    }
+    return true;
+  };
+  auto store_tile = [&](int buf) {
+    uint16_t* kt = lds + buf * 2 * AT_TILE;
+    uint16_t* vt = kt + AT_TILE;
+    *(u32x4*)(kt + aswz(srow, sch)) = rk;
+    *(u32x4*)(vt + aswz(srow, sch)) = rv;
+  };
+
+  float16v o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -1e30f;  // running max of the raw scores
+  float l_run = 0.f;     // this lane's partial row sum (its own 32 keys per tile)
+  const float c = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*c)
+
+  // pi: swap bits 2 and 3 of the key row index fed to the MFMA A operand
+  const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+
+  bool have = load_next();
+  int valid_cur = valid_ld;
+  if (have) store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  while (have) {
+    const int valid = valid_cur;
+    const bool more = load_next();
+    const uint16_t* kt = lds + cur * 2 * AT_TILE;
+    const uint16_t* vt = kt + AT_TILE;
+
+    // ---- S^T = K Q^T
+    float16v s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(kt + aswz(kb * 32 + krow_pi, ds * 2 + g)));
+        s[kb] = T::mfma32(a, qf[ds], s[kb]);
+      }
+    }
+    // register r of block kb is key  kb*32 + 16*(r>>3) + 8*g + (r&7)  of the tile
+    if (valid < AT_KB) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
+          if (key >= valid) s[kb][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (fp32)
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+    typename T::vec8 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][(ks & 1) * 8 + 2 * j], c, -mc));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][(ks & 1) * 8 + 2 * j + 1], c, -mc));
+        psum += p0 + p1;
+        pk[j] = pack2<T>(p0, p1);
+      }
+      pf[ks] = as_vec8<T>(pk);
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(vt + aswz(db * 32 + lq, ks * 2 + g)));
+        o[db] = T::mfma32(a, pf[ks], o[db]);
+      }
+
+    if (more) store_tile(cur ^ 1);
+    valid_cur = valid_ld;
+    __syncthreads();
+    cur ^= 1;
+    have = more;
+  }
+
+  // ---- epilogue: normalise, store O[q][head*64 + d], d = db*32 + (r&3) + 8*(r>>2) + 4*g
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_ok) {
+    uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow * p.ldo + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 w;
+        w[0] = pack2<T>(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
+        w[1] = pack2<T>(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
+        *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
+  F3R_REQUIRE(args != nullptr, "f3r_attn_fwd: null args");
+  const f3r_attn_args& a = *args;
+  F3R_REQUIRE(a.q && a.o, "f3r_attn_fwd: null q/o");
+  F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_attn_fwd: bad dtype %d", a.dtype);
+  F3R_REQUIRE(a.n_heads > 0 && a.batch > 0 && a.tq >= 0, "f3r_attn_fwd: bad sizes");
+  F3R_REQUIRE(a.n_seg >= 1 && a.n_seg <= F3R_MAX_SEG, "f3r_attn_fwd: n_seg %d out of range", a.n_seg);
+  F3R_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "f3r_attn_fwd: ldq/ldk must be multiples of 8, ldo of 4");
+  F3R_REQUIRE(a.ldq >= a.n_heads * 64 && a.ldk >= a.n_heads * 64 && a.ldo >= a.n_heads * 64, "f3r_attn_fwd: row strides < heads*64");
+  F3R_REQUIRE((((uintptr_t)a.q) & 15) == 0 && (((uintptr_t)a.o) & 7) == 0, "f3r_attn_fwd: q/o alignment");
+  F3R_REQUIRE(a.q_batch_stride % 8 == 0 && a.o_batch_stride % 4 == 0, "f3r_attn_fwd: batch strides alignment");
+  int64_t total = 0;
+  for (int s = 0; s < a.n_seg; ++s) {
+    F3R_REQUIRE(a.seg_len[s] >= 0, "f3r_attn_fwd: negative segment length");
+    if (a.seg_len[s] == 0) continue;
+    F3R_REQUIRE(a.k_seg[s] && a.vt_seg[s], "f3r_attn_fwd: null K/V^T segment %d", s);
+    F3R_REQUIRE((((uintptr_t)a.k_seg[s]) & 15) == 0 && (((uintptr_t)a.vt_seg[s]) & 15) == 0, "f3r_attn_fwd: K/V^T alignment");
+    F3R_REQUIRE(a.ldvt[s] % 64 == 0 && a.ldvt[s] >= a.seg_len[s], "f3r_attn_fwd: ldvt[%d]=%lld must be a multiple of 64 covering the segment (zero padded)", s,
+                (long long)a.ldvt[s]);
+    F3R_REQUIRE(a.k_batch_stride[s] % 8 == 0 && a.vt_batch_stride[s] % 8 == 0, "f3r_attn_fwd: K/V^T batch stride alignment");
+    total += a.seg_len[s];
+  }
+  F3R_REQUIRE(total > 0, "f3r_attn_fwd: no keys");
+  if (a.tq == 0) return F3R_OK;
+  const int64_t qblocks = (a.tq + AT_QB - 1) / AT_QB;
+  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
+  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (a.dtype == F3R_F16)
+    hipLaunchKernelGGL(attn_kernel<F16>, grid, dim3(AT_NT), 0, s, a);
+  else
+    hipLaunchKernelGGL(attn_kernel<BF16>, grid, dim3(AT_NT), 0, s, a);
+  return f3r_check_launch("f3r_attn_fwd");
+}

@@ -1,0 +1,37 @@
+// Host-side glue of libf3r_hip.so: version, per-thread last-error string, launch check.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "f3r_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void f3r_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int f3r_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    f3r_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return F3R_ERR_LAUNCH;
+  }
+  return F3R_OK;
+}
+
+extern "C" int f3r_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* f3r_last_error_string(void) { return g_err; }
+
+extern "C" size_t f3r_sizeof(int what) {
+  switch (what) {
+    case 0: return sizeof(f3r_gemm_args);
+    case 1: return sizeof(f3r_attn_args);
+    default: return 0;
+  }
+}

@@ -1,0 +1,268 @@
+// HBM-bound kernels of the Fast3R path: patchify (im2col for the k=s=16 patch conv), LayerNorm/RMSNorm,
+// bilinear x2 upsample (align_corners=True, NHWC), the fused last 1x1 conv + postprocess, fp32->lowp cast.
+// All of them move 16 bytes per lane per access and keep statistics in fp32.
+#include "f3r_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ patchify
+// one thread = 8 consecutive dx of one (patch, c, dy) row: reads 2 x float4, writes 16 B
+template <class T>
+__global__ void patchify_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int B, int H, int W, int ps,
+                                int64_t n_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_chunks) return;
+  const int cpr = ps / 8;  // chunks per patch row
+  const int K = 3 * ps * ps;
+  const int cpp = K / 8;  // chunks per patch
+  const int64_t patch = i / cpp;
+  const int ck = (int)(i % cpp);
+  const int c = ck / (ps * cpr);
+  const int r2 = ck % (ps * cpr);
+  const int dy = r2 / cpr, dx0 = (r2 % cpr) * 8;
+  const int w = W / ps, h = H / ps;
+  const int b = (int)(patch / ((int64_t)h * w));
+  const int pr = (int)(patch % ((int64_t)h * w));
+  const int py = pr / w, px = pr % w;
+  const float* src = img + (((int64_t)b * 3 + c) * H + (py * ps + dy)) * W + px * ps + dx0;
+  const float4v a = *(const float4v*)src;
+  const float4v bq = *(const float4v*)(src + 4);
+  u32x4 o;
+  o[0] = pack2<T>(a[0], a[1]);
+  o[1] = pack2<T>(a[2], a[3]);
+  o[2] = pack2<T>(bq[0], bq[1]);
+  o[3] = pack2<T>(bq[2], bq[3]);
+  *(u32x4*)(out + patch * K + (int64_t)ck * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------ layernorm
+// one wave per row; D % 4 == 0; float4 loads; two-pass (mean, then centred variance) from registers when
+// D <= 2048 (8 float4 per lane), otherwise re-reads the row.
+template <class T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ out_lp,
+                                                        float* __restrict__ out_f32, int64_t rows, int D, float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  const int nv = D / 4;  // float4 per row
+  float4v v[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      v[i] = *(const float4v*)(xr + idx * 4);
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  const float mean = rms ? 0.f : sum / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4v d = v[i] - mean;
+      sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  const float rstd = rsqrtf(sq / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4v gm = *(const float4v*)(gamma + idx * 4);
+      float4v y = (v[i] - mean) * rstd * gm;
+      if (!rms && beta) y += *(const float4v*)(beta + idx * 4);
+      if (out_f32) *(float4v*)(out_f32 + row * D + idx * 4) = y;
+      if (out_lp) {
+        u32x2 o;
+        o[0] = pack2<T>(y[0], y[1]);
+        o[1] = pack2<T>(y[2], y[3]);
+        *(u32x2*)(out_lp + row * D + idx * 4) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ upsample x2 (align_corners)
+// thread = 8 channels of one output pixel.  src = dst * (in-1)/(out_full-1), out_full = 2*in (F.interpolate
+// scale_factor=2, align_corners=True); the output may be cropped to (oh, ow).
+template <class T>
+__global__ void upsample2x_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int h, int w, int C, int oh,
+                                  int ow, int64_t n_items) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const int cv = C / 8;
+  const int c8 = (int)(i % cv);
+  const int64_t pix = i / cv;
+  const int ox = (int)(pix % ow);
+  const int oy = (int)((pix / ow) % oh);
+  const int b = (int)(pix / ((int64_t)ow * oh));
+  const float sy = (h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+  const float sx = (w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  const float fy = sy * (float)oy, fx = sx * (float)ox;
+  int y0 = (int)fy, x0 = (int)fx;
+  if (y0 > h - 1) y0 = h - 1;
+  if (x0 > w - 1) x0 = w - 1;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const uint16_t* base = in + (int64_t)b * h * w * C + c8 * 8;
+  const u32x4 p00 = *(const u32x4*)(base + ((int64_t)y0 * w + x0) * C);
+  const u32x4 p01 = *(const u32x4*)(base + ((int64_t)y0 * w + x1) * C);
+  const u32x4 p10 = *(const u32x4*)(base + ((int64_t)y1 * w + x0) * C);
+  const u32x4 p11 = *(const u32x4*)(base + ((int64_t)y1 * w + x1) * C);
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // torch's upsample_bilinear2d: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
+    const float a = hy * (hx * lo_f<T>(p00[k]) + lx * lo_f<T>(p01[k])) + ly * (hx * lo_f<T>(p10[k]) + lx * lo_f<T>(p11[k]));
+    const float bq = hy * (hx * hi_f<T>(p00[k]) + lx * hi_f<T>(p01[k])) + ly * (hx * hi_f<T>(p10[k]) + lx * hi_f<T>(p11[k]));
+    o[k] = pack2<T>(a, bq);
+  }
+  *(u32x4*)(out + pix * C + c8 * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------ final 1x1 conv + postprocess
+// thread = one pixel: 4 dot products over Cin (weights through LDS), then
+//   d = |xyz|, pts = xyz / max(d, 1e-8) * expm1(d), conf = vmin + min(exp(c), vmax - vmin)   (postprocess.py:32-61)
+template <class T>
+__global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
+                                                        int64_t npix, int Cin, float vmin, float vmax) {
+  extern __shared__ float wsh[];  // [4][Cin]
+  for (int i = threadIdx.x; i < 4 * Cin; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  float a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = bias[3];
+  const uint16_t* xp = x + pix * Cin;
+  for (int c = 0; c < Cin; c += 8) {
+    const u32x4 v = *(const u32x4*)(xp + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float f0 = lo_f<T>(v[k]), f1 = hi_f<T>(v[k]);
+      const int cc = c + 2 * k;
+      a0 = __builtin_fmaf(f0, wsh[cc], a0);            a0 = __builtin_fmaf(f1, wsh[cc + 1], a0);
+      a1 = __builtin_fmaf(f0, wsh[Cin + cc], a1);      a1 = __builtin_fmaf(f1, wsh[Cin + cc + 1], a1);
+      a2 = __builtin_fmaf(f0, wsh[2 * Cin + cc], a2);  a2 = __builtin_fmaf(f1, wsh[2 * Cin + cc + 1], a2);
+      a3 = __builtin_fmaf(f0, wsh[3 * Cin + cc], a3);  a3 = __builtin_fmaf(f1, wsh[3 * Cin + cc + 1], a3);
+    }
+  }
+  const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+  pts[pix * 3 + 0] = a0 * sc;
+  pts[pix * 3 + 1] = a1 * sc;
+  pts[pix * 3 + 2] = a2 * sc;
+  if (conf) conf[pix] = vmin + fminf(expf(a3), vmax - vmin);
+}
+
+template <class T>
+__global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4v a = *(const float4v*)(in + i * 8);
+  const float4v b = *(const float4v*)(in + i * 8 + 4);
+  u32x4 o;
+  o[0] = pack2<T>(a[0], a[1]);
+  o[1] = pack2<T>(a[2], a[3]);
+  o[2] = pack2<T>(b[0], b[1]);
+  o[3] = pack2<T>(b[2], b[3]);
+  *(u32x4*)(out + i * 8) = o;
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+#define F3R_DTYPE_OK(dt) F3R_REQUIRE((dt) == F3R_F16 || (dt) == F3R_BF16, "bad dtype %d", (dt))
+
+extern "C" int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(img && out && al16(img) && al16(out), "f3r_patchify: null/misaligned pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(ps > 0 && ps % 8 == 0, "f3r_patchify: patch size %d must be a multiple of 8", ps);
+  F3R_REQUIRE(H % ps == 0 && W % ps == 0 && batch >= 0, "f3r_patchify: H/W (%d,%d) not multiples of the patch size %d", H, W, ps);
+  const int64_t n = (int64_t)batch * (H / ps) * (W / ps) * (3 * ps * ps / 8);
+  if (n == 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == F3R_F16)
+    hipLaunchKernelGGL(patchify_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
+  else
+    hipLaunchKernelGGL(patchify_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
+  return f3r_check_launch("f3r_patchify");
+}
+
+extern "C" int f3r_layernorm(const float* x, const float* gamma, const float* beta, void* out_lp, float* out_f32, int64_t rows, int D,
+                             float eps, int rms, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(x && gamma && (out_lp || out_f32), "f3r_layernorm: null pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "f3r_layernorm: D %d must be a multiple of 4, <= 8192", D);
+  F3R_REQUIRE(al16(x) && al16(gamma) && (!beta || al16(beta)) && (!out_f32 || al16(out_f32)) && (!out_lp || (((uintptr_t)out_lp) & 7) == 0),
+              "f3r_layernorm: misaligned pointer");
+  if (rows <= 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = nblk(rows, 4);
+#define LN_LAUNCH(TT, MV) \
+  hipLaunchKernelGGL((layernorm_kernel<TT, MV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, (uint16_t*)out_lp, out_f32, rows, D, eps, rms)
+  const int nv = (D / 4 + 63) / 64;
+  if (dtype == F3R_F16) {
+    if (nv <= 4) LN_LAUNCH(F16, 4); else if (nv <= 8) LN_LAUNCH(F16, 8); else LN_LAUNCH(F16, 32);
+  } else {
+    if (nv <= 4) LN_LAUNCH(BF16, 4); else if (nv <= 8) LN_LAUNCH(BF16, 8); else LN_LAUNCH(BF16, 32);
+  }
+#undef LN_LAUNCH
+  return f3r_check_launch("f3r_layernorm");
+}
+
+extern "C" int f3r_upsample2x(const void* in, void* out, int batch, int h, int w, int C, int out_h, int out_w, int dtype,
+                              f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && al16(in) && al16(out), "f3r_upsample2x: null/misaligned pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(C > 0 && C % 8 == 0, "f3r_upsample2x: C %d must be a multiple of 8", C);
+  F3R_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= 2 * h && out_w <= 2 * w, "f3r_upsample2x: bad sizes");
+  const int64_t n = (int64_t)batch * out_h * out_w * (C / 8);
+  if (n <= 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == F3R_F16)
+    hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, batch, h, w, C, out_h, out_w, n);
+  else
+    hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, batch, h, w, C, out_h, out_w, n);
+  return f3r_check_launch("f3r_upsample2x");
+}
+
+extern "C" int f3r_dpt_final(const void* x, const float* w, const float* b, float* pts3d, float* conf, int64_t npix, int Cin,
+                             float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(x && w && b && pts3d && al16(x), "f3r_dpt_final: null/misaligned pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cin <= 2048, "f3r_dpt_final: Cin %d must be a multiple of 8, <= 2048", Cin);
+  if (npix <= 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t sh = (size_t)4 * Cin * sizeof(float);
+  if (dtype == F3R_F16)
+    hipLaunchKernelGGL(dpt_final_kernel<F16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, w, b, pts3d, conf, npix, Cin, conf_vmin, conf_vmax);
+  else
+    hipLaunchKernelGGL(dpt_final_kernel<BF16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, w, b, pts3d, conf, npix, Cin, conf_vmin, conf_vmax);
+  return f3r_check_launch("f3r_dpt_final");
+}
+
+extern "C" int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && al16(in) && al16(out), "f3r_cast_f32_to_lp: null/misaligned pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(n >= 0 && n % 8 == 0, "f3r_cast_f32_to_lp: n %lld must be a multiple of 8", (long long)n);
+  if (n == 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == F3R_F16)
+    hipLaunchKernelGGL(cast_kernel<F16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, n / 8);
+  else
+    hipLaunchKernelGGL(cast_kernel<BF16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, n / 8);
+  return f3r_check_launch("f3r_cast_f32_to_lp");
+}

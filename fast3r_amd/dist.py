@@ -1,0 +1,111 @@
+"""View-sharded multi-GPU execution of the fusion transformer (one process per GPU, RCCL over xGMI).
+
+The reference has no multi-GPU inference at all: this is new design.  Views shard
+naturally -- the encoder, every LayerNorm / Linear / MLP of the fusion blocks and both DPT heads are token- or
+view-local -- and only softmax(Q K^T) V couples views.  Rank r owns a contiguous range of views, i.e. a
+contiguous range of token rows; per fusion layer it contributes its K [T_r][D] and V^T [D][T_r] and needs
+everybody else's.  The exchange is ONE all-gather per tensor per layer (24 x 2 per forward) of equal-size padded
+buffers; the attention kernel then walks the R segments in rank order (f3r_attn_args.k_seg / vt_seg), which is
+the same key order the single-GPU kernel sees, so sharded == unsharded up to the tile boundaries of the online
+softmax.  xGMI is point-to-point (7 links per GPU), so a direct all-gather uses every link at once; at N=320 /
+8 GPUs a layer moves 7 x 168 MB into each GPU (~1.1 ms at 153 GB/s per link) against >= 22 ms of attention math.
+
+Nothing else crosses GPUs: image ids are drawn once on rank 0 and broadcast (the reference's `seed + rank`
+recipe, fast3r.py:707-708, assumes data parallelism over *samples* and would give every shard different ids).
+
+The host logic below is device-agnostic: it runs unchanged over gloo on CPU tensors, which is how
+tests/test_dist_gloo.py covers it (the attention math in that test is done by the oracle as the checker).
+"""
+import torch
+import torch.distributed as dist
+
+
+def split_range(n_items: int, world: int, rank: int):
+    """Contiguous, balanced split: the first n % world ranks own one extra item."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class KVExchange:
+    """Per-forward send/receive buffers for the per-layer K / V^T all-gather (allocated once, reused by all layers)."""
+
+    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device):
+        self.group, self.world, self.rank = group, world, rank
+        self.t_loc, self.t_all, self.D = t_loc, list(t_all), D
+        t_max = max(self.t_all)
+        self.t_max = t_max
+        self.ldvt = _round_up(t_max, 64)
+        # local shard is written in place by the QKV GEMM epilogue; padding rows/columns stay zero forever
+        self.k_loc = torch.zeros((t_max, D), dtype=dtype, device=device)
+        self.vt_loc = torch.zeros((1, D, self.ldvt), dtype=dtype, device=device)
+        self.k_all = torch.empty((world, t_max, D), dtype=dtype, device=device)
+        self.vt_all = torch.empty((world, D, self.ldvt), dtype=dtype, device=device)
+
+    def _all_gather(self, out2d, in2d):
+        """RCCL moves device buffers directly.  Any other backend (gloo: CPU tests, and the 2-process single-GPU
+        test) goes through host staging -- a transport detail, the segments handed to the kernel are the same."""
+        if out2d.is_cuda and dist.get_backend(self.group) != "nccl":
+            o, i = torch.empty(out2d.shape, dtype=out2d.dtype), in2d.cpu()
+            dist.all_gather_into_tensor(o, i, group=self.group)
+            out2d.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out2d, in2d, group=self.group)
+
+    def exchange(self):
+        """All-gather this layer's K and V^T; returns the attention segments in rank order:
+        [(k [T_r][D], vt [D][ldvt], T_r, k_batch_stride, vt_batch_stride)]."""
+        self._all_gather(self.k_all.view(self.world * self.t_max, self.D), self.k_loc)
+        self._all_gather(self.vt_all.view(self.world * self.D, self.ldvt), self.vt_loc.view(self.D, self.ldvt))
+        return [(self.k_all[r], self.vt_all[r], self.t_all[r], 0, 0) for r in range(self.world) if self.t_all[r] > 0]
+
+
+class ViewSharding:
+    def __init__(self, process_group=None, gather_outputs=False):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("ViewSharding needs an initialised torch.distributed process group (RCCL: backend 'nccl')")
+        self.group = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world = dist.get_world_size(process_group)
+        self.gather_outputs = gather_outputs
+        if self.world > 8:
+            raise ValueError("the attention kernel takes at most 8 K/V segments (one MI355X node)")
+
+    def my_range(self, n_views):
+        return split_range(n_views, self.world, self.rank)
+
+    def _comm_device(self, dev):
+        return dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def broadcast_ids(self, ids, dev):
+        """Rank 0's image ids win (every rank still consumed its own global-RNG draw, like one reference forward)."""
+        t = ids.to(self._comm_device(dev)).contiguous()
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return t.cpu()
+
+    def all_token_counts(self, t_loc, dev):
+        cd = self._comm_device(dev)
+        mine = torch.tensor([t_loc], dtype=torch.int64, device=cd)
+        out = torch.empty((self.world,), dtype=torch.int64, device=cd)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        return [int(v) for v in out.cpu().tolist()]
+
+    def make_kv_exchange(self, t_loc, D, dtype, dev):
+        return KVExchange(self.group, self.world, self.rank, t_loc, self.all_token_counts(t_loc, dev), D, dtype, dev)
+
+    def gather_results(self, results, n_total, dev):
+        """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with
+        gather_outputs=True every rank receives all N dicts (N x 8.4 MB of fp32 at 512^2)."""
+        if not self.gather_outputs:
+            return results
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, [{k: v.cpu() for k, v in r.items()} for r in results], group=self.group)
+        out = []
+        for part in gathered:
+            out.extend([{k: v.to(dev) for k, v in r.items()} for r in part])
+        assert len(out) == n_total
+        return out

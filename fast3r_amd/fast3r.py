@@ -1,0 +1,592 @@
+"""Fast3R on MI355X: the reference's model API (fast3r/models/fast3r.py) executed by hand-written HIP kernels.
+
+Drop-in surface kept from the reference (file:line = /root/reference/fast3r/models/fast3r.py):
+  Fast3R(encoder_args, decoder_args, head_args, freeze="none")       :50-70
+  Fast3R.forward(views, profiling=False) -> list[dict] | (list, dict) :302-497
+  Fast3R.set_max_parallel_views_for_head(int)                         :298-300
+  attributes encoder_args / decoder_args / head_args, .encoder / .decoder / .downstream_head[_local]
+  state_dict(): identical keys and shapes, so `load_state_dict(ref.state_dict(), strict=True)`
+  works, including the duplicated `scratch.layer_rn.{i}` aliases (croco/models/dpt_block.py:79-86).
+
+What is different by design: torch.nn modules are used ONLY as parameter containers (names, shapes, device moves);
+none of their forward() methods is ever called.  All arithmetic goes through fast3r_amd.ops -> libf3r_hip.so.  The
+residual stream, LayerNorm statistics, softmax and post-processing are fp32; GEMM / conv / attention operands are
+16-bit (`compute_dtype`, fp16 by default, bf16 selectable) with fp32 MFMA accumulation.  There is no CPU path.
+"""
+import math
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import F3RError
+from .dist import ViewSharding
+
+
+# ======================================================================================= parameter containers
+class _Params(nn.Module):
+    """A module that only owns parameters; calling it is a bug (the compute lives in the HIP engine)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise F3RError("fast3r_amd parameter containers are not callable; use Fast3R.forward")
+
+
+class _Attention(_Params):
+    def __init__(self, dim, qkv_bias=True):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)  # blocks.py:125
+        self.proj = nn.Linear(dim, dim)                    # blocks.py:128
+
+
+class _Mlp(_Params):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)  # blocks.py:94
+        self.fc2 = nn.Linear(hidden, dim)  # blocks.py:97
+
+
+class _Block(_Params):
+    def __init__(self, dim, mlp_ratio, eps, qkv_bias=True):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)  # blocks.py:214
+        self.attn = _Attention(dim, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)  # blocks.py:227
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _PatchEmbed(_Params):
+    def __init__(self, patch_size, dim):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch_size, stride=patch_size)  # blocks.py:412-414
+        self.norm = nn.Identity()
+
+
+class CroCoEncoder(_Params):
+    """fast3r.py:499-559.  RoPE-2D (freq from 'RoPE<freq>'), LayerNorm eps 1e-6."""
+
+    def __init__(self, img_size=512, patch_size=16, patch_embed_cls="ManyAR_PatchEmbed", embed_dim=768, num_heads=12,
+                 depth=12, mlp_ratio=4, pos_embed="RoPE100", attn_implementation="pytorch_naive"):
+        super().__init__()
+        assert patch_embed_cls in ["PatchEmbedDust3R", "ManyAR_PatchEmbed"]  # patch_embed.py:19
+        if not pos_embed.startswith("RoPE"):
+            raise NotImplementedError("Unknown pos_embed " + pos_embed)  # fast3r.py:533
+        if attn_implementation not in ("pytorch_naive", "flash_attention", "pytorch_auto"):
+            raise ValueError(f"Unknown attn_implementation: {attn_implementation}")  # blocks.py:192
+        if embed_dim % num_heads != 0 or embed_dim // num_heads != 64:
+            raise ValueError("fast3r_amd kernels are built for head_dim 64 (ViT-B/L/H family)")
+        self.patch_embed_cls = patch_embed_cls
+        self.patch_size, self.embed_dim, self.num_heads, self.depth = patch_size, embed_dim, num_heads, depth
+        self.pos_embed = pos_embed
+        self.rope_freq = float(pos_embed[len("RoPE"):])
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        self.enc_blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, 1e-6) for _ in range(depth)])
+        self.enc_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+
+
+def sincos_1d_table(embed_dim, n_pos):
+    """get_1d_sincos_pos_embed_from_grid (croco/models/pos_embed.py:58-76): [sin | cos], float64 -> float32."""
+    omega = np.arange(embed_dim // 2, dtype=float)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", np.arange(n_pos).reshape(-1).astype(float), omega)
+    return torch.from_numpy(np.concatenate([np.sin(out), np.cos(out)], axis=1)).float()
+
+
+class Fast3RDecoder(_Params):
+    """fast3r.py:654-808.  No RoPE; additive image-index embedding; block LayerNorm eps 1e-5, dec_norm 1e-6."""
+
+    def __init__(self, random_image_idx_embedding, enc_embed_dim, embed_dim=768, num_heads=12, depth=12, mlp_ratio=4.0,
+                 qkv_bias=True, drop=0.0, attn_drop=0.0, attn_implementation="pytorch_naive",
+                 attn_bias_for_inference_enabled=True, max_image_idx=1000):
+        super().__init__()
+        if attn_implementation not in ("pytorch_naive", "flash_attention", "pytorch_auto"):
+            raise ValueError(f"Unknown attn_implementation: {attn_implementation}")
+        if embed_dim // num_heads != 64:
+            raise ValueError("fast3r_amd kernels are built for head_dim 64")
+        self.embed_dim, self.num_heads, self.depth = embed_dim, num_heads, depth
+        self.random_image_idx_embedding = random_image_idx_embedding
+        self.attn_bias_for_inference_enabled = attn_bias_for_inference_enabled
+        self.decoder_embed = nn.Linear(enc_embed_dim, embed_dim, bias=True)
+        self.dec_blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, 1e-5, qkv_bias) for _ in range(depth)])
+        # The reference table has 1000 rows (fast3r.py:691-697) and therefore fails for N > 1000 views
+        # (SURVEY.md section 0.7).  Same formula, more rows when asked for: ids < 1000 are bit-identical.
+        self.register_buffer("image_idx_emb", sincos_1d_table(embed_dim, max_image_idx), persistent=False)
+        self.dec_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+
+    def attention_scale(self, training: bool) -> float:
+        """blocks.py:116-124,151-154."""
+        hd = self.embed_dim // self.num_heads
+        if (not training) and self.attn_bias_for_inference_enabled:
+            return hd ** -0.5 * (1.0 * math.log(137) / math.log(20)) ** 0.5
+        return hd ** -0.5
+
+    def draw_image_ids(self, batch_size, num_views, rank=0):
+        """fast3r.py:702-743 (_generate_per_rank_generator + _get_random_image_pos), or 0..N-1 (fast3r.py:339-348,794-796).
+        Consumes exactly one value of the global torch CPU RNG when random ids are on, like the reference."""
+        if not self.random_image_idx_embedding:
+            return torch.arange(num_views)[None].repeat(batch_size, 1)
+        max_image_idx = self.image_idx_emb.shape[0] - 1
+        if num_views - 1 > max_image_idx:
+            raise ValueError(f"{num_views} views need an image-index table of at least {num_views} rows "
+                             f"(have {max_image_idx + 1}); build the decoder with max_image_idx >= {num_views}")
+        seed = torch.randint(0, 2 ** 32, (1,)).item()
+        g = torch.Generator()
+        g.manual_seed(seed + rank)
+        ids = torch.zeros(batch_size, num_views, dtype=torch.long)
+        for b in range(batch_size):
+            ids[b, 1:] = torch.randperm(max_image_idx, generator=g)[: num_views - 1] + 1
+        return ids
+
+
+class _RCU(_Params):
+    def __init__(self, f):
+        super().__init__()
+        self.conv1 = nn.Conv2d(f, f, 3, padding=1)  # dpt_block.py:105-123
+        self.conv2 = nn.Conv2d(f, f, 3, padding=1)
+
+
+class _Fusion(_Params):
+    def __init__(self, f):
+        super().__init__()
+        self.out_conv = nn.Conv2d(f, f, 1)  # dpt_block.py:180-188
+        self.resConfUnit1 = _RCU(f)
+        self.resConfUnit2 = _RCU(f)
+
+
+class _DPT(_Params):
+    """Parameter layout of DPTOutputAdapter_fix (heads/dpt_head.py:28-40; croco/models/dpt_block.py:315-490)."""
+
+    def __init__(self, num_channels, feature_dim, last_dim, hooks, dim_tokens, patch_size, layer_dims=(96, 192, 384, 768)):
+        super().__init__()
+        self.hooks, self.patch_size, self.num_channels = hooks, patch_size, num_channels
+        self.feature_dim, self.last_dim, self.layer_dims = feature_dim, last_dim, list(layer_dims)
+        ld = layer_dims
+        scratch = _Params()
+        for i in range(4):
+            setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(ld[i], feature_dim, 3, padding=1, bias=False))
+        scratch.layer_rn = nn.ModuleList([getattr(scratch, f"layer{i + 1}_rn") for i in range(4)])  # aliases
+        for i in range(1, 5):
+            setattr(scratch, f"refinenet{i}", _Fusion(feature_dim))
+        self.scratch = scratch
+        self.head = nn.Sequential(nn.Conv2d(feature_dim, feature_dim // 2, 3, padding=1), nn.Identity(),
+                                  nn.Conv2d(feature_dim // 2, last_dim, 3, padding=1), nn.Identity(),
+                                  nn.Conv2d(last_dim, num_channels, 1))
+        self.act_postprocess = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(dim_tokens[0], ld[0], 1), nn.ConvTranspose2d(ld[0], ld[0], 4, stride=4)),
+            nn.Sequential(nn.Conv2d(dim_tokens[1], ld[1], 1), nn.ConvTranspose2d(ld[1], ld[1], 2, stride=2)),
+            nn.Sequential(nn.Conv2d(dim_tokens[2], ld[2], 1)),
+            nn.Sequential(nn.Conv2d(dim_tokens[3], ld[3], 1), nn.Conv2d(ld[3], ld[3], 3, stride=2, padding=1)),
+        ])
+
+
+class PixelwiseTaskWithDPT(_Params):
+    """heads/dpt_head.py:93-129 (parameters under `.dpt`)."""
+
+    def __init__(self, *, hooks_idx, dim_tokens, num_channels, feature_dim, last_dim, patch_size, depth_mode, conf_mode):
+        super().__init__()
+        self.depth_mode, self.conf_mode = depth_mode, conf_mode
+        self.dpt = _DPT(num_channels, feature_dim, last_dim, hooks_idx, dim_tokens, patch_size)
+
+
+# ======================================================================================= packed (device) weights
+class _PackedBlock:
+    __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+def _f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _pack_block(blk: _Block, lp):
+    p = _PackedBlock()
+    p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
+    p.eps = blk.norm1.eps
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp), _f32(blk.attn.qkv.bias)
+    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp), _f32(blk.attn.proj.bias)
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp), _f32(blk.mlp.fc1.bias)
+    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp), _f32(blk.mlp.fc2.bias)
+    return p
+
+
+class _PackedHead:
+    pass
+
+
+def _pack_head(head: PixelwiseTaskWithDPT, lp):
+    d = head.dpt
+    h = _PackedHead()
+    ap = d.act_postprocess
+    h.a_w = [ops.pack_linear_weight(ap[i][0].weight.detach().float(), lp) for i in range(4)]
+    h.a_b = [_f32(ap[i][0].bias) for i in range(4)]
+    h.t0_w, h.t0_b = ops.pack_convT_weight(ap[0][1].weight.detach().float(), ap[0][1].bias.detach(), lp)
+    h.t1_w, h.t1_b = ops.pack_convT_weight(ap[1][1].weight.detach().float(), ap[1][1].bias.detach(), lp)
+    h.c3_w, h.c3_b = ops.pack_conv3x3_weight(ap[3][1].weight.detach().float(), lp), _f32(ap[3][1].bias)
+    h.rn_w = [ops.pack_conv3x3_weight(getattr(d.scratch, f"layer{i + 1}_rn").weight.detach().float(), lp) for i in range(4)]
+    h.ref = []
+    for i in range(1, 5):
+        r = getattr(d.scratch, f"refinenet{i}")
+        h.ref.append(dict(
+            u1c1=(ops.pack_conv3x3_weight(r.resConfUnit1.conv1.weight.detach().float(), lp), _f32(r.resConfUnit1.conv1.bias)),
+            u1c2=(ops.pack_conv3x3_weight(r.resConfUnit1.conv2.weight.detach().float(), lp), _f32(r.resConfUnit1.conv2.bias)),
+            u2c1=(ops.pack_conv3x3_weight(r.resConfUnit2.conv1.weight.detach().float(), lp), _f32(r.resConfUnit2.conv1.bias)),
+            u2c2=(ops.pack_conv3x3_weight(r.resConfUnit2.conv2.weight.detach().float(), lp), _f32(r.resConfUnit2.conv2.bias)),
+            out=(ops.pack_linear_weight(r.out_conv.weight.detach().float(), lp), _f32(r.out_conv.bias))))
+    h.h0_w, h.h0_b = ops.pack_conv3x3_weight(d.head[0].weight.detach().float(), lp), _f32(d.head[0].bias)
+    h.h2_w, h.h2_b = ops.pack_conv3x3_weight(d.head[2].weight.detach().float(), lp), _f32(d.head[2].bias)
+    h.h4_w = d.head[4].weight.detach().float().reshape(d.num_channels, -1).contiguous()
+    h.h4_b = _f32(d.head[4].bias)
+    h.dims = d.layer_dims
+    h.feature_dim, h.last_dim, h.num_channels, h.patch_size = d.feature_dim, d.last_dim, d.num_channels, d.patch_size
+    h.depth_mode, h.conf_mode = head.depth_mode, head.conf_mode
+    return h
+
+
+# ======================================================================================= the model
+class Fast3R(nn.Module):
+    def __init__(self, encoder_args: dict, decoder_args: dict, head_args: dict, freeze="none",
+                 compute_dtype: torch.dtype = torch.float16):
+        super().__init__()
+        self.encoder_args = dict(encoder_args)
+        self.build_encoder(encoder_args)
+        self.decoder_args = dict(decoder_args)
+        self.build_decoder(decoder_args)
+        self.head_args = dict(head_args)
+        self.build_head(head_args)
+        self.max_parallel_views_for_head = 25  # fast3r.py:68
+        self.max_parallel_views_for_encoder = 128  # the reference chunks at 400 (fast3r.py:250); bounds the workspace
+        self.compute_dtype = compute_dtype
+        self.sharding = None  # set by shard_views(): view-sharded multi-GPU execution (fast3r_amd/dist.py)
+        self._packed = None
+        self._rope_cache = {}
+        self.set_freeze(freeze)
+
+    # ---------------------------------------------------------------- construction (fast3r.py:72-157)
+    def build_encoder(self, encoder_args):
+        if encoder_args["encoder_type"] == "croco":
+            a = deepcopy(dict(encoder_args))
+            a.pop("encoder_type")
+            self.encoder = CroCoEncoder(**a)
+        elif encoder_args["encoder_type"] == "dino_v2":
+            raise ValueError("fast3r_amd: encoder_type 'dino_v2' is outside the MI355X hot path (SURVEY.md section 2.1 #2)")
+        else:
+            raise ValueError(f"Unsupported encoder type: {encoder_args['encoder_type']}")
+
+    def build_decoder(self, decoder_args):
+        dt = decoder_args.get("decoder_type", "fast3r")
+        self.decoder_args["decoder_type"] = dt
+        if dt == "fast3r":
+            a = deepcopy(dict(decoder_args))
+            a.pop("decoder_type", None)
+            self.decoder = Fast3RDecoder(**a)
+        elif dt == "llama":
+            raise ValueError("fast3r_amd: decoder_type 'llama' is outside the MI355X hot path (SURVEY.md section 2.1 #2)")
+        else:
+            raise ValueError(f"Unsupported decoder type: {dt}")
+
+    def build_head(self, head_args):
+        self.output_mode, self.head_type = head_args["output_mode"], head_args["head_type"]
+        self.depth_mode, self.conf_mode = head_args["depth_mode"], head_args["conf_mode"]
+        mk = lambda: self.head_factory(head_args["head_type"], head_args["output_mode"], has_conf=bool(head_args["conf_mode"]),
+                                       patch_size=head_args["patch_size"])
+        self.downstream_head = mk()
+        self.downstream_head_local = mk() if head_args.get("with_local_head", False) else None
+        self.landscape_only = bool(head_args.get("landscape_only", False))
+
+    # `.head` / `.local_head` of the reference are closures over the two heads (utils/misc.py:61-106), not modules:
+    # expose the names without registering the heads a second time (state_dict keys must not change).
+    @property
+    def head(self):
+        return self.downstream_head
+
+    @property
+    def local_head(self):
+        return self.downstream_head_local
+
+    def head_factory(self, head_type, output_mode, has_conf=False, patch_size=16):
+        if head_type == "dpt" and output_mode == "pts3d":
+            assert self.decoder_args["depth"] > 9  # fast3r.py:137
+            l2 = self.decoder_args["depth"]
+            ed, dd = self.encoder_args["embed_dim"], self.decoder_args["embed_dim"]
+            if tuple(self.head_args["depth_mode"])[0] != "exp" or (self.head_args["conf_mode"] and tuple(self.head_args["conf_mode"])[0] != "exp"):
+                raise NotImplementedError("fast3r_amd: only depth_mode/conf_mode 'exp' (the released configuration) are fused")
+            return PixelwiseTaskWithDPT(num_channels=3 + has_conf, feature_dim=256, last_dim=128,
+                                        hooks_idx=[0, l2 * 2 // 4, l2 * 3 // 4, l2], dim_tokens=[ed, dd, dd, dd],
+                                        patch_size=patch_size, depth_mode=self.head_args["depth_mode"],
+                                        conf_mode=self.head_args["conf_mode"])
+        raise NotImplementedError(f"unexpected {head_type=} and {output_mode=}")  # fast3r.py:157
+
+    def set_freeze(self, freeze):
+        self.freeze = freeze
+        todo = {"none": [], "encoder": [self.encoder], "sandwich": [self.encoder, self.downstream_head]}[freeze]
+        for m in todo:
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def set_max_parallel_views_for_head(self, n):
+        self.max_parallel_views_for_head = n
+
+    def shard_views(self, process_group=None):
+        """Enable the view-sharded multi-GPU path: this rank encodes / decodes / regresses only its contiguous range of
+        views and exchanges K / V^T per fusion layer with an RCCL all-gather (fast3r_amd/dist.py)."""
+        self.sharding = ViewSharding(process_group)
+        return self
+
+    # ---------------------------------------------------------------- packed weights
+    def load_state_dict(self, ckpt, **kw):
+        self._packed = None
+        return super().load_state_dict(ckpt, **kw)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def invalidate_packed_weights(self):
+        self._packed = None
+
+    def _pack(self, device):
+        lp = self.compute_dtype
+        key = (lp, str(device))
+        if self._packed is not None and self._packed["key"] == key:
+            return self._packed
+        enc, dec = self.encoder, self.decoder
+        pk = dict(key=key)
+        pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp)
+        pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
+        pk["enc"] = [_pack_block(b, lp) for b in enc.enc_blocks]
+        pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
+        pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp)
+        pk["de_b"] = _f32(dec.decoder_embed.bias)
+        pk["dec"] = [_pack_block(b, lp) for b in dec.dec_blocks]
+        pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
+        pk["head"] = _pack_head(self.downstream_head, lp)
+        pk["head_local"] = _pack_head(self.downstream_head_local, lp) if self.downstream_head_local is not None else None
+        self._packed = pk
+        return pk
+
+    def _rope(self, n_pos, device):
+        key = (n_pos, str(device))
+        if key not in self._rope_cache:
+            self._rope_cache[key] = ops.rope_tables(n_pos, self.encoder.rope_freq, device)
+        return self._rope_cache[key]
+
+    # ---------------------------------------------------------------- transformer block on the HIP kernels
+    def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None):
+        """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239."""
+        lp = self.compute_dtype
+        D = x.shape[1]
+        T = x.shape[0]
+        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp)
+        q = torch.empty((T, D), dtype=lp, device=x.device)
+        if kv_exchange is None:
+            k = torch.empty((T, D), dtype=lp, device=x.device)
+            ldvt = ops.vt_ld(seq_len)
+            vt = torch.zeros((n_seq, D, ldvt), dtype=lp, device=x.device) if ldvt != seq_len else \
+                torch.empty((n_seq, D, ldvt), dtype=lp, device=x.device)
+        else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
+            k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
+        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope)
+        if kv_exchange is None:
+            segs = [(k, vt, seq_len, seq_len * D, D * ldvt)]
+        else:
+            segs = kv_exchange.exchange()
+        o = h  # LN output is dead: reuse as the attention output buffer
+        ops.attention(q, o, n_heads, scale, segs, tq=seq_len, batch=n_seq, q_batch_stride=seq_len * D, o_batch_stride=seq_len * D)
+        ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x)
+        h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o)
+        _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)
+        ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x)
+        return x
+
+    def _encode(self, imgs, pk):
+        """CroCoEncoder.forward (fast3r.py:549-559) for a batch of same-size images -> lowp enc_norm output [NV*P][D]."""
+        lp = self.compute_dtype
+        enc = self.encoder
+        NV, _, H, W = imgs.shape
+        ps = enc.patch_size
+        assert H % ps == 0, f"Input image height ({H}) is not a multiple of patch size ({ps})."  # patch_embed.py:27-32
+        assert W % ps == 0, f"Input image width ({W}) is not a multiple of patch size ({ps})."
+        h, w = H // ps, W // ps
+        P = h * w
+        rope = self._rope(max(h, w), imgs.device) + (w,)
+        out = torch.empty((NV * P, enc.embed_dim), dtype=lp, device=imgs.device)
+        step = max(1, self.max_parallel_views_for_encoder)
+        for v0 in range(0, NV, step):
+            v1 = min(NV, v0 + step)
+            a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp)
+            x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True)
+            for pb in pk["enc"]:
+                self._block(x, pb, enc.num_heads, (enc.embed_dim // enc.num_heads) ** -0.5, P, v1 - v0, rope)
+            w_, b_, eps = pk["enc_norm"]
+            ops.layernorm(x, w_, b_, eps, lp, out_lp=out[v0 * P:v1 * P])
+        return out, P, (h, w)
+
+    # ---------------------------------------------------------------- DPT head on the HIP kernels
+    def _dpt(self, hk, toks, nv, gh, gw):
+        """DPTOutputAdapter_fix.forward + postprocess (heads/dpt_head.py:42-129) for nv same-size views.
+        toks: the 4 hooked token matrices, lowp [nv*gh*gw][C].  Everything stays NHWC lowp; accumulation fp32."""
+        P = gh * gw
+        ld = hk.dims
+
+        def c1(i):
+            _, y = ops.gemm(toks[i], hk.a_w[i], bias=hk.a_b[i], want_lp=True)
+            return y.view(nv, gh, gw, ld[i])
+
+        l0 = ops.convT(c1(0), hk.t0_w, hk.t0_b, 4, ld[0])                              # dpt_block.py:416-434
+        l1 = ops.convT(c1(1), hk.t1_w, hk.t1_b, 2, ld[1])                              # :436-454
+        l2 = c1(2)                                                                      # :456-464
+        l3 = ops.conv3x3(c1(3), hk.c3_w, stride=2, bias=hk.c3_b)                        # :466-481
+        ls = [ops.conv3x3(l, hk.rn_w[i]) for i, l in enumerate((l0, l1, l2, l3))]       # scratch.layer_rn, no bias
+        del l0, l1, l2, l3
+
+        def rcu(x, c1w, c2w, extra=None):
+            # x + conv2(relu(conv1(relu(x)))) (+ extra): ReLUs fused into the operand staging, adds into the epilogue
+            t = ops.conv3x3(x, c1w[0], bias=c1w[1], a_relu=True)
+            return ops.conv3x3(t, c2w[0], bias=c2w[1], a_relu=True, res_lp=x, res_lp2=extra)
+
+        def fusion(r, path, skip=None, crop=None):
+            # out_conv(up2(RCU2(path + RCU1(skip)))); the 1x1 out_conv commutes exactly with the bilinear
+            # interpolation (both linear, weights sum to 1), so it runs BEFORE the upsample on 4x fewer pixels.
+            if skip is not None:
+                path = rcu(skip, r["u1c1"], r["u1c2"], extra=path)
+            y = rcu(path, r["u2c1"], r["u2c2"])
+            B, hh, ww, C = y.shape
+            _, z = ops.gemm(y.view(B * hh * ww, C), r["out"][0], bias=r["out"][1], want_lp=True)
+            return ops.upsample2x(z.view(B, hh, ww, C), crop)
+
+        p4 = fusion(hk.ref[3], ls[3], None, crop=(ls[2].shape[1], ls[2].shape[2]))    # dpt_head.py:69-71
+        p3 = fusion(hk.ref[2], p4, ls[2])
+        p2 = fusion(hk.ref[1], p3, ls[1])
+        p1 = fusion(hk.ref[0], p2, ls[0])
+        del ls, p4, p3, p2
+        y = ops.conv3x3(p1, hk.h0_w, bias=hk.h0_b)                                      # head[0]
+        assert hk.patch_size == 16, "head Interpolate scale = patch_size / 8 (dpt_block.py:374): only x2 is fused"
+        y = ops.upsample2x(y)                                                           # head[1]
+        y = ops.conv3x3(y, hk.h2_w, bias=hk.h2_b, act="relu")                          # head[2], head[3]
+        return ops.dpt_final(y, hk.h4_w, hk.h4_b, hk.conf_mode)                         # head[4] + postprocess
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, views, profiling=False):
+        """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device."""
+        if len(views) == 0:
+            return ([], {}) if profiling else []
+        dev = views[0]["img"].device
+        if dev.type != "cuda":
+            raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (views are on {dev}); there is no CPU fallback")
+        prof = {} if profiling else None
+        lp = self.compute_dtype
+        pk = self._pack(dev)
+        enc, dec = self.encoder, self.decoder
+        sh = self.sharding
+        N_total = len(views)
+        v_lo, v_hi = (0, N_total) if sh is None else sh.my_range(N_total)
+        my_views = views[v_lo:v_hi]
+        B = views[0]["img"].shape[0]
+
+        # ---- encode (fast3r.py:250-296): same-shape views are batched, others go one by one
+        t0 = time.time()
+        shapes = [tuple(v["img"].shape[-2:]) for v in views]
+        for v in views:
+            ts = v.get("true_shape", None)
+            if ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
+                raise AssertionError("true_shape must be all identical")  # utils/misc.py:69
+        same = all(s == shapes[0] for s in shapes)
+        feats, Ps, grids = [], [], []
+        if same and len(my_views) > 0:
+            imgs = torch.cat([v["img"] for v in my_views], dim=0).float()
+            f, P, grid = self._encode(imgs, pk)
+            f = f.view(len(my_views), B, P, -1)
+            feats = [f[i] for i in range(len(my_views))]
+            Ps, grids = [P] * len(my_views), [grid] * len(my_views)
+        else:
+            for v in my_views:
+                f, P, grid = self._encode(v["img"].float().contiguous(), pk)
+                feats.append(f.view(B, P, -1))
+                Ps.append(P)
+                grids.append(grid)
+        if profiling:
+            torch.cuda.synchronize()
+            prof["encode_images_time"] = time.time() - t0
+
+        # ---- image ids (fast3r.py:339-348 / 702-743): drawn once for all N views (rank 0 decides when sharded)
+        t1 = time.time()
+        ids = dec.draw_image_ids(B, N_total)
+        if sh is not None:
+            ids = sh.broadcast_ids(ids, dev)
+        emb_rows = dec.image_idx_emb.to(dev)[ids.to(dev)]  # (B, N_total, D) fp32 rows of the table
+        if profiling:
+            prof["pos_emb_time"] = time.time() - t1
+
+        # ---- fusion decoder (fast3r.py:768-808) per sample; local tokens are queries, K/V cover all views
+        if profiling:
+            torch.cuda.synchronize()
+        t2 = time.time()
+        L = dec.depth
+        hooks = [0, L * 2 // 4, L * 3 // 4, L]
+        scale = dec.attention_scale(self.training)
+        D = dec.embed_dim
+        T_loc = sum(Ps)
+        n_loc = len(my_views)
+        hook_toks = []  # per sample: [4] lowp [T_loc][C]
+        for b in range(B):
+            enc_b = torch.cat([feats[i][b] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b]
+            enc_b = enc_b.contiguous()
+            x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
+            if len(set(Ps)) == 1:
+                ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo:v_hi].contiguous(), rowadd_div=Ps[0], out_f32=x)
+            else:
+                r0 = 0
+                for i in range(n_loc):
+                    ops.gemm(enc_b[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo + i:v_lo + i + 1].contiguous(),
+                             rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]])
+                    r0 += Ps[i]
+            taps = {0: enc_b}
+            kvx = None if sh is None else sh.make_kv_exchange(T_loc, D, lp, dev)
+            for li, pb in enumerate(pk["dec"]):
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
+                if (li + 1) in hooks[1:3]:
+                    taps[li + 1] = ops.cast_lp(x, lp)
+            w_, b_, eps = pk["dec_norm"]
+            taps[L], _ = ops.layernorm(x, w_, b_, eps, lp)
+            hook_toks.append([taps[hk] for hk in hooks])
+            del x
+        if profiling:
+            torch.cuda.synchronize()
+            prof["decoder_time"] = time.time() - t2
+            prof["head_prepare_input_time"] = 0.0  # hooks are consumed in place: no rearrange step (fast3r.py:385-398)
+
+        # ---- heads (fast3r.py:407-485), in chunks of max_parallel_views_for_head same-size views
+        t3 = time.time()
+        results = [{} for _ in range(n_loc)]
+        offs = np.concatenate([[0], np.cumsum(Ps)]).tolist()
+        step = max(1, self.max_parallel_views_for_head)
+        heads = [("pts3d_in_other_view", "conf", pk["head"])]
+        if pk["head_local"] is not None:
+            heads.append(("pts3d_local", "conf_local", pk["head_local"]))
+        i0 = 0
+        while i0 < n_loc:
+            i1 = i0 + 1
+            while i1 < n_loc and i1 - i0 < step and grids[i1] == grids[i0]:
+                i1 += 1
+            gh, gw = grids[i0]
+            for pname, cname, hk in heads:
+                per_b = []
+                for b in range(B):
+                    toks = [t[offs[i0]:offs[i1]] for t in hook_toks[b]]
+                    per_b.append(self._dpt(hk, toks, i1 - i0, gh, gw))
+                for i in range(i0, i1):
+                    results[i][pname] = torch.stack([pb_[0][i - i0] for pb_ in per_b], dim=0)
+                    if per_b[0][1] is not None:
+                        results[i][cname] = torch.stack([pb_[1][i - i0] for pb_ in per_b], dim=0)
+            i0 = i1
+        if sh is not None:
+            results = sh.gather_results(results, N_total, dev)
+        if profiling:
+            torch.cuda.synchronize()
+            prof["head_forward_time"] = time.time() - t3
+            prof["total_time"] = time.time() - t0
+            return results, prof
+        return results

@@ -1,0 +1,100 @@
+"""`inference()` with the reference's signature and return structure
+(fast3r/dust3r/inference_multiview.py:70-99 -> loss_of_one_batch :22-67), driving fast3r_amd.Fast3R.
+
+Precision argument.  The reference turns `dtype` into a torch.autocast context (:41-52): "32" disables autocast,
+"16-mixed" -> fp16, "bf16-mixed" / torch.bfloat16 -> bf16, and anything else -- notably torch.float32, which the
+demo passes -- silently falls through to the *default* autocast dtype.  Here the argument
+selects the MFMA operand type of the HIP kernels: fp16 for "16-mixed"/torch.float16, bf16 for
+"bf16-mixed"/"bf16-mixed-no-grad-scaling"/torch.bfloat16, and the model's own `compute_dtype` (fp16 by default)
+for "32"/torch.float32/anything else.  Accumulation, residual stream, LayerNorm, softmax and outputs are always
+fp32, so every mode is at least as precise as the reference's mixed-precision modes; the measured distance to the
+reference's true-fp32 CPU path is recorded in DESIGN.md.
+"""
+import numpy as np
+import torch
+
+_TENSOR_KEYS = "img pts3d valid_mask camera_pose camera_intrinsics F_matrix corres".split()  # :30-37
+
+
+def collate_with_cat(whatever, lists=False):
+    """fast3r/dust3r/utils/device.py:60-91: recursive collate; tensors are concatenated (or listified)."""
+    if isinstance(whatever, dict):
+        return {k: collate_with_cat(v, lists=lists) for k, v in whatever.items()}
+    if isinstance(whatever, (tuple, list)):
+        if len(whatever) == 0:
+            return whatever
+        elem, T = whatever[0], type(whatever)
+        if elem is None:
+            return None
+        if isinstance(elem, (bool, float, int, str)):
+            return whatever
+        if isinstance(elem, tuple):
+            return T(collate_with_cat(x, lists=lists) for x in zip(*whatever))
+        if isinstance(elem, dict):
+            return {k: collate_with_cat([e[k] for e in whatever], lists=lists) for k in elem}
+        if isinstance(elem, torch.Tensor):
+            return [x for e in whatever for x in e] if lists else torch.cat(whatever)
+        if isinstance(elem, np.ndarray):
+            return [x for e in whatever for x in e] if lists else torch.cat([torch.from_numpy(x) for x in whatever])
+        return sum(whatever, T())
+
+
+def to_cpu(x):
+    """fast3r/dust3r/utils/device.py:17-53 todevice(x, 'cpu')."""
+    if isinstance(x, dict):
+        return {k: to_cpu(v) for k, v in x.items()}
+    if isinstance(x, (tuple, list)):
+        return type(x)(to_cpu(v) for v in x)
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    if torch.is_tensor(x):
+        return x.to("cpu")
+    return x
+
+
+def check_if_same_size(imgs):
+    shapes = [img["img"].shape[-2:] for img in imgs]  # :102-104
+    return all(s == shapes[0] for s in shapes)
+
+
+def _operand_dtype(precision, model):
+    if precision in ("16-mixed", torch.float16):
+        return torch.float16
+    if precision in ("bf16-mixed", "bf16-mixed-no-grad-scaling", torch.bfloat16):
+        return torch.bfloat16
+    return model.compute_dtype
+
+
+def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_batch=False, use_amp=False, ret=None,
+                      profiling=False):
+    for view in batch:
+        for name in _TENSOR_KEYS:
+            if name in view:
+                view[name] = view[name].to(device, non_blocking=True)
+    net = getattr(model, "net", model)  # accept the MultiViewDUSt3RLitModule shim too
+    saved = net.compute_dtype
+    net.compute_dtype = _operand_dtype(precision, net)
+    try:
+        out = model(batch, profiling=profiling) if net is model else (net(batch, profiling=profiling))
+    finally:
+        net.compute_dtype = saved
+    preds, profiling_info = out if profiling else (out, None)
+    loss = criterion(batch, preds) if criterion is not None else None
+    result = dict(views=batch, preds=preds, loss=loss)
+    if profiling:
+        result["profiling_info"] = profiling_info
+    return result[ret] if ret else result
+
+
+@torch.no_grad()
+def inference(multiple_views_in_one_sample, model, device, dtype, verbose=True, profiling=False):
+    if verbose:
+        print(f">> Inference with model on {len(multiple_views_in_one_sample)} images")
+    multiple_shapes = not check_if_same_size(multiple_views_in_one_sample)
+    res = loss_of_one_batch(collate_with_cat([tuple(multiple_views_in_one_sample)]), model, None, torch.device(device),
+                            dtype, profiling=profiling)
+    profiling_info = res.pop("profiling_info") if profiling and "profiling_info" in res else None
+    result = collate_with_cat([to_cpu(res)], lists=multiple_shapes)
+    if profiling and profiling_info is not None:
+        return result, profiling_info
+    return result

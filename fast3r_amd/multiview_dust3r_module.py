@@ -1,0 +1,39 @@
+"""Inference-only shim of MultiViewDUSt3RLitModule (fast3r/models/multiview_dust3r_module.py:67-126).
+
+The reference class is a LightningModule whose training / validation / metric machinery is outside the MI355X hot
+path.  What inference callers use is kept with the same names:
+    lit = MultiViewDUSt3RLitModule.load_for_inference(net)   (:119-123)
+    lit.eval(); lit(views) == net(views)                     (:125-126)
+The post-processing helpers (estimate_camera_poses :807-869, align_local_pts3d_to_global :427-549) are the "next"
+rows of SURVEY.md section 8f and raise NotImplementedError until they are built.
+"""
+import torch
+
+
+class MultiViewDUSt3RLitModule(torch.nn.Module):
+    def __init__(self, net, train_criterion=None, validation_criterion=None, optimizer=None, scheduler=None,
+                 compile=False, pretrained=None, resume_from_checkpoint=None, eval_use_pts3d_from_local_head=True):
+        super().__init__()
+        self.net = net
+        self.train_criterion, self.validation_criterion = train_criterion, validation_criterion
+        self.pretrained, self.resume_from_checkpoint = pretrained, resume_from_checkpoint
+        self.eval_use_pts3d_from_local_head = eval_use_pts3d_from_local_head
+
+    @classmethod
+    def load_for_inference(cls, net):
+        lit_module = cls(net=net, train_criterion=None, validation_criterion=None, optimizer=None, scheduler=None, compile=False)
+        lit_module.eval()
+        return lit_module
+
+    def forward(self, views, **kw):
+        return self.net(views, **kw)
+
+    @staticmethod
+    def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimation_method="individual"):
+        raise NotImplementedError("estimate_camera_poses is a post-processing step outside the MI355X hot path "
+                                  "(SURVEY.md section 8f, rank 2); not built yet")
+
+    @staticmethod
+    def align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=0):
+        raise NotImplementedError("align_local_pts3d_to_global is a post-processing step outside the MI355X hot path "
+                                  "(SURVEY.md section 8f, rank 1); not built yet")

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers over the C ABI (include/f3r.h).  torch tensors are device memory + shape bookkeeping;
+every arithmetic op below is a hand-written HIP kernel in fast3r_amd/csrc/.  No function here has a torch
+fallback: CPU tensors raise F3RError.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (AttnArgs, F3R_A_CONV3X3, F3R_A_PLAIN, F3R_ACT_GELU, F3R_ACT_NONE, F3R_ACT_RELU, F3R_EPI_CONVT,
+                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, GemmArgs, check, dtype_id, ptr, require_gpu, stream_ptr)
+
+ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F3R_ACT_RELU}
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------- weight packing (host, once)
+def pack_linear_weight(w: torch.Tensor, lp: torch.dtype) -> torch.Tensor:
+    """nn.Linear / 1x1-conv weight (N, K[,1,1]) fp32 -> lowp [N][Kpad], Kpad = roundup(K, 64), zero padded."""
+    w = w.reshape(w.shape[0], -1)
+    n, k = w.shape
+    out = torch.zeros((n, round_up(k, 64)), dtype=lp, device=w.device)
+    out[:, :k] = w.to(lp)
+    return out
+
+
+def pack_conv3x3_weight(w: torch.Tensor, lp: torch.dtype) -> torch.Tensor:
+    """Conv2d weight (Cout, Cin, 3, 3) -> lowp [Cout][9 * Cpad], k = (ky*3 + kx) * Cpad + ci, Cpad = roundup(Cin, 64)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    cpad = round_up(ci, 64)
+    out = torch.zeros((co, 9, cpad), dtype=lp, device=w.device)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(lp)
+    return out.reshape(co, 9 * cpad)
+
+
+def pack_convT_weight(w: torch.Tensor, b: torch.Tensor, lp: torch.dtype):
+    """ConvTranspose2d (kernel == stride == s) weight (Cin, Cout, s, s) -> lowp [(dy*s+dx)*Cout + co][Kpad] and the bias
+    tiled to [s*s*Cout] (every output pixel gets exactly one tap)."""
+    ci, co, s, s2 = w.shape
+    assert s == s2
+    wp = w.permute(2, 3, 1, 0).reshape(s * s * co, ci)
+    return pack_linear_weight(wp, lp), b.float().repeat(s * s).contiguous()
+
+
+def rope_tables(n_pos: int, base: float, device, half_dim: int = 32):
+    """cos/sin(pos * base^(-2i/half_dim)), i < half_dim/2, exactly as RoPE2D.get_cos_sin builds them in fp32
+    (pos_embed.py:139-150) -> two [n_pos][16] fp32 tables."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, half_dim, 2).float() / half_dim))
+    t = torch.arange(n_pos, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    return freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device)
+
+
+# ----------------------------------------------------------------------------------------- kernels
+def patchify(img: torch.Tensor, ps: int, lp: torch.dtype) -> torch.Tensor:
+    """(B,3,H,W) fp32 -> [B*h*w][3*ps*ps] lowp rows for the patch-embed GEMM."""
+    require_gpu(img, "img")
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    B, C, H, W = img.shape
+    assert C == 3
+    out = torch.empty((B * (H // ps) * (W // ps), 3 * ps * ps), dtype=lp, device=img.device)
+    check(_lib.lib().f3r_patchify(ptr(img), ptr(out), B, H, W, ps, dtype_id(lp), stream_ptr()), "f3r_patchify")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, lp, out_lp=None, out_f32=None, want_lp=True, want_f32=False, rms=False):
+    require_gpu(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if want_lp and out_lp is None:
+        out_lp = torch.empty(x.shape, dtype=lp, device=x.device)
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty_like(x)
+    check(_lib.lib().f3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out_lp), ptr(out_f32), rows, D, float(eps),
+                                   int(rms), dtype_id(lp), stream_ptr()), "f3r_layernorm")
+    return out_lp, out_f32
+
+
+def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f32=None, res_lp=None, res_lp2=None,
+         out_f32=None, out_lp=None, want_f32=False, want_lp=False):
+    """out = act(A W^T + bias) [+ rowadd[m//div]] [+ residuals].  a: lowp [M][lda>=K]; w: packed lowp [N][Kpad]."""
+    require_gpu(a, "a")
+    lp = a.dtype
+    assert w.dtype == lp and a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1
+    M = a.shape[0]
+    N, Kpad = w.shape
+    K = a.shape[1] if K is None else K
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if want_lp and out_lp is None:
+        out_lp = torch.empty((M, N), dtype=lp, device=a.device)
+    g = GemmArgs()
+    g.A, g.W, g.bias = ptr(a), ptr(w), ptr(bias)
+    g.M, g.N, g.K, g.Kpad, g.lda = M, N, K, Kpad, a.stride(0)
+    g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_GENERIC, ACT[act]
+    if rowadd is not None:
+        g.rowadd, g.rowadd_div = ptr(rowadd), rowadd_div
+    if res_f32 is not None:
+        g.res_f32, g.ldr_f32 = ptr(res_f32), res_f32.stride(0)
+    if res_lp is not None:
+        g.res_lp, g.ldr_lp = ptr(res_lp), res_lp.stride(0)
+    if res_lp2 is not None:
+        g.res_lp2, g.ldr_lp2 = ptr(res_lp2), res_lp2.stride(0)
+    if out_f32 is not None:
+        g.out_f32, g.ldo_f32 = ptr(out_f32), out_f32.stride(0)
+    if out_lp is not None:
+        g.out_lp, g.ldo_lp = ptr(out_lp), out_lp.stride(0)
+    g.dtype = dtype_id(lp)
+    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
+    return out_f32, out_lp
+
+
+def vt_ld(seq_len: int) -> int:
+    """Row stride of a V^T buffer: the attention kernel reads whole 64-key tiles, so rows are padded to 64 (zeroed)."""
+    return round_up(seq_len, 64)
+
+
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None):
+    """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE-2D'd), v -> vt[M/seq][D][ldvt].
+    rope = (cos, sin, tokens_per_row) or None.  vt must be zero-initialised once (its padding is never written)."""
+    require_gpu(a, "a")
+    lp = a.dtype
+    M = a.shape[0]
+    N, Kpad = w.shape
+    g = GemmArgs()
+    g.A, g.W, g.bias = ptr(a), ptr(w), ptr(bias)
+    g.M, g.N, g.K, g.Kpad, g.lda = M, N, a.shape[1], Kpad, a.stride(0)
+    g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_QKV, F3R_ACT_NONE
+    g.q, g.k, g.vt = ptr(q), ptr(k), ptr(vt)
+    g.seq_len, g.ldvt = seq_len, vt.stride(-2)
+    if rope is not None:
+        g.rope_cos, g.rope_sin, g.rope_w = ptr(rope[0]), ptr(rope[1]), rope[2]
+    g.dtype = dtype_id(lp)
+    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
+
+
+def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, res_lp2=None, out=None):
+    """3x3 conv, pad 1, NHWC lowp in/out, as an implicit GEMM.  x: (B,H,W,C); w: pack_conv3x3_weight(...)."""
+    require_gpu(x, "x")
+    lp = x.dtype
+    assert x.is_contiguous() and x.dim() == 4
+    B, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    N, Kpad = w.shape
+    if out is None:
+        out = torch.empty((B, OH, OW, N), dtype=lp, device=x.device)
+    g = GemmArgs()
+    g.A, g.W, g.bias = ptr(x), ptr(w), ptr(bias)
+    g.M, g.N, g.K, g.Kpad, g.lda = B * OH * OW, N, 0, Kpad, 0
+    g.a_mode, g.a_relu = F3R_A_CONV3X3, int(a_relu)
+    g.conv_H, g.conv_W, g.conv_C, g.conv_stride, g.conv_OH, g.conv_OW = H, W, C, stride, OH, OW
+    g.epi, g.act = F3R_EPI_GENERIC, ACT[act]
+    if res_lp is not None:
+        g.res_lp, g.ldr_lp = ptr(res_lp), N
+    if res_lp2 is not None:
+        g.res_lp2, g.ldr_lp2 = ptr(res_lp2), N
+    g.out_lp, g.ldo_lp = ptr(out), N
+    g.dtype = dtype_id(lp)
+    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(conv3x3)")
+    return out
+
+
+def convT(x, w, bias_tiled, s, cout):
+    """ConvTranspose2d with kernel == stride == s: x (B,h,w,Cin) NHWC lowp -> (B,h*s,w*s,cout)."""
+    require_gpu(x, "x")
+    lp = x.dtype
+    B, h, wd, cin = x.shape
+    out = torch.empty((B, h * s, wd * s, cout), dtype=lp, device=x.device)
+    g = GemmArgs()
+    g.A, g.W, g.bias = ptr(x), ptr(w), ptr(bias_tiled)
+    g.M, g.N, g.K, g.Kpad, g.lda = B * h * wd, s * s * cout, cin, w.shape[1], cin
+    g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_CONVT, F3R_ACT_NONE
+    g.out_lp, g.ldo_lp = ptr(out), cout
+    g.ct_s, g.ct_h, g.ct_w, g.ct_cout = s, h, wd, cout
+    g.dtype = dtype_id(lp)
+    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(convT)")
+    return out
+
+
+def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0):
+    """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
+    with k [..][seg_len][ldk] and vt [..][heads*64][ldvt]."""
+    require_gpu(q, "q")
+    lp = q.dtype
+    assert 1 <= len(segments) <= F3R_MAX_SEG
+    a = AttnArgs()
+    a.q, a.o = ptr(q), ptr(out)
+    a.ldq, a.ldo = q.stride(-2), out.stride(-2)
+    a.q_batch_stride, a.o_batch_stride = q_batch_stride, o_batch_stride
+    a.tq = q.shape[-2] if tq is None else tq
+    a.batch, a.n_heads, a.n_seg, a.dtype = batch, n_heads, len(segments), dtype_id(lp)
+    for i, (k, vt, seg_len, kbs, vbs) in enumerate(segments):
+        assert k.dtype == lp and vt.dtype == lp
+        a.k_seg[i], a.vt_seg[i] = ptr(k), ptr(vt)
+        a.seg_len[i], a.ldvt[i] = seg_len, vt.stride(-2)
+        a.k_batch_stride[i], a.vt_batch_stride[i] = kbs, vbs
+        a.ldk = k.stride(-2)
+    a.scale = float(scale)
+    check(_lib.lib().f3r_attn_fwd(ctypes.byref(a), stream_ptr()), "f3r_attn_fwd")
+    return out
+
+
+def upsample2x(x, out_hw=None):
+    """bilinear x2, align_corners=True, NHWC lowp; optional crop to out_hw."""
+    require_gpu(x, "x")
+    B, h, w, C = x.shape
+    oh, ow = (2 * h, 2 * w) if out_hw is None else out_hw
+    out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
+    check(_lib.lib().f3r_upsample2x(ptr(x), ptr(out), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
+    return out
+
+
+def dpt_final(x, w, b, conf_mode):
+    """x (B,H,W,Cin) NHWC lowp -> pts3d (B,H,W,3) fp32, conf (B,H,W) fp32 (or None)."""
+    require_gpu(x, "x")
+    B, H, W, Cin = x.shape
+    pts = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
+    conf = None
+    vmin, vmax = 1.0, math.inf
+    if conf_mode is not None:
+        conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+        vmin, vmax = float(conf_mode[1]), float(conf_mode[2])
+    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(w), ptr(b), ptr(pts), ptr(conf), B * H * W, Cin, vmin, vmax,
+                                   dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
+    return pts, conf
+
+
+def cast_lp(x, lp, out=None):
+    require_gpu(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=lp, device=x.device)
+    check(_lib.lib().f3r_cast_f32_to_lp(ptr(x), ptr(out), x.numel(), dtype_id(lp), stream_ptr()), "f3r_cast_f32_to_lp")
+    return out

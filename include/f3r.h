@@ -1,0 +1,188 @@
+/*
+ * f3r.h -- C ABI of libf3r_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the Fast3R
+ * single-forward-pass inference hot path
+ *     fast3r/dust3r/inference_multiview.py:70-99  inference()
+ *       -> fast3r/models/fast3r.py:302-497        Fast3R.forward
+ *
+ * The reference has exactly one native binding, the pybind `curope.rope_2d(tokens, positions,
+ * base, fwd)` (fast3r/croco/models/curope/curope.cpp:49-69); everything else it computes through
+ * torch ops (nn.Linear / Conv2d / LayerNorm / SDPA / F.interpolate).  This header is what a
+ * from-scratch native backend for the same path binds instead: one entry point per fused op,
+ * plain device pointers + sizes, no torch types.  Each entry cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch-ROCm allocator); the
+ *     library allocates nothing and keeps no mutable global state except the last-error string;
+ *   - every launch is asynchronous on the caller's `stream` (unlike the reference extension,
+ *     which launches on the legacy default stream: curope/kernels.cu:102);
+ *   - return value: F3R_OK (0) or a negative f3r_status; nothing throws across the boundary.
+ *     The Python host (fast3r_amd/_lib.py) maps errors onto the exception types the reference
+ *     raises (ValueError / AssertionError / RuntimeError);
+ *   - "lowp" = the 16-bit MFMA operand type selected by `dtype` (F3R_F16 or F3R_BF16);
+ *     accumulation, residual stream, LayerNorm statistics, softmax and post-processing are fp32.
+ */
+#ifndef F3R_H_
+#define F3R_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* f3r_stream_t; /* hipStream_t */
+
+typedef enum {
+  F3R_OK = 0,
+  F3R_ERR_ARG = -1,         /* bad argument (null pointer, bad size, misalignment) */
+  F3R_ERR_UNSUPPORTED = -2, /* shape / mode not implemented by the kernels */
+  F3R_ERR_LAUNCH = -3       /* hipGetLastError() after the launch was not hipSuccess */
+} f3r_status;
+
+typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
+
+#define F3R_MAX_SEG 8
+
+/* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
+int f3r_version(void);
+const char* f3r_last_error_string(void);
+/* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1): lets a foreign-language binding
+   verify its struct layout before the first call; 0 for an unknown `what` */
+size_t f3r_sizeof(int what);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_patchify: fp32 NCHW image -> lowp im2col rows for the k=s=ps patch-embedding convolution.
+ * Replaces the input side of PatchEmbedDust3R.forward's Conv2d (fast3r/dust3r/patch_embed.py:24-38,
+ * fast3r/croco/models/blocks.py:412-415).  out[(b*h+py)*w+px][c*ps*ps+dy*ps+dx] = img[b][c][py*ps+dy][px*ps+dx]
+ * (the Conv2d weight's own (c,dy,dx) order, so weight.view(D, 3*ps*ps) is the GEMM operand).
+ */
+int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int dtype, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_layernorm: rows of fp32 -> normalised lowp (GEMM operand) and/or fp32.
+ * Replaces nn.LayerNorm in Block.forward (blocks.py:236-239), enc_norm (fast3r.py:558) and dec_norm
+ * (fast3r.py:805).  Biased variance, y=(x-mu)/sqrt(var+eps)*gamma+beta; eps is 1e-6 or 1e-5 per
+ * site (fast3r.py:509,683,700).  rms!=0: RMSNorm (no mean, no beta: components/llama.py:137-163).
+ * D % 4 == 0.  out_lp / out_f32 may each be NULL.
+ */
+int f3r_layernorm(const float* x, const float* gamma, const float* beta, void* out_lp, float* out_f32,
+                  int64_t rows, int D, float eps, int rms, int dtype, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_gemm: out = epilogue( A(M,K) * W(N,K)^T ) on MFMA, fp32 accumulate.
+ * Replaces every nn.Linear on the path (blocks.py:94-105 Mlp, :125-131,138,169 Attention qkv/proj,
+ * fast3r.py:782 decoder_embed), the patch-embed Conv2d (as GEMM over f3r_patchify rows), and all
+ * Conv2d / ConvTranspose2d of the DPT head (dpt_block.py:42-78,105-154,187-250,365-382,416-481).
+ */
+typedef enum { F3R_A_PLAIN = 0, F3R_A_CONV3X3 = 1 } f3r_a_mode;
+typedef enum { F3R_EPI_GENERIC = 0, F3R_EPI_QKV = 1, F3R_EPI_CONVT = 2 } f3r_epi_mode;
+typedef enum { F3R_ACT_NONE = 0, F3R_ACT_GELU = 1, F3R_ACT_RELU = 2 } f3r_act;
+
+typedef struct f3r_gemm_args {
+  /* operands */
+  const void* A;     /* lowp. PLAIN: [M][lda].  CONV3X3: NHWC [B][conv_H][conv_W][conv_C] */
+  const void* W;     /* lowp [N][Kpad] row-major, zero padded. PLAIN: k < K real.  CONV3X3: k = tap*Cpad + ci */
+  const float* bias; /* [N] or NULL */
+  int64_t M;         /* rows (tokens / output pixels) */
+  int32_t N;
+  int32_t K;         /* PLAIN: real K (multiple of 8).  CONV3X3: ignored */
+  int32_t Kpad;      /* multiple of 64.  CONV3X3: 9*Cpad with Cpad = roundup(conv_C, 64) */
+  int64_t lda;       /* PLAIN: row stride of A in elements */
+  int32_t a_mode;    /* f3r_a_mode */
+  int32_t a_relu;    /* ReLU applied to A as it is staged (the pre-activation of ResidualConvUnit_custom, dpt_block.py:143,148) */
+  int32_t conv_H, conv_W, conv_C, conv_stride, conv_OH, conv_OW; /* CONV3X3 (pad 1): M = B*conv_OH*conv_OW */
+  /* epilogue */
+  int32_t epi;       /* f3r_epi_mode */
+  int32_t act;       /* f3r_act, applied after bias */
+  const float* rowadd; /* GENERIC: out += rowadd[m / rowadd_div][n] (image-index embedding, fast3r.py:799) or NULL */
+  int64_t rowadd_div;
+  const float* res_f32; /* GENERIC: fp32 residual [M][ldr_f32] or NULL (x + attn(..), x + mlp(..): blocks.py:237-238) */
+  int64_t ldr_f32;
+  const void* res_lp;   /* GENERIC: lowp residuals (skip_add of the RCU / fusion block, dpt_block.py:154,216) or NULL */
+  int64_t ldr_lp;
+  const void* res_lp2;
+  int64_t ldr_lp2;
+  float* out_f32;    /* GENERIC: fp32 output [M][ldo_f32] or NULL */
+  int64_t ldo_f32;
+  void* out_lp;      /* GENERIC: lowp output [M][ldo_lp] or NULL.  CONVT: NHWC [B][h*s][w*s][ct_cout] */
+  int64_t ldo_lp;
+  /* QKV epilogue (N = 3*D, D = heads*64): q -> [M][D], k -> [M][D], v -> transposed vt[m / seq_len][D][ldvt] at column m % seq_len */
+  void* q;
+  void* k;
+  void* vt;
+  int64_t seq_len;
+  int64_t ldvt;
+  const float* rope_cos; /* [n_pos][16] fp32 cos/sin of pos * 100^(-i/16) (pos_embed.py:139-150) or NULL = no RoPE (fusion decoder) */
+  const float* rope_sin;
+  int32_t rope_w;    /* tokens per image row: token p of a view sits at (y, x) = (p / rope_w, p % rope_w) (blocks.py:376-388) */
+  /* CONVT epilogue (ConvTranspose2d with kernel == stride == ct_s): rows m = (b, y, x) on a ct_h x ct_w grid,
+     columns n = (dy*ct_s + dx)*ct_cout + co  ->  out_lp[b][y*ct_s+dy][x*ct_s+dx][co] */
+  int32_t ct_s, ct_h, ct_w, ct_cout;
+  int32_t dtype;     /* f3r_dtype */
+} f3r_gemm_args;
+
+int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_attn_fwd: O = softmax(scale * Q K^T) V, non-causal, head_dim 64, flash-style (never forms
+ * the T x T matrix), fp32 online softmax.  Replaces the q@k^T -> softmax -> @v core of
+ * Attention.forward (blocks.py:158-190; all three `attn_implementation`s compute this).
+ * K/V arrive as up to F3R_MAX_SEG segments so that the view-sharded multi-GPU path can attend
+ * over the local shard plus the all-gathered remote shards without concatenating them.
+ *   q  : [batch][tq][ldq]   (head h at columns h*64 .. h*64+63)
+ *   k_seg[s]  : [batch][seg_len[s]][ldk]
+ *   vt_seg[s] : [batch][heads*64][ldvt[s]]  (V transposed, as written by the F3R_EPI_QKV epilogue)
+ *   o  : [batch][tq][ldo]
+ */
+typedef struct f3r_attn_args {
+  const void* q;
+  void* o;
+  int64_t ldq, ldo;
+  int64_t q_batch_stride, o_batch_stride; /* elements */
+  int64_t tq;
+  int32_t batch;
+  int32_t n_heads;
+  int32_t n_seg;
+  int32_t dtype;
+  const void* k_seg[F3R_MAX_SEG];
+  const void* vt_seg[F3R_MAX_SEG];
+  int64_t seg_len[F3R_MAX_SEG];
+  int64_t ldvt[F3R_MAX_SEG];
+  int64_t ldk;
+  int64_t k_batch_stride[F3R_MAX_SEG];  /* elements */
+  int64_t vt_batch_stride[F3R_MAX_SEG]; /* elements */
+  float scale; /* 0.125, or 0.160192 for the fusion decoder in eval mode (blocks.py:119-124,151-154) */
+} f3r_attn_args;
+
+int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_upsample2x: bilinear x2, align_corners=True, NHWC lowp -> NHWC lowp.
+ * Replaces F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) in
+ * FeatureFusionBlock_custom.forward (dpt_block.py:238-243) and the head's Interpolate (:374).
+ * The output may be cropped to (out_h, out_w) <= (2h, 2w) (refinenet4 crop, dpt_head.py:69-71).
+ */
+int f3r_upsample2x(const void* in, void* out, int batch, int h, int w, int C, int out_h, int out_w, int dtype,
+                   f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_dpt_final: last 1x1 conv (Cin -> 4) fused with postprocess.
+ * Replaces head[4] Conv2d(last_dim, 4, 1) (dpt_block.py:379-381) + postprocess/reg_dense_depth/
+ * reg_dense_conf (heads/postprocess.py:16-64), depth_mode ('exp', -inf, inf), conf_mode ('exp', vmin, vmax):
+ *   xyz,c = W(4,Cin) x + b;  d = |xyz|;  pts = xyz / max(d, 1e-8) * expm1(d);  conf = vmin + min(exp(c), vmax - vmin)
+ *   x : NHWC lowp [npix][Cin];  w: fp32 [4][Cin];  b: fp32 [4];  pts3d: fp32 [npix][3];  conf: fp32 [npix]
+ */
+int f3r_dpt_final(const void* x, const float* w, const float* b, float* pts3d, float* conf, int64_t npix, int Cin,
+                  float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f3r_cast_f32_to_lp: fp32 -> lowp copy (hooked residual streams 12/18 as DPT inputs, dpt_head.py:54;
+ * weight packing).
+ */
+int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dtype, f3r_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3R_H_ */

@@ -1,0 +1,72 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.pt by running the REAL reference on CPU (true fp32, dtype="32").
+
+Run in the build container only (needs /root/reference):   python -m oracle.make_golden
+The reference ships no golden vectors, so these are "outputs of the reference itself run
+here": each fixture stores the constructor args, the input recipe (seeds; inputs and weights are regenerated
+bit-identically by fast3r_amd/synthetic.py), the image ids the reference drew, and the reference outputs.
+Weights are NOT stored (the DPT heads alone are 2 x 20.5 M parameters): both sides rebuild them from
+synth_state_dict(shapes, seed).
+"""
+import copy
+import os
+import sys
+import warnings
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args  # noqa: E402
+from oracle.ref_loader import load_reference  # noqa: E402
+
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# name -> (tiny_args kwargs, list of (H, W) per view, batch, weight seed, rng seed)
+CASES = {
+    "tiny_3x64": (dict(), [(64, 64)] * 3, 1, 0, 1234),
+    "tiny_mixed": (dict(enc_depth=1), [(64, 64), (48, 64), (64, 80)], 1, 1, 99),
+    "tiny_b2_seqids": (dict(random_image_idx_embedding=False, with_local_head=False), [(32, 48)] * 4, 2, 2, 7),
+    "tiny_oddgrid": (dict(enc_depth=1, attn_bias_for_inference_enabled=False), [(112, 160)] * 2, 1, 3, 5),
+}
+
+
+def views_for(shapes, batch, seed=1000):
+    vs = []
+    for i, (h, w) in enumerate(shapes):
+        vs.append(make_views(1, h, w, batch, seed=seed + i)[0])
+        vs[-1]["idx"], vs[-1]["instance"], vs[-1]["label"] = i, str(i), f"syn/{i}"
+    return vs
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    Fast3R, inference = load_reference()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for name, (kw, shapes, batch, wseed, rseed) in CASES.items():
+        enc, dec, head = tiny_args(**kw)
+        model = Fast3R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head)).eval()
+        shp = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synth_state_dict(shp, wseed), strict=True)
+        views = views_for(shapes, batch)
+        # capture the ids the reference draws (fast3r.py:740-743) without touching its code path
+        torch.manual_seed(rseed)
+        ids = None
+        if dec["random_image_idx_embedding"]:
+            seed = torch.randint(0, 2 ** 32, (1,)).item()
+            g = torch.Generator().manual_seed(seed)
+            ids = torch.zeros(batch, len(shapes), dtype=torch.long)
+            for b in range(batch):
+                ids[b, 1:] = torch.randperm(999, generator=g)[: len(shapes) - 1] + 1
+        torch.manual_seed(rseed)
+        out = inference(copy.deepcopy(views), model, torch.device("cpu"), dtype="32", verbose=False)
+        preds = out["preds"]
+        fix = dict(name=name, tiny_kwargs=kw, shapes=shapes, batch=batch, weight_seed=wseed, rng_seed=rseed,
+                   state_shapes=shp, image_ids=ids,
+                   preds=[{k: v.clone() for k, v in p.items()} for p in preds],
+                   torch_version=torch.__version__)
+        path = os.path.join(OUT_DIR, name + ".pt")
+        torch.save(fix, path)
+        print(name, os.path.getsize(path) // 1024, "KB", {k: tuple(v.shape) for k, v in preds[0].items()})
+
+
+if __name__ == "__main__":
+    main()

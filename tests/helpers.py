@@ -1,0 +1,44 @@
+"""Shared test helpers: fixture loading, model construction from a golden fixture, comparators."""
+import copy
+import os
+
+import torch
+
+from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid"]
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name + ".pt"), weights_only=False)
+
+
+def golden_views(fix, seed=1000):
+    vs = []
+    for i, (h, w) in enumerate(fix["shapes"]):
+        v = make_views(1, h, w, fix["batch"], seed=seed + i)[0]
+        v["idx"], v["instance"], v["label"] = i, str(i), f"syn/{i}"
+        vs.append(v)
+    return vs
+
+
+def golden_model_inputs(fix):
+    """-> (encoder_args, decoder_args, head_args, state_dict, views)"""
+    enc, dec, head = tiny_args(**fix["tiny_kwargs"])
+    sd = synth_state_dict(fix["state_shapes"], fix["weight_seed"])
+    return enc, dec, head, sd, golden_views(fix)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def views_to(views, device):
+    out = []
+    for v in views:
+        v = dict(v)
+        v["img"] = v["img"].to(device)
+        out.append(v)
+    return out

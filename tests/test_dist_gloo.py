@@ -1,0 +1,81 @@
+"""world_size-2 gloo test of the view-sharded path's host logic on CPU: range split, image-id broadcast, token-count
+all-gather, the per-layer K / V^T all-gather with uneven shards, and -- with the oracle's attention maths standing in
+for the HIP kernel as the checker -- that attention over the gathered segments equals unsharded attention."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _segment_attention(q, segs, scale):
+    """Checker: softmax over the concatenation of the segments (k [T][D], vt [D][ld], len), 2 heads of 64."""
+    k = torch.cat([s[0][: s[2]] for s in segs], dim=0).float()
+    v = torch.cat([s[1][:, : s[2]].t() for s in segs], dim=0).float()
+    H = q.shape[1] // 64
+    out = torch.empty_like(q, dtype=torch.float32)
+    for h in range(H):
+        sl = slice(h * 64, h * 64 + 64)
+        a = ((q[:, sl].float() @ k[:, sl].t()) * scale).softmax(-1)
+        out[:, sl] = a @ v[:, sl]
+    return out
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fast3r_amd.dist import ViewSharding
+        sh = ViewSharding()
+        n_views, P, D = 5, 24, 128  # uneven: rank 0 owns 3 views, rank 1 owns 2
+        lo, hi = sh.my_range(n_views)
+        assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
+        ids = torch.arange(n_views)[None] * (rank + 1)  # ranks disagree until the broadcast
+        ids = sh.broadcast_ids(ids, torch.device("cpu"))
+        assert ids.tolist() == [list(range(n_views))]
+        t_loc = (hi - lo) * P
+        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"))
+        assert kvx.t_all == [3 * P, 2 * P] and kvx.ldvt % 64 == 0 and kvx.ldvt >= 3 * P
+        # full (unsharded) problem, identical on both ranks
+        g = torch.Generator().manual_seed(0)
+        T = n_views * P
+        qf, kf, vf = (torch.randn(T, D, generator=g) for _ in range(3))
+        r0 = lo * P
+        for layer in range(2):  # buffers are reused across layers
+            kvx.k_loc[:t_loc] = kf[r0:r0 + t_loc] + layer
+            kvx.vt_loc[0, :, :t_loc] = (vf[r0:r0 + t_loc] + layer).t()
+            segs = kvx.exchange()
+            assert [s[2] for s in segs] == [3 * P, 2 * P]
+            out = _segment_attention(qf[r0:r0 + t_loc], segs, 0.16)
+            full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
+            assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
+            assert float(kvx.vt_loc[0, :, t_loc:].abs().sum()) == 0.0  # padding stays zero
+        res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
+        assert len(res) == hi - lo  # outputs stay sharded by default
+        sh.gather_outputs = True
+        res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
+        assert [float(r["x"][0, 0]) for r in res] == [0.0, 1.0, 2.0, 3.0, 4.0]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_sharding_gloo_world2():
+    mp.set_start_method("spawn", force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [mp.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: "ok", 1: "ok"}

@@ -1,0 +1,160 @@
+"""CPU tests of the host side: state_dict layout, image-id RNG recipe, weight packing layouts (checked by emulating
+the kernels' index maps with torch on CPU), collate / inference plumbing, error behaviour without a GPU."""
+import copy
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden
+from fast3r_amd import Fast3R, MultiViewDUSt3RLitModule, inference, ops
+from fast3r_amd._lib import F3RError
+from fast3r_amd.dist import split_range
+from fast3r_amd.inference_multiview import collate_with_cat, to_cpu
+from fast3r_amd.synthetic import make_views, tiny_args, vit_large_args
+from oracle.ref_loader import reference_available
+
+
+def test_state_dict_layout_matches_golden_shapes():
+    fix = load_golden("tiny_3x64")
+    m = Fast3R(*tiny_args(**fix["tiny_kwargs"]))
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in fix["state_shapes"].items()}
+    assert "decoder.image_idx_emb" not in sd  # non-persistent buffer (fast3r.py:691-697)
+    s = m.downstream_head.dpt.scratch
+    assert s.layer_rn[2].weight is s.layer3_rn.weight  # aliases, both key sets present (dpt_block.py:79-86)
+    assert "downstream_head.dpt.scratch.layer_rn.2.weight" in sd and "downstream_head.dpt.scratch.layer3_rn.weight" in sd
+
+
+def test_vit_large_param_count():
+    m = Fast3R(*vit_large_args())
+    sd = m.state_dict()
+    assert len(sd) == 720
+    n_enc = sum(p.numel() for p in m.encoder.parameters())
+    n_dec = sum(p.numel() for p in m.decoder.parameters())
+    assert abs(n_enc / 1e6 - 303.10) < 0.05 and abs(n_dec / 1e6 - 303.36) < 0.05
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference checkout only exists in the build container")
+def test_strict_load_of_reference_state_dict():
+    from oracle.ref_loader import load_reference
+    warnings.filterwarnings("ignore")
+    R, _ = load_reference()
+    enc, dec, head = tiny_args()
+    ref = R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head))
+    m = Fast3R(enc, dec, head)
+    res = m.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(m.decoder.image_idx_emb, ref.decoder.image_idx_emb)
+    assert abs(m.decoder.attention_scale(False) - ref.decoder.dec_blocks[0].attn.attn_bias_scale) < 1e-12
+    assert m.decoder.attention_scale(True) == ref.decoder.dec_blocks[0].attn.scale
+
+
+def test_image_id_recipe_matches_reference_draw():
+    fix = load_golden("tiny_3x64")
+    m = Fast3R(*tiny_args(**fix["tiny_kwargs"]))
+    torch.manual_seed(fix["rng_seed"])
+    ids = m.decoder.draw_image_ids(fix["batch"], len(fix["shapes"]))
+    assert torch.equal(ids, fix["image_ids"])
+    # exactly one draw of the global RNG (fast3r.py:706)
+    torch.manual_seed(5)
+    m.decoder.draw_image_ids(1, 4)
+    after = torch.rand(1)
+    torch.manual_seed(5)
+    torch.randint(0, 2 ** 32, (1,))
+    assert torch.equal(after, torch.rand(1))
+    m2 = Fast3R(*tiny_args(random_image_idx_embedding=False))
+    assert m2.decoder.draw_image_ids(2, 3).tolist() == [[0, 1, 2], [0, 1, 2]]
+    with pytest.raises(ValueError):
+        m.decoder.draw_image_ids(1, 1001)  # the reference fails here too
+
+
+def test_constructor_errors_match_reference_types():
+    enc, dec, head = tiny_args()
+    with pytest.raises(ValueError):
+        Fast3R(dict(enc, encoder_type="nope"), dec, head)  # fast3r.py:85
+    with pytest.raises(ValueError):
+        Fast3R(enc, dict(dec, decoder_type="nope"), head)  # fast3r.py:98
+    with pytest.raises(NotImplementedError):
+        Fast3R(enc, dec, dict(head, head_type="linear"))  # fast3r.py:157
+    with pytest.raises(ValueError):
+        Fast3R(dict(enc, attn_implementation="nope"), dec, head)  # blocks.py:192
+
+
+def test_no_cpu_fallback():
+    m = Fast3R(*tiny_args()).eval()
+    with pytest.raises(F3RError):
+        m(make_views(2, 32, 32))
+    with pytest.raises(F3RError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-6, torch.float16)
+    lit = MultiViewDUSt3RLitModule.load_for_inference(m)
+    assert not lit.training and lit.net is m
+    with pytest.raises(F3RError):
+        inference(make_views(2, 32, 32), lit, "cpu", "32", verbose=False)
+
+
+def test_split_range_is_contiguous_and_balanced():
+    for n in (0, 1, 7, 8, 320, 1500):
+        for w in (1, 2, 3, 8):
+            rs = [split_range(n, w, r) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    assert [split_range(1500, 8, r)[1] - split_range(1500, 8, r)[0] for r in range(8)] == [188] * 4 + [187] * 4
+
+
+def test_collate_and_to_cpu_structure():
+    views = make_views(3, 32, 48)
+    batch = collate_with_cat([tuple(views)])
+    assert isinstance(batch, list) and len(batch) == 3 and batch[0]["img"].shape == (1, 3, 32, 48)
+    assert batch[1]["true_shape"].tolist() == [[32, 48]]
+    res = dict(views=batch, preds=[{"a": torch.ones(1, 2)} for _ in range(3)], loss=None)
+    out = collate_with_cat([to_cpu(res)], lists=False)
+    assert out["loss"] is None and len(out["preds"]) == 3 and out["preds"][0]["a"].shape == (1, 2)
+
+
+# ---- packing layouts: emulate the kernels' index maps on CPU with torch and compare with the torch op they replace
+def test_pack_conv3x3_layout():
+    torch.manual_seed(0)
+    co, ci, H, W = 8, 24, 5, 6
+    w = torch.randn(co, ci, 3, 3)
+    x = torch.randn(2, ci, H, W)
+    wp = ops.pack_conv3x3_weight(w, torch.float32)  # fp32 "lowp" just to test the index map
+    cpad = 64
+    assert wp.shape == (co, 9 * cpad)
+    xn = x.permute(0, 2, 3, 1)  # NHWC
+    xp = F.pad(xn, (0, cpad - ci, 1, 1, 1, 1))
+    cols = torch.stack([xp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=3)  # (B,H,W,9,cpad)
+    y = cols.reshape(2, H, W, 9 * cpad) @ wp.t()
+    ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(y, ref, atol=1e-4)
+
+
+def test_pack_convT_layout():
+    torch.manual_seed(0)
+    ci, co, s, h, w_ = 16, 8, 4, 3, 5
+    wt = torch.randn(ci, co, s, s)
+    b = torch.randn(co)
+    x = torch.randn(2, ci, h, w_)
+    wp, bt = ops.pack_convT_weight(wt, b, torch.float32)
+    assert wp.shape == (s * s * co, 64) and bt.shape == (s * s * co,)
+    y = x.permute(0, 2, 3, 1).reshape(-1, ci) @ wp[:, :ci].t() + bt  # rows (b,y,x), cols (dy,dx,co)
+    y = y.view(2, h, w_, s, s, co).permute(0, 1, 3, 2, 4, 5).reshape(2, h * s, w_ * s, co)
+    ref = F.conv_transpose2d(x, wt, b, stride=s).permute(0, 2, 3, 1)
+    assert torch.allclose(y, ref, atol=1e-4)
+
+
+def test_pack_linear_pads_k_to_64():
+    w = torch.randn(12, 96)
+    p = ops.pack_linear_weight(w, torch.float16)
+    assert p.shape == (12, 128) and p.dtype == torch.float16
+    assert torch.equal(p[:, :96], w.half()) and p[:, 96:].abs().sum() == 0
+
+
+def test_rope_tables_match_reference_formula():
+    cos, sin = ops.rope_tables(32, 100.0, "cpu")
+    i = torch.arange(16).float()
+    th = torch.arange(32).float()[:, None] * (100.0 ** (-i / 16))[None]
+    assert cos.shape == (32, 16) and torch.allclose(cos, th.cos(), atol=1e-6) and torch.allclose(sin, th.sin(), atol=1e-6)

@@ -1,0 +1,63 @@
+"""The oracle (oracle/fast3r_oracle.py) against (a) the committed reference outputs under tests/golden/ -- runs
+everywhere -- and (b) the live reference, wherever /root/reference exists (the build container)."""
+import copy
+import warnings
+
+import pytest
+import torch
+
+from helpers import GOLDEN_CASES, golden_model_inputs, load_golden, rel_l2
+from oracle import fast3r_oracle as O
+from oracle.ref_loader import reference_available
+
+TOL = 2e-5  # fp32 vs fp32: only summation-order differences (batched vs per-view encoding)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_matches_golden(name):
+    fix = load_golden(name)
+    enc, dec, head, sd, views = golden_model_inputs(fix)
+    torch.manual_seed(fix["rng_seed"])
+    out = O.forward(views, sd, enc, dec, head)
+    assert len(out) == len(fix["preds"])
+    for o, g in zip(out, fix["preds"]):
+        assert set(o) == set(g)
+        for k in g:
+            assert o[k].shape == g[k].shape
+            assert rel_l2(o[k], g[k]) < TOL, (name, k, rel_l2(o[k], g[k]))
+
+
+def test_oracle_image_ids_match_reference_recipe():
+    fix = load_golden("tiny_3x64")
+    torch.manual_seed(fix["rng_seed"])
+    ids = O.random_image_ids(fix["batch"], len(fix["shapes"]))
+    assert torch.equal(ids, fix["image_ids"])
+    assert ids[0, 0] == 0 and len(set(ids[0].tolist())) == ids.shape[1]
+
+
+def test_postprocess_invariants():
+    x = torch.randn(2, 4, 5, 7)
+    r = O.postprocess(x, ["exp", -float("inf"), float("inf")], ["exp", 1, float("inf")])
+    d = x[:, :3].norm(dim=1)
+    assert torch.allclose(r["pts3d"].norm(dim=-1), torch.expm1(d), rtol=1e-5, atol=1e-6)
+    assert (r["conf"] >= 1).all()
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference checkout only exists in the build container")
+def test_oracle_matches_live_reference():
+    from oracle.ref_loader import load_reference
+    from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
+    warnings.filterwarnings("ignore")
+    Fast3R, inference = load_reference()
+    enc, dec, head = tiny_args(embed_dim=192, num_heads=3, enc_depth=2, dec_depth=10)
+    m = Fast3R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head)).eval()
+    sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=11)
+    m.load_state_dict(sd, strict=True)
+    views = make_views(4, 48, 80)
+    torch.manual_seed(3)
+    ref = inference(copy.deepcopy(views), m, torch.device("cpu"), dtype="32", verbose=False)["preds"]
+    torch.manual_seed(3)
+    ora = O.forward(views, sd, enc, dec, head)
+    for o, g in zip(ora, ref):
+        for k in g:
+            assert rel_l2(o[k], g[k]) < TOL, (k, rel_l2(o[k], g[k]))
