@@ -13,6 +13,10 @@ from ._lib import (AttnArgs, F3R_A_CONV3X3, F3R_A_PLAIN, F3R_ACT_GELU, F3R_ACT_N
 
 ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F3R_ACT_RELU}
 
+# Optional per-launch timing of the attention kernel (bench.py's live roofline): when set to a list, every
+# f3r_attn_fwd launch is bracketed by events on the launch stream and (start, end, flops) is appended.
+ATTN_TIMER = None
+
 
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
@@ -202,7 +206,14 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
         a.k_batch_stride[i], a.vt_batch_stride[i] = kbs, vbs
         a.ldk = k.stride(-2)
     a.scale = float(scale)
+    if ATTN_TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().f3r_attn_fwd(ctypes.byref(a), stream_ptr()), "f3r_attn_fwd")
+    if ATTN_TIMER is not None:
+        e1.record()
+        t_k = sum(int(s[2]) for s in segments)
+        ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * 64 * n_heads * batch))
     return out
 
 

@@ -1,0 +1,274 @@
+"""Per-kernel parity on a real MI355X, through the C ABI.  Reference = plain torch fp32/fp64 on CPU applied to the SAME
+16-bit-rounded operands, so the only differences are fp32 accumulation order and the final rounding of lowp outputs.
+Tolerances: fp32 outputs 2e-4 of the output scale; lowp outputs 2^-9 (fp16) / 2^-6 (bf16) relative to the scale.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fast3r_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def lp_tol(dt):
+    return 2.0 ** -9 if dt == torch.float16 else 2.0 ** -6
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt)
+
+
+def assert_close(got, ref, tol, what=""):
+    got, ref = got.detach().double().cpu(), ref.double()
+    scale = float(ref.abs().max().clamp_min(1e-6))
+    err = float((got - ref).abs().max())
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol:.1e})"
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("dt", DTYPES)
+def test_cast_and_patchify_exact(built_lib, dt):
+    x = torch.randn(3, 1000 * 8)
+    assert torch.equal(ops.cast_lp(x.to(DEV), dt).cpu(), x.to(dt))
+    img = torch.rand(2, 3, 48, 80) * 2 - 1
+    got = ops.patchify(img.to(DEV), 16, dt).cpu()
+    ref = F.unfold(img, kernel_size=16, stride=16).transpose(1, 2).reshape(-1, 768).to(dt)  # (c,dy,dx) order = Conv2d weight order
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,D,eps", [(7, 1024, 1e-6), (130, 128, 1e-5), (5, 1280, 1e-6), (3, 4096, 1e-5)])
+def test_layernorm(built_lib, dt, rows, D, eps):
+    x = torch.randn(rows, D) * 3 + 0.5
+    g, b = torch.randn(D), torch.randn(D)
+    lp, f32 = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, dt, want_f32=True)
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), eps)
+    assert_close(f32, ref, 2e-5, "ln f32")
+    assert_close(lp.float(), ref, lp_tol(dt), "ln lowp")
+    rms, _ = ops.layernorm(x.to(DEV), g.to(DEV), None, eps, dt, rms=True)
+    ref_rms = x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + eps) * g.double()
+    assert_close(rms.float(), ref_rms, lp_tol(dt), "rmsnorm")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,h,w,C,crop", [(2, 16, 16, 256, None), (1, 4, 5, 64, (7, 10)), (3, 7, 10, 128, None), (1, 1, 1, 8, None)])
+def test_upsample2x(built_lib, dt, B, h, w, C, crop):
+    x = rnd((B, h, w, C), dt, 1)
+    got = ops.upsample2x(x.to(DEV), crop)
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    if crop:
+        ref = ref[:, :crop[0], :crop[1]]
+    assert got.shape == ref.shape
+    assert_close(got.float(), ref, lp_tol(dt), "upsample")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dpt_final(built_lib, dt):
+    x = rnd((2, 9, 13, 128), dt, 2)
+    w, b = torch.randn(4, 128) * 0.1, torch.randn(4) * 0.1
+    pts, conf = ops.dpt_final(x.to(DEV), w.to(DEV), b.to(DEV), ["exp", 1, float("inf")])
+    y = x.double() @ w.double().t() + b.double()
+    d = y[..., :3].norm(dim=-1, keepdim=True)
+    ref_p = y[..., :3] / d.clip(min=1e-8) * torch.expm1(d)
+    assert_close(pts, ref_p, 1e-5, "pts3d")
+    assert_close(conf, 1 + y[..., 3].exp(), 1e-5, "conf")
+    assert (conf >= 1).all()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 1024), (77, 260, 200), (1024, 512, 768), (2048, 1024, 4096)])
+def test_gemm_bias_f32_and_lowp(built_lib, dt, M, N, K):
+    a, w, bias = rnd((M, K), dt, 3), rnd((N, K), dt, 4, K ** -0.5), torch.randn(N)
+    wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
+    f32, lp = ops.gemm(a.to(DEV), wp, bias=bias.to(DEV), want_f32=True, want_lp=True)
+    ref = a.double() @ w.double().t() + bias.double()
+    assert_close(f32, ref, 2e-5, "gemm f32")
+    assert_close(lp.float(), ref, lp_tol(dt), "gemm lowp")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_epilogues(built_lib, dt):
+    M, N, K, P = 200, 192, 128, 50
+    a, w, bias = rnd((M, K), dt, 5), rnd((N, K), dt, 6, K ** -0.5), torch.randn(N)
+    wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
+    base = a.double() @ w.double().t() + bias.double()
+    # GELU (erf), lowp out
+    _, y = ops.gemm(a.to(DEV), wp, bias=bias.to(DEV), act="gelu", want_lp=True)
+    assert_close(y.float(), F.gelu(base), lp_tol(dt), "gelu")
+    # image-id row add + fp32 residual, in place on the residual buffer
+    rowadd = torch.randn(M // P, N)
+    x = torch.randn(M, N)
+    xg = x.clone().to(DEV)
+    ops.gemm(a.to(DEV), wp, bias=bias.to(DEV), rowadd=rowadd.to(DEV), rowadd_div=P, res_f32=xg, out_f32=xg)
+    assert_close(xg, base + rowadd.double().repeat_interleave(P, 0) + x.double(), 2e-5, "rowadd+res in place")
+    # relu + two lowp residuals
+    r1, r2 = rnd((M, N), dt, 7), rnd((M, N), dt, 8)
+    _, y = ops.gemm(a.to(DEV), wp, bias=bias.to(DEV), act="relu", res_lp=r1.to(DEV), res_lp2=r2.to(DEV), want_lp=True)
+    assert_close(y.float(), F.relu(base) + r1.double() + r2.double(), lp_tol(dt), "relu+2res")
+    # strided A (lda > K) and K tail (K=96 -> Kpad 128)
+    abig = rnd((M, 160), dt, 9)
+    w96 = rnd((N, 96), dt, 10, 0.1)
+    f32, _ = ops.gemm(abig.to(DEV)[:, :96], ops.pack_linear_weight(w96.float(), dt).to(DEV), K=96, want_f32=True)
+    assert_close(f32, abig[:, :96].double() @ w96.double().t(), 2e-5, "strided A, K tail")
+
+
+def _rope_ref(t, pos_y, pos_x, cos, sin):
+    """pos_embed.py:162-183 on (M, H, 64) fp64."""
+    def r1(h, p):
+        c, s = cos[p][:, None, :].double(), sin[p][:, None, :].double()
+        a, b = h[..., :16], h[..., 16:]
+        return torch.cat([a * c - b * s, b * c + a * s], -1)
+    return torch.cat([r1(t[..., :32], pos_y), r1(t[..., 32:], pos_x)], -1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n_seq,gh,gw,D,use_rope", [(3, 8, 8, 128, True), (2, 7, 10, 256, True), (1, 1, 300, 128, False), (1, 1, 70, 128, False)])
+def test_gemm_qkv_epilogue(built_lib, dt, n_seq, gh, gw, D, use_rope):
+    S = gh * gw
+    M, K = n_seq * S, 128
+    a, w, bias = rnd((M, K), dt, 11), rnd((3 * D, K), dt, 12, K ** -0.5), torch.randn(3 * D) * 0.1
+    wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
+    q = torch.empty((M, D), dtype=dt, device=DEV)
+    k = torch.empty((M, D), dtype=dt, device=DEV)
+    ld = ops.vt_ld(S)
+    vt = torch.zeros((n_seq, D, ld), dtype=dt, device=DEV)
+    rope = None
+    if use_rope:
+        cos, sin = ops.rope_tables(max(gh, gw), 100.0, DEV)
+        rope = (cos, sin, gw)
+    ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, rope)
+    ref = a.double() @ w.double().t() + bias.double()
+    rq, rk, rv = ref[:, :D], ref[:, D:2 * D], ref[:, 2 * D:]
+    if use_rope:
+        p = torch.arange(M) % S
+        py, px = p // gw, p % gw
+        rq = _rope_ref(rq.reshape(M, D // 64, 64), py, px, cos.cpu(), sin.cpu()).reshape(M, D)
+        rk = _rope_ref(rk.reshape(M, D // 64, 64), py, px, cos.cpu(), sin.cpu()).reshape(M, D)
+    assert_close(q.float(), rq, lp_tol(dt), "q")
+    assert_close(k.float(), rk, lp_tol(dt), "k")
+    got_v = vt[:, :, :S].float().cpu().permute(0, 2, 1).reshape(M, D)
+    assert_close(got_v, rv, lp_tol(dt), "v^T")
+    assert float(vt[:, :, S:].abs().sum()) == 0.0  # padding untouched
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 8, 8, 256, 256, 1), (1, 16, 12, 96, 256, 1), (2, 9, 7, 768, 128, 2), (1, 32, 32, 128, 128, 1), (3, 5, 5, 192, 64, 2)])
+def test_conv3x3(built_lib, dt, B, H, W, Ci, Co, stride):
+    x = rnd((B, H, W, Ci), dt, 13)
+    w = rnd((Co, Ci, 3, 3), dt, 14, (9 * Ci) ** -0.5)
+    bias = torch.randn(Co)
+    wp = ops.pack_conv3x3_weight(w.float(), dt).to(DEV)
+    y = ops.conv3x3(x.to(DEV), wp, stride=stride, bias=bias.to(DEV))
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=stride, padding=1).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert_close(y.float(), ref, lp_tol(dt), "conv3x3")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv3x3_rcu_fusions(built_lib, dt):
+    """pre-ReLU on the operand + bias + two residual adds = ResidualConvUnit_custom inside a fusion block."""
+    B, H, W, C = 2, 10, 6, 256
+    x, extra = rnd((B, H, W, C), dt, 15), rnd((B, H, W, C), dt, 16)
+    w = rnd((C, C, 3, 3), dt, 17, (9 * C) ** -0.5)
+    bias = torch.randn(C) * 0.1
+    wp = ops.pack_conv3x3_weight(w.float(), dt).to(DEV)
+    y = ops.conv3x3(x.to(DEV), wp, bias=bias.to(DEV), a_relu=True, res_lp=x.to(DEV), res_lp2=extra.to(DEV))
+    ref = F.conv2d(F.relu(x.double()).permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + x.double() + extra.double()
+    assert_close(y.float(), ref, lp_tol(dt), "rcu conv")
+    y = ops.conv3x3(x.to(DEV), wp, bias=bias.to(DEV), act="relu")
+    ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), padding=1)).permute(0, 2, 3, 1)
+    assert_close(y.float(), ref, lp_tol(dt), "conv+relu")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,h,w,Ci,Co,s", [(2, 4, 4, 96, 96, 4), (1, 7, 10, 192, 192, 2), (3, 2, 3, 96, 96, 4)])
+def test_conv_transpose(built_lib, dt, B, h, w, Ci, Co, s):
+    x = rnd((B, h, w, Ci), dt, 18)
+    wt = rnd((Ci, Co, s, s), dt, 19, Ci ** -0.5)
+    bias = torch.randn(Co)
+    wp, bt = ops.pack_convT_weight(wt.float(), bias, dt)
+    y = ops.convT(x.to(DEV), wp.to(DEV), bt.to(DEV), s, Co)
+    ref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), wt.double(), bias.double(), stride=s).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert_close(y.float(), ref, lp_tol(dt), "convT")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, H, scale):
+    """q (Tq, H*64), k/v (Tk, H*64) lowp -> fp64 softmax(q k^T scale) v."""
+    Tq, Tk = q.shape[0], k.shape[0]
+    qh, kh, vh = (t.double().reshape(-1, H, 64).transpose(0, 1) for t in (q, k, v))
+    a = ((qh @ kh.transpose(1, 2)) * scale).softmax(-1)
+    return (a @ vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+def _vt_of(v, H):
+    """(T, H*64) -> zero padded V^T [H*64][ld]"""
+    T = v.shape[0]
+    vt = torch.zeros((H * 64, ops.vt_ld(T)), dtype=v.dtype)
+    vt[:, :T] = v.t()
+    return vt
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,H,scale", [(16, 2, 0.125), (64, 2, 0.160192), (100, 1, 0.125), (256, 2, 0.125), (1000, 2, 0.160192), (3072, 1, 0.125)])
+def test_attention_single_segment(built_lib, dt, T, H, scale):
+    q, k, v = rnd((T, H * 64), dt, 20), rnd((T, H * 64), dt, 21), rnd((T, H * 64), dt, 22)
+    o = torch.empty((T, H * 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, scale, [(k.to(DEV), _vt_of(v, H).to(DEV), T, 0, 0)])
+    assert_close(o.float(), _attn_ref(q, k, v, H, scale), 2 * lp_tol(dt), f"attn T={T}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_segments_equal_concatenation(built_lib, dt):
+    """Uneven K/V segments (the view-sharded multi-GPU layout, incl. a padded and an empty one) == one segment."""
+    H, Tq = 2, 200
+    lens = [130, 0, 64, 257]
+    q = rnd((Tq, H * 64), dt, 23)
+    ks = [rnd((max(n, 1), H * 64), dt, 30 + i) for i, n in enumerate(lens)]
+    vs = [rnd((max(n, 1), H * 64), dt, 40 + i) for i, n in enumerate(lens)]
+    segs = []
+    for kk, vv, n in zip(ks, vs, lens):
+        pad_k = torch.cat([kk[:n], torch.full((7, H * 64), float("nan"), dtype=dt)])  # rows past seg_len must never be read as keys
+        segs.append((pad_k.to(DEV), _vt_of(vv[:n], H).to(DEV) if n else _vt_of(vv[:1] * 0, H).to(DEV), n, 0, 0))
+    o = torch.empty((Tq, H * 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, segs)
+    kcat = torch.cat([kk[:n] for kk, n in zip(ks, lens)])
+    vcat = torch.cat([vv[:n] for vv, n in zip(vs, lens)])
+    assert_close(o.float(), _attn_ref(q, kcat, vcat, H, 0.125), 2 * lp_tol(dt), "segments")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_batched_sequences(built_lib, dt):
+    """Encoder layout: batch of independent sequences, strided batch access."""
+    nb, S, H = 3, 80, 2
+    D = H * 64
+    q, k, v = rnd((nb * S, D), dt, 50), rnd((nb * S, D), dt, 51), rnd((nb * S, D), dt, 52)
+    ld = ops.vt_ld(S)
+    vt = torch.zeros((nb, D, ld), dtype=dt)
+    for b in range(nb):
+        vt[b, :, :S] = v[b * S:(b + 1) * S].t()
+    o = torch.empty((nb * S, D), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, [(k.to(DEV), vt.to(DEV), S, S * D, D * ld)], tq=S, batch=nb, q_batch_stride=S * D, o_batch_stride=S * D)
+    ref = torch.cat([_attn_ref(q[b * S:(b + 1) * S], k[b * S:(b + 1) * S], v[b * S:(b + 1) * S], H, 0.125) for b in range(nb)])
+    assert_close(o.float(), ref, 2 * lp_tol(dt), "batched attn")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_online_softmax_rescale_is_forced(built_lib, dt):
+    """A key far above the rest, placed in a LATE tile: the running max must jump and every earlier contribution be
+    rescaled (the rare data-dependent branch gets its own test)."""
+    T, H = 640, 1
+    q, k, v = rnd((T, 64), dt, 60), rnd((T, 64), dt, 61, 0.3), rnd((T, 64), dt, 62)
+    k[500] = (q[7].float() * 3.0).to(dt)  # q7 . k500 >> everything else, in tile 7
+    k[130] = (q[300].float() * 2.0).to(dt)
+    o = torch.empty((T, 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, [(k.to(DEV), _vt_of(v, H).to(DEV), T, 0, 0)])
+    assert_close(o.float(), _attn_ref(q, k, v, H, 0.125), 2 * lp_tol(dt), "forced rescale")
