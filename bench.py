@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--views", type=int, default=320, help="total views N of the forward pass (BASELINE headline: 320)")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type (fp32 accumulate)")
+    ap.add_argument("--dtype", default="bf16", choices=["fp16", "bf16"], help="MFMA operand type (fp32 accumulate)")
     ap.add_argument("--fusion-only", action="store_true",
                     help="BASELINE configs[1]: time only the fusion decoder on frozen random encoder features")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -260,6 +260,7 @@ class Fast3R(nn.Module):
         self.max_parallel_views_for_encoder = 128  # the reference chunks at 400 (fast3r.py:250); bounds the workspace
         self.compute_dtype = compute_dtype
         self.sharding = None  # set by shard_views(): view-sharded multi-GPU execution (fast3r_amd/dist.py)
+        self.debug_taps = None  # set to a dict to capture the lowp DPT inputs (hooks 0, L/2, 3L/4, L) per sample
         self._packed = None
         self._rope_cache = {}
         self.set_freeze(freeze)
@@ -552,6 +553,8 @@ class Fast3R(nn.Module):
             w_, b_, eps = pk["dec_norm"]
             taps[L], _ = ops.layernorm(x, w_, b_, eps, lp)
             hook_toks.append([taps[hk] for hk in hooks])
+            if self.debug_taps is not None:
+                self.debug_taps.setdefault("hooks", []).append([t.float().cpu() for t in hook_toks[-1]])
             del x
         if profiling:
             torch.cuda.synchronize()

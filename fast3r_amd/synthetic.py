@@ -47,27 +47,41 @@ def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64
     return encoder_args, decoder_args, head_args
 
 
-def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
-    """One tensor of a synthetic state_dict; a pure function of (key, shape, seed).
+def synth_tensor(key: str, shape, seed: int = 0, dist: str = "default") -> torch.Tensor:
+    """One tensor of a synthetic state_dict; a pure function of (key, shape, seed, dist).
 
-    Weights (ndim >= 2) ~ N(0, 1/fan_in) so activations stay O(1) through 48 blocks;
-    LayerNorm weights ~ 1 + 0.1 N(0,1); biases ~ 0.02 N(0,1).
+    dist="default": the distribution of the reference's own random init (torch defaults, which is all the reference
+        applies on this path): Linear / Conv2d / ConvTranspose2d weight and bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)).
+        This is the protocol of BASELINE.md section 3 / SURVEY.md section 8c (the 1e-3 rel-L2 yardstick).
+    dist="hot": weights ~ N(0, 1/fan_in) (3x the variance): attention logits have std ~1.3 instead of ~0.15, so the
+        softmax is far from uniform and rounding noise is amplified instead of averaged away -- a stress distribution.
+    LayerNorm gamma ~ 1 + 0.1 N(0,1), beta ~ 0.02 N(0,1) in both (so gamma/beta mistakes cannot hide).
     """
     g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
     shape = tuple(shape)
+    is_norm = ".norm" in key or key.endswith("_norm.weight") or key.endswith("_norm.bias")
+    if is_norm:
+        if key.endswith("weight"):
+            return 1.0 + 0.1 * torch.randn(shape, generator=g)
+        return 0.02 * torch.randn(shape, generator=g)
     if len(shape) >= 2:
         if key.endswith("act_postprocess.0.1.weight") or key.endswith("act_postprocess.1.1.weight"):
-            fan_in = shape[0]  # ConvTranspose2d weight is (Cin, Cout, k, k); k == stride -> one tap per output
+            fan_in = shape[1] * shape[2] * shape[3]  # ConvTranspose2d (Cin, Cout, k, k): torch's fan_in = size(1) * k * k
+            eff = shape[0]                            # but each output pixel sums over Cin only
         else:
-            fan_in = math.prod(shape[1:])
-        gain = 0.1 if key.endswith("dpt.head.4.weight") else 1.0  # keeps |xyz| = O(1) ahead of expm1 / exp
-        return torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
-    if key.endswith("weight"):  # LayerNorm gamma
-        return 1.0 + 0.1 * torch.randn(shape, generator=g)
-    return 0.02 * torch.randn(shape, generator=g)
+            fan_in = eff = math.prod(shape[1:])
+        if dist == "hot":
+            gain = 0.1 if key.endswith("dpt.head.4.weight") else 1.0  # keeps |xyz| = O(1) ahead of expm1 / exp
+            return torch.randn(shape, generator=g) * (gain / math.sqrt(eff))
+        bound = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+    if dist == "hot":
+        return 0.02 * torch.randn(shape, generator=g)
+    # bias: U(+-1/sqrt(fan_in)); fan_in is not recoverable from the bias shape alone, use the layer width as proxy
+    return (torch.rand(shape, generator=g) * 2 - 1) * (1.0 / math.sqrt(max(shape[0], 1)))
 
 
-def synth_state_dict(shapes: dict, seed: int = 0) -> dict:
+def synth_state_dict(shapes: dict, seed: int = 0, dist: str = "default") -> dict:
     """shapes: {key: shape} (e.g. from `model.state_dict()`) -> deterministic fp32 state_dict.
 
     `scratch.layer_rn.{i}` aliases `scratch.layer{i+1}_rn` (dpt_block.py:79-86); aliases get equal values.
@@ -77,7 +91,7 @@ def synth_state_dict(shapes: dict, seed: int = 0) -> dict:
         canon = k
         for i in range(4):
             canon = canon.replace(f"scratch.layer_rn.{i}.", f"scratch.layer{i + 1}_rn.")
-        out[k] = synth_tensor(canon, shp, seed)
+        out[k] = synth_tensor(canon, shp, seed, dist)
     return out
 
 

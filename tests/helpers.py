@@ -7,7 +7,7 @@ import torch
 from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid"]
+GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid", "tiny_hot_3x64"]
 
 
 def load_golden(name):
@@ -26,7 +26,7 @@ def golden_views(fix, seed=1000):
 def golden_model_inputs(fix):
     """-> (encoder_args, decoder_args, head_args, state_dict, views)"""
     enc, dec, head = tiny_args(**fix["tiny_kwargs"])
-    sd = synth_state_dict(fix["state_shapes"], fix["weight_seed"])
+    sd = synth_state_dict(fix["state_shapes"], fix["weight_seed"], fix["weight_dist"])
     return enc, dec, head, sd, golden_views(fix)
 
 
