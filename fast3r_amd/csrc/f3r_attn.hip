@@ -19,19 +19,26 @@
 //
 // K/V arrive as segments (f3r_attn_args.k_seg / vt_seg): the single-GPU path uses one segment, the
 // view-sharded multi-GPU path passes the local shard plus the all-gathered remote shards.
+#include <stdlib.h>
+
 #include "f3r_common.h"
 
 namespace {
 
-constexpr int AT_NT = 512;
-constexpr int AT_QB = 256;  // queries per workgroup
 constexpr int AT_KB = 64;   // keys per tile
 constexpr int AT_TILE = 64 * 64;
 
 __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-template <class T>
-__global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
+// NW   waves per workgroup (4 or 8)
+// QPW  32-query blocks per wave (1 or 2): with 2, every K / V^T fragment read from LDS feeds two MFMAs
+// OPT  bit 0: skip the O rescale when no running max of the wave moved (exact, wave-uniform branch)
+//      bit 1: s_setprio 1 around the MFMA clusters
+template <class T, int NW, int QPW, int OPT, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * QPW * 32;  // queries per workgroup
+  constexpr int CPT = 512 / NT;      // 16-byte chunks of each tile staged per thread
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];  // [buf][K | Vt][64][64] = 32 KB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -41,28 +48,33 @@ __global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
 
   const int head = blockIdx.y;
   const int b = blockIdx.z;
-  const int64_t q0 = (int64_t)blockIdx.x * AT_QB + wid * 32;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * (QPW * 32);
 
   // ---- Q fragments (B operand of K Q^T): lane (q, g) holds Q[q][ds*16 + g*8 .. +7]
   const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
-  int64_t qrow = q0 + lq;
-  const bool q_ok = qrow < p.tq;
-  if (!q_ok) qrow = p.tq - 1;
-  typename T::vec8 qf[4];
+  int64_t qrow[QPW];
+  bool q_ok[QPW];
+  typename T::vec8 qf[QPW][4];
 #pragma unroll
-  for (int ds = 0; ds < 4; ++ds)
-    qf[ds] = as_vec8<T>(*(const u32x4*)(Qg + qrow * p.ldq + head * 64 + ds * 16 + g * 8));
+  for (int qb = 0; qb < QPW; ++qb) {
+    qrow[qb] = q0 + qb * 32 + lq;
+    q_ok[qb] = qrow[qb] < p.tq;
+    if (!q_ok[qb]) qrow[qb] = p.tq - 1;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+      qf[qb][ds] = as_vec8<T>(*(const u32x4*)(Qg + qrow[qb] * p.ldq + head * 64 + ds * 16 + g * 8));
+  }
 
-  // ---- staging role: one 16 B chunk of the K tile and one of the V^T tile per thread
-  const int srow = tid >> 3;  // key row (K) / d row (V^T)
+  // ---- staging role: CPT 16 B chunks of the K tile and of the V^T tile per thread
   const int sch = tid & 7;
+  const int srow0 = tid >> 3;  // + i * (NT / 8)
 
   // flattened (segment, tile) iteration
   int seg_ld = 0;
   int64_t tile_ld = 0;  // next tile to load inside seg_ld
   while (seg_ld < p.n_seg && p.seg_len[seg_ld] <= 0) ++seg_ld;
 
-  u32x4 rk, rv;
+  u32x4 rk[CPT], rv[CPT];
   int valid_ld = 0;  // valid keys of the tile held in (rk, rv)
   auto load_next = [&]() -> bool {
     if (seg_ld >= p.n_seg) return false;
@@ -72,12 +84,15 @@ __global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
     valid_ld = rem < AT_KB ? (int)rem : AT_KB;
     const uint16_t* Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld];
     const uint16_t* Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld];
-    u32x4 z = {0u, 0u, 0u, 0u};
-    rk = z;
-    if (srow < valid_ld) rk = *(const u32x4*)(Kg + (key0 + srow) * p.ldk + head * 64 + sch * 8);
-    // V^T rows are padded to ldvt (multiple of 64, pad zeroed by the host), so the chunk is always in bounds
-    rv = *(const u32x4*)(Vg + ((int64_t)head * 64 + srow) * p.ldvt[seg_ld] + key0 + sch * 8);
-    // advance
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int srow = srow0 + i * (NT / 8);
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rk[i] = z;
+      if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key0 + srow) * p.ldk + head * 64 + sch * 8);
+      // V^T rows are padded to ldvt (multiple of 64, pad zeroed by the host), so the chunk is always in bounds
+      rv[i] = *(const u32x4*)(Vg + ((int64_t)head * 64 + srow) * p.ldvt[seg_ld] + key0 + sch * 8);
+    }
     ++tile_ld;
     if (tile_ld * AT_KB >= len) {
       tile_ld = 0;
@@ -89,15 +104,23 @@ __global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
   auto store_tile = [&](int buf) {
     uint16_t* kt = lds + buf * 2 * AT_TILE;
     uint16_t* vt = kt + AT_TILE;
-    *(u32x4*)(kt + aswz(srow, sch)) = rk;
-    *(u32x4*)(vt + aswz(srow, sch)) = rv;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int srow = srow0 + i * (NT / 8);
+      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
+      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
+    }
   };
 
-  float16v o[2];
+  float16v o[QPW][2];
+  float m_run[QPW], l_run[QPW];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -1e30f;  // running max of the raw scores
-  float l_run = 0.f;     // this lane's partial row sum (its own 32 keys per tile)
+  for (int qb = 0; qb < QPW; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; }
+    m_run[qb] = -1e30f;  // running max of the raw scores
+    l_run[qb] = 0.f;     // this lane's partial row sum (its own 32 keys per tile)
+  }
   const float c = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*c)
 
   // pi: swap bits 2 and 3 of the key row index fed to the MFMA A operand
@@ -115,64 +138,82 @@ __global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
     const uint16_t* vt = kt + AT_TILE;
 
     // ---- S^T = K Q^T
-    float16v s[2];
+    float16v s[QPW][2];
+    if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      for (int qb = 0; qb < QPW; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
         const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(kt + aswz(kb * 32 + krow_pi, ds * 2 + g)));
-        s[kb] = T::mfma32(a, qf[ds], s[kb]);
+#pragma unroll
+        for (int qb = 0; qb < QPW; ++qb) s[qb][kb] = T::mfma32(a, qf[qb][ds], s[qb][kb]);
       }
     }
+    if (OPT & 2) __builtin_amdgcn_s_setprio(0);
     // register r of block kb is key  kb*32 + 16*(r>>3) + 8*g + (r&7)  of the tile
     if (valid < AT_KB) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int qb = 0; qb < QPW; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
-          if (key >= valid) s[kb][r] = -1e30f;
-        }
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
+            if (key >= valid) s[qb][kb][r] = -1e30f;
+          }
     }
     // ---- online softmax (fp32)
-    float mx = s[0][0];
+    typename T::vec8 pf[QPW][4];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    for (int qb = 0; qb < QPW; ++qb) {
+      float mx = s[qb][0][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
-    float psum = 0.f;
-    typename T::vec8 pf[4];
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 pk;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qb], mx);
+      const bool moved = m_new > m_run[qb];
+      const float mc = m_new * c;
+      float psum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][(ks & 1) * 8 + 2 * j], c, -mc));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ks >> 1][(ks & 1) * 8 + 2 * j + 1], c, -mc));
-        psum += p0 + p1;
-        pk[j] = pack2<T>(p0, p1);
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j], c, -mc));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1], c, -mc));
+          psum += p0 + p1;
+          pk[j] = pack2<T>(p0, p1);
+        }
+        pf[qb][ks] = as_vec8<T>(pk);
       }
-      pf[ks] = as_vec8<T>(pk);
-    }
-    l_run = l_run * alpha + psum;
+      if (!(OPT & 1) || __any(moved)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+        l_run[qb] = l_run[qb] * alpha + psum;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o[qb][0][i] *= alpha; o[qb][1][i] *= alpha; }
+      } else {
+        l_run[qb] += psum;
+      }
+      m_run[qb] = m_new;
+    }
 
     // ---- O^T += V^T P^T
+    if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(vt + aswz(db * 32 + lq, ks * 2 + g)));
-        o[db] = T::mfma32(a, pf[ks], o[db]);
+#pragma unroll
+        for (int qb = 0; qb < QPW; ++qb) o[qb][db] = T::mfma32(a, pf[qb][ks], o[qb][db]);
       }
+    if (OPT & 2) __builtin_amdgcn_s_setprio(0);
 
     if (more) store_tile(cur ^ 1);
     valid_cur = valid_ld;
@@ -182,23 +223,71 @@ __global__ __launch_bounds__(AT_NT, 2) void attn_kernel(const f3r_attn_args p) {
   }
 
   // ---- epilogue: normalise, store O[q][head*64 + d], d = db*32 + (r&3) + 8*(r>>2) + 4*g
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_ok) {
-    uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow * p.ldo + head * 64;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int qb = 0; qb < QPW; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_ok[qb]) {
+      uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow[qb] * p.ldo + head * 64;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 w;
-        w[0] = pack2<T>(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
-        w[1] = pack2<T>(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
-        *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
-      }
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          u32x2 w;
+          w[0] = pack2<T>(o[qb][db][rq * 4 + 0] * inv, o[qb][db][rq * 4 + 1] * inv);
+          w[1] = pack2<T>(o[qb][db][rq * 4 + 2] * inv, o[qb][db][rq * 4 + 3] * inv);
+          *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
+        }
+    }
   }
 }
 
+template <class T, int NW, int QPW, int OPT, int MINW>
+int attn_launch(const f3r_attn_args& a, hipStream_t s) {
+  constexpr int QB = NW * QPW * 32;
+  const int64_t qblocks = (a.tq + QB - 1) / QB;
+  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
+  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
+  hipLaunchKernelGGL((attn_kernel<T, NW, QPW, OPT, MINW>), grid, dim3(NW * 64), 0, s, a);
+  return f3r_check_launch("f3r_attn_fwd");
+}
+
+// kernel variants, selectable with F3R_ATTN_VARIANT for A/B measurement (tools/attn_bench.py)
+template <class T>
+int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
+  switch (variant) {
+    case 0: return attn_launch<T, 8, 1, 0, 2>(a, s);  // round-1 first light: 8 waves in barrier lockstep
+    case 1: return attn_launch<T, 4, 1, 0, 3>(a, s);  // 4-wave workgroups, 3 independent workgroups per CU
+    case 2: return attn_launch<T, 4, 1, 3, 3>(a, s);  // + skip-rescale + setprio
+    case 3: return attn_launch<T, 4, 2, 3, 2>(a, s);  // 2 query blocks per wave (LDS fragment reuse), 2 WG / CU
+    case 4: return attn_launch<T, 8, 1, 3, 2>(a, s);  // 8 waves + skip-rescale + setprio
+    case 5: return attn_launch<T, 4, 1, 1, 3>(a, s);  // 4 waves + skip-rescale only
+    default: f3r_set_error("f3r_attn_fwd: unknown variant %d", variant); return F3R_ERR_ARG;
+  }
+}
+
+constexpr int AT_DEFAULT_VARIANT = 2;
+
+int g_variant = -1;
+
+int attn_variant() {
+  if (g_variant < 0) {
+    const char* e = getenv("F3R_ATTN_VARIANT");
+    g_variant = e ? atoi(e) : AT_DEFAULT_VARIANT;
+  }
+  return g_variant;
+}
+
 }  // namespace
+
+extern "C" int f3r_attn_set_variant(int variant) {
+  if (variant < -1 || variant > 5) {
+    f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
+    return F3R_ERR_ARG;
+  }
+  g_variant = variant < 0 ? AT_DEFAULT_VARIANT : variant;
+  return F3R_OK;
+}
 
 extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(args != nullptr, "f3r_attn_fwd: null args");
@@ -224,13 +313,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   }
   F3R_REQUIRE(total > 0, "f3r_attn_fwd: no keys");
   if (a.tq == 0) return F3R_OK;
-  const int64_t qblocks = (a.tq + AT_QB - 1) / AT_QB;
-  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
-  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
   hipStream_t s = (hipStream_t)stream;
-  if (a.dtype == F3R_F16)
-    hipLaunchKernelGGL(attn_kernel<F16>, grid, dim3(AT_NT), 0, s, a);
-  else
-    hipLaunchKernelGGL(attn_kernel<BF16>, grid, dim3(AT_NT), 0, s, a);
-  return f3r_check_launch("f3r_attn_fwd");
+  const int variant = attn_variant();
+  return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

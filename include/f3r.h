@@ -157,6 +157,10 @@ typedef struct f3r_attn_args {
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
 
+/* Tuning knob (measurement only): selects the workgroup shape / schedule variant of the attention kernel
+ * (fast3r_amd/csrc/f3r_attn.hip, attn_dispatch); -1 restores the default.  All variants compute the same function. */
+int f3r_attn_set_variant(int variant);
+
 /* ---------------------------------------------------------------------------------------------
  * f3r_upsample2x: bilinear x2, align_corners=True, NHWC lowp -> NHWC lowp.
  * Replaces F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) in

@@ -1,0 +1,159 @@
+"""Kernel micro-benchmarks on the GPU box (interleaved rounds, random data, HIP events on the launch stream):
+attention variants on fusion / encoder shapes and the model's GEMM / conv shapes.  Prints one JSON line per item."""
+import argparse
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from fast3r_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def time_ms(fn, rounds=5, inner=3):
+    best = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / inner)
+    best.sort()
+    return best[len(best) // 2], best[0]
+
+
+def bench_attn(dt, views, variants, H=16):
+    T = views * 1024
+    D = H * 64
+    q = torch.randn((T, D), device=DEV).to(dt)
+    k = torch.randn((T, D), device=DEV).to(dt)
+    vt = torch.randn((D, T), device=DEV).to(dt)
+    o = torch.empty((T, D), dtype=dt, device=DEV)
+    flops = 4.0 * T * T * 64 * H
+    res = {}
+    fns = {}
+    for v in variants:
+        def f(v=v):
+            _lib.lib().f3r_attn_set_variant(v)
+            ops.attention(q, o, H, 0.160192, [(k, vt, T, 0, 0)])
+        fns[v] = f
+        f()
+    torch.cuda.synchronize()
+    ref = None
+    for v in variants:  # all variants must agree
+        fns[v]()
+        torch.cuda.synchronize()
+        cur = o.float().clone()
+        if ref is None:
+            ref = cur
+        else:
+            assert float((cur - ref).abs().max()) < 2e-2, ("variant mismatch", v)
+    for rnd in range(3):  # interleaved
+        for v in variants:
+            med, mn = time_ms(fns[v], rounds=3, inner=2)
+            res.setdefault(v, []).append(med)
+    for v in variants:
+        ms = sorted(res[v])[1]
+        print(json.dumps({"kernel": "attn", "dtype": str(dt).split(".")[-1], "views": views, "T": T, "variant": v, "ms": round(ms, 3),
+                          "tflops": round(flops / ms / 1e9, 1)}), flush=True)
+    _lib.lib().f3r_attn_set_variant(-1)
+
+
+def bench_attn_encoder(dt, views, variants, H=16):
+    S, D = 1024, H * 64
+    q = torch.randn((views * S, D), device=DEV).to(dt)
+    k = torch.randn((views * S, D), device=DEV).to(dt)
+    vt = torch.randn((views, D, S), device=DEV).to(dt)
+    o = torch.empty_like(q)
+    flops = 4.0 * S * S * 64 * H * views
+    for v in variants:
+        def f():
+            _lib.lib().f3r_attn_set_variant(v)
+            ops.attention(q, o, H, 0.125, [(k, vt, S, S * D, D * S)], tq=S, batch=views, q_batch_stride=S * D, o_batch_stride=S * D)
+        f()
+        med, mn = time_ms(f)
+        print(json.dumps({"kernel": "attn_encoder", "dtype": str(dt).split(".")[-1], "views": views, "variant": v, "ms": round(med, 3),
+                          "tflops": round(flops / med / 1e9, 1)}), flush=True)
+    _lib.lib().f3r_attn_set_variant(-1)
+
+
+def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32"):
+    a = torch.randn((M, K), device=DEV).to(dt)
+    w = ops.pack_linear_weight(torch.randn((N, K), device=DEV) * K ** -0.5, dt)
+    bias = torch.randn(N, device=DEV)
+    x = torch.randn((M, N), device=DEV) if (res or out == "f32") else None
+    olp = torch.empty((M, N), dtype=dt, device=DEV) if out == "lp" else None
+
+    def f():
+        if out == "f32":
+            ops.gemm(a, w, bias=bias, act=act, res_f32=x if res else None, out_f32=x)
+        else:
+            ops.gemm(a, w, bias=bias, act=act, out_lp=olp)
+    f()
+    med, mn = time_ms(f)
+    print(json.dumps({"kernel": "gemm", "name": name, "dtype": str(dt).split(".")[-1], "M": M, "N": N, "K": K, "ms": round(med, 3),
+                      "tflops": round(2.0 * M * N * K / med / 1e9, 1)}), flush=True)
+
+
+def bench_qkv(dt, M, D, seq):
+    a = torch.randn((M, D), device=DEV).to(dt)
+    w = ops.pack_linear_weight(torch.randn((3 * D, D), device=DEV) * D ** -0.5, dt)
+    bias = torch.randn(3 * D, device=DEV)
+    q = torch.empty((M, D), dtype=dt, device=DEV)
+    k = torch.empty((M, D), dtype=dt, device=DEV)
+    vt = torch.empty((M // seq, D, seq), dtype=dt, device=DEV)
+    cos, sin = ops.rope_tables(32, 100.0, DEV)
+    for rope in (None, (cos, sin, 32)):
+        def f():
+            ops.gemm_qkv(a, w, bias, q, k, vt, seq, rope)
+        f()
+        med, mn = time_ms(f)
+        print(json.dumps({"kernel": "gemm_qkv", "rope": rope is not None, "dtype": str(dt).split(".")[-1], "M": M, "seq": seq, "ms": round(med, 3),
+                          "tflops": round(2.0 * M * 3 * D * D / med / 1e9, 1)}), flush=True)
+
+
+def bench_conv(dt, B, H, W, Ci, Co, name, stride=1):
+    x = torch.randn((B, H, W, Ci), device=DEV).to(dt)
+    w = ops.pack_conv3x3_weight(torch.randn((Co, Ci, 3, 3), device=DEV) * (9 * Ci) ** -0.5, dt)
+    bias = torch.randn(Co, device=DEV)
+
+    def f():
+        ops.conv3x3(x, w, stride=stride, bias=bias, a_relu=True)
+    f()
+    med, mn = time_ms(f)
+    oh, ow = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    print(json.dumps({"kernel": "conv3x3", "name": name, "dtype": str(dt).split(".")[-1], "B": B, "HW": [H, W], "Ci": Ci, "Co": Co, "ms": round(med, 3),
+                      "tflops": round(2.0 * B * oh * ow * 9 * Ci * Co / med / 1e9, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="attn,gemm,conv")
+    ap.add_argument("--variants", default="0,1,2,3,4,5")
+    ap.add_argument("--views", default="20,100")
+    args = ap.parse_args()
+    variants = [int(v) for v in args.variants.split(",")]
+    dt = torch.bfloat16
+    if "attn" in args.what:
+        for nv in [int(v) for v in args.views.split(",")]:
+            bench_attn(dt, nv, variants)
+        bench_attn(torch.float16, 20, variants[:3])
+        bench_attn_encoder(dt, 64, variants)
+    if "gemm" in args.what:
+        M = 40 * 1024
+        bench_gemm(dt, M, 1024, 1024, "proj+res", res=True)
+        bench_gemm(dt, M, 4096, 1024, "fc1+gelu", act="gelu", out="lp")
+        bench_gemm(dt, M, 1024, 4096, "fc2+res", res=True)
+        bench_gemm(dt, M, 1024, 768, "patch_embed")
+        bench_qkv(dt, M, 1024, 1024)
+        bench_qkv(dt, M, 1024, M)
+    if "conv" in args.what:
+        bench_conv(dt, 8, 128, 128, 256, 256, "refinenet1 rcu")
+        bench_conv(dt, 8, 256, 256, 256, 128, "head0")
+        bench_conv(dt, 8, 512, 512, 128, 128, "head2")
+        bench_conv(dt, 8, 64, 64, 256, 256, "refinenet2 rcu")
+        bench_conv(dt, 8, 32, 32, 768, 768, "act3 s2", stride=2)
