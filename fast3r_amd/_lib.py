@@ -34,7 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("out_f32", _c_vp), ("ldo_f32", _c_i64),
         ("out_lp", _c_vp), ("ldo_lp", _c_i64),
         ("q", _c_vp), ("k", _c_vp), ("vt", _c_vp), ("seq_len", _c_i64), ("ldvt", _c_i64),
-        ("rope_cos", _c_vp), ("rope_sin", _c_vp), ("rope_w", _c_i32),
+        ("rope_cos", _c_vp), ("rope_sin", _c_vp), ("rope_w", _c_i32), ("q_scale", _c_f32),
         ("ct_s", _c_i32), ("ct_h", _c_i32), ("ct_w", _c_i32), ("ct_cout", _c_i32),
         ("dtype", _c_i32),
     ]
@@ -52,7 +52,7 @@ class AttnArgs(ctypes.Structure):
         ("seg_len", _c_i64 * F3R_MAX_SEG), ("ldvt", _c_i64 * F3R_MAX_SEG),
         ("ldk", _c_i64),
         ("k_batch_stride", _c_i64 * F3R_MAX_SEG), ("vt_batch_stride", _c_i64 * F3R_MAX_SEG),
-        ("scale", _c_f32),
+        ("scale", _c_f32), ("q_prescaled", _c_i32),
     ]
 
 

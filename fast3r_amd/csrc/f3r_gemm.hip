@@ -293,6 +293,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
             v[2 * h + 1] = b * c + a * s;
           }
         }
+        if (part == 0 && p.q_scale != 0.f) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) v[nf] *= p.q_scale;
+        }
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           const int nb = n0 + wn * 64 + nf * 16 + fg * 4 - part * Dm;

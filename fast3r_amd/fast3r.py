@@ -389,13 +389,14 @@ class Fast3R(nn.Module):
                 torch.empty((n_seq, D, ldvt), dtype=lp, device=x.device)
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
-        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope)
+        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E)
         if kv_exchange is None:
             segs = [(k, vt, seq_len, seq_len * D, D * ldvt)]
         else:
             segs = kv_exchange.exchange()
         o = h  # LN output is dead: reuse as the attention output buffer
-        ops.attention(q, o, n_heads, scale, segs, tq=seq_len, batch=n_seq, q_batch_stride=seq_len * D, o_batch_stride=seq_len * D)
+        ops.attention(q, o, n_heads, scale, segs, tq=seq_len, batch=n_seq, q_batch_stride=seq_len * D, o_batch_stride=seq_len * D,
+                      q_prescaled=True)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o)
         _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)

@@ -125,7 +125,10 @@ def vt_ld(seq_len: int) -> int:
     return round_up(seq_len, 64)
 
 
-def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None):
+LOG2E = 1.4426950408889634
+
+
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0):
     """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE-2D'd), v -> vt[M/seq][D][ldvt].
     rope = (cos, sin, tokens_per_row) or None.  vt must be zero-initialised once (its padding is never written)."""
     require_gpu(a, "a")
@@ -140,6 +143,7 @@ def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None):
     g.seq_len, g.ldvt = seq_len, vt.stride(-2)
     if rope is not None:
         g.rope_cos, g.rope_sin, g.rope_w = ptr(rope[0]), ptr(rope[1]), rope[2]
+    g.q_scale = float(q_scale)
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
 
@@ -187,7 +191,7 @@ def convT(x, w, bias_tiled, s, cout):
     return out
 
 
-def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0):
+def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][heads*64][ldvt]."""
     require_gpu(q, "q")
@@ -206,6 +210,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
         a.k_batch_stride[i], a.vt_batch_stride[i] = kbs, vbs
         a.ldk = k.stride(-2)
     a.scale = float(scale)
+    a.q_prescaled = int(q_prescaled)
     if ATTN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -116,6 +116,8 @@ typedef struct f3r_gemm_args {
   const float* rope_cos; /* [n_pos][16] fp32 cos/sin of pos * 100^(-i/16) (pos_embed.py:139-150) or NULL = no RoPE (fusion decoder) */
   const float* rope_sin;
   int32_t rope_w;    /* tokens per image row: token p of a view sits at (y, x) = (p / rope_w, p % rope_w) (blocks.py:376-388) */
+  float q_scale;     /* QKV: q (after bias and RoPE) is multiplied by this before rounding; 0 means 1.  The attention kernel
+                        wants softmax_scale*log2(e) folded in here (f3r_attn_args.q_prescaled) */
   /* CONVT epilogue (ConvTranspose2d with kernel == stride == ct_s): rows m = (b, y, x) on a ct_h x ct_w grid,
      columns n = (dy*ct_s + dx)*ct_cout + co  ->  out_lp[b][y*ct_s+dy][x*ct_s+dx][co] */
   int32_t ct_s, ct_h, ct_w, ct_cout;
@@ -153,6 +155,8 @@ typedef struct f3r_attn_args {
   int64_t k_batch_stride[F3R_MAX_SEG];  /* elements */
   int64_t vt_batch_stride[F3R_MAX_SEG]; /* elements */
   float scale; /* 0.125, or 0.160192 for the fusion decoder in eval mode (blocks.py:119-124,151-154) */
+  int32_t q_prescaled; /* != 0: q was already multiplied by scale*log2(e) (F3R_EPI_QKV with q_scale) before its one
+                          rounding to lowp, so the kernel exponentiates with exp2 directly; `scale` is then unused */
 } f3r_attn_args;
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
