@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${F3R_EXTRA_FLAGS:-}"
 pids=()
 for f in f3r_gemm f3r_attn f3r_elem f3r_capi; do
-  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/f3r_common.h" -nt "$here/obj/$f.o" ] || [ "$here/../../include/f3r.h" -nt "$here/obj/$f.o" ]; then
+  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/f3r_common.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_attn_lab.h" -nt "$here/obj/$f.o" ] || [ "$here/../../include/f3r.h" -nt "$here/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$here/$f.hip" -o "$here/obj/$f.o" &
     pids+=($!)
   fi

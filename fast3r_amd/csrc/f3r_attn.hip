@@ -27,6 +27,10 @@
 
 namespace {
 
+// OPT bit 5 of attn_kernel (measurement builds only): wave 0 of workgroup (0,0,0) accumulates s_memtime deltas of the
+// four sections of its tile loop here: [0] QK^T MFMAs, [1] softmax, [2] P V MFMAs, [3] LDS write + barrier, [4] tiles.
+__device__ unsigned long long g_attn_prof[8];
+
 constexpr int AT_KB = 64;   // keys per tile
 constexpr int AT_TILE = 64 * 64;
 
@@ -42,7 +46,8 @@ template <class T, int NW, int QPW, int OPT, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args p) {
   constexpr int NT = NW * 64;
   constexpr int QB = NW * QPW * 32;  // queries per workgroup
-  constexpr int CPT = 512 / NT;      // 16-byte chunks of each tile staged per thread
+  constexpr bool SPLIT = NT > 512;   // 1024 threads: waves 0-7 stage the K tile, waves 8-15 the V^T tile (one chunk each)
+  constexpr int CPT = SPLIT ? 1 : 512 / NT;  // 16-byte chunks of EACH tile staged per thread (of one tile when SPLIT)
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];  // [buf][K | Vt][64][64] = 32 KB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,9 +74,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       qf[qb][ds] = as_vec8<T>(*(const u32x4*)(Qg + qrow[qb] * p.ldq + head * 64 + ds * 16 + g * 8));
   }
 
-  // ---- staging role: CPT 16 B chunks of the K tile and of the V^T tile per thread
+  // ---- staging role: chunk ids tid + i*NT of the combined [K tile | V^T tile] chunk space (id < 512: K, else V^T);
+  // with NT = 1024 a wave stages either K or V^T chunks (wave-uniform), with NT <= 512 every thread stages both kinds
   const int sch = tid & 7;
-  const int srow0 = tid >> 3;  // + i * (NT / 8)
+  const int srow0 = SPLIT ? ((tid >> 3) & 63) : (tid >> 3);
 
   // flattened (segment, tile) iteration.  The current segment's base pointers live in registers and are re-read from
   // the kernel arguments only when the walk crosses into the next segment (scalar loads stay off the per-tile path).
@@ -94,21 +100,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   };
   next_segment();  // the host guarantees at least one non-empty segment
 
-  u32x4 rk[CPT], rv[CPT];
+  u32x4 rk[CPT], rv[SPLIT ? 1 : CPT];  // staged chunks (SPLIT: only rk is used, for either tile)
   int valid_ld = 0;  // valid keys of the tile held in (rk, rv)
   auto load_next = [&]() -> bool {
     if (seg_keys == 0) return false;
     const int64_t rem = seg_keys - key_ld;
     valid_ld = rem < AT_KB ? (int)rem : AT_KB;
     if (!(OPT & 4) || key_ld == 0) {
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int srow = srow0 + i * (NT / 8);
+      if constexpr (SPLIT) {
         u32x4 z = {0u, 0u, 0u, 0u};
-        rk[i] = z;
-        if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key_ld + srow) * p.ldk);
-        // V^T rows are padded to ldvt (multiple of 64, pad zeroed by the host), so the chunk is always in bounds
-        rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
+        rk[0] = z;
+        if (tid < 512) {
+          if (srow0 < valid_ld) rk[0] = *(const u32x4*)(Kg + (key_ld + srow0) * p.ldk);
+        } else {
+          rk[0] = *(const u32x4*)(Vg + (int64_t)srow0 * seg_ldvt + key_ld);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          const int srow = srow0 + i * (NT / 8);
+          u32x4 z = {0u, 0u, 0u, 0u};
+          rk[i] = z;
+          if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key_ld + srow) * p.ldk);
+          // V^T rows are padded to ldvt (multiple of 64, pad zeroed by the host), so the chunk is always in bounds
+          rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
+        }
       }
     }
     key_ld += AT_KB;
@@ -118,11 +134,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   auto store_tile = [&](int buf) {
     uint16_t* kt = lds + buf * 2 * AT_TILE;
     uint16_t* vt = kt + AT_TILE;
+    if constexpr (SPLIT) {
+      *(u32x4*)((tid < 512 ? kt : vt) + aswz(srow0, sch)) = rk[0];
+    } else {
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
-      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
+      for (int i = 0; i < CPT; ++i) {
+        const int srow = srow0 + i * (NT / 8);
+        *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
+        *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
+      }
     }
   };
 
@@ -150,9 +170,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
   int cur = 0;
   bool have = true;
+  unsigned long long tq_ = 0, ts_ = 0, tp_ = 0, tb_ = 0, nt_ = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   while (have) {
     const int valid = valid_cur;
     const bool more = load_next();
+    if (OPT & 32) c0 = __builtin_readcyclecounter();
     const uint16_t* kt = lds + cur * 2 * AT_TILE;
     const uint16_t* vt = kt + AT_TILE;
 
@@ -173,6 +195,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       }
     }
     if (OPT & 2) __builtin_amdgcn_s_setprio(0);
+    if (OPT & 32) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[QPW - 1][1][15])); c1 = __builtin_readcyclecounter(); }
     // register r of block kb is key  kb*32 + 16*(r>>3) + 8*g + (r&7)  of the tile
     if (valid < AT_KB) {
 #pragma unroll
@@ -233,6 +256,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       m_run[qb] = m_new;
     }
 
+    if (OPT & 32) { asm volatile("" :: "v"(pf[0][0]), "v"(pf[QPW - 1][3])); c2 = __builtin_readcyclecounter(); }
     // ---- O^T += V^T P^T
     if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -245,11 +269,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       }
     if (OPT & 2) __builtin_amdgcn_s_setprio(0);
 
+    if (OPT & 32) { asm volatile("" :: "v"(o[0][0][0]), "v"(o[QPW - 1][1][15])); c3 = __builtin_readcyclecounter(); }
     if (more) store_tile(cur ^ 1);
     valid_cur = valid_ld;
     __syncthreads();
+    if (OPT & 32) {
+      const unsigned long long c4 = __builtin_readcyclecounter();
+      tq_ += c1 - c0; ts_ += c2 - c1; tp_ += c3 - c2; tb_ += c4 - c3; ++nt_;
+    }
     cur ^= 1;
     have = more;
+  }
+  if ((OPT & 32) && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    g_attn_prof[0] = tq_; g_attn_prof[1] = ts_; g_attn_prof[2] = tp_; g_attn_prof[3] = tb_; g_attn_prof[4] = nt_;
   }
 
   // ---- epilogue: normalise, store O[q][head*64 + d], d = db*32 + (r&3) + 8*(r>>2) + 4*g
@@ -272,716 +304,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// v2 body: fewer VALU instructions per MFMA (head_dim 64 gives only 16 MFMAs per 32 x 64 score block, half of what
-// head_dim 128 kernels get, so the softmax VALU stream -- not the matrix pipe -- is what bounds this kernel).
-//   * Q is pre-multiplied by scale*log2(e) (by the QKV GEMM epilogue, or here in the prologue), and the running
-//     maximum enters through the MFMA C operand: the first MFMA of every score block accumulates onto 16 registers
-//     holding -m (in exp2 units), so the block comes out as s' = (q.k)*c - m and P = exp2(s') needs no per-element
-//     subtract/fma.  The 16 registers change only when the running max moves (rare after the first tiles).
-//   * "max moved" is detected on s' (any s' > 0); only then are s', O, l re-based (wave-uniform rare branch).
-//   * row sums accumulate as packed pairs (v_pk_add_f32).
-template <class T, int NW, int QPW, int MINW>
-__global__ __launch_bounds__(NW * 64, MINW) void attn_kernel_v2(const f3r_attn_args p) {
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * QPW * 32;
-  constexpr int CPT = 512 / NT;
-  typedef float float2v __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int lq = lane & 31;
-  const int g = lane >> 5;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * (QPW * 32);
-  const float c = p.scale * 1.44269504088896340736f;
-
-  const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
-  int64_t qrow[QPW];
-  bool q_ok[QPW];
-  typename T::vec8 qf[QPW][4];
-#pragma unroll
-  for (int qb = 0; qb < QPW; ++qb) {
-    qrow[qb] = q0 + qb * 32 + lq;
-    q_ok[qb] = qrow[qb] < p.tq;
-    if (!q_ok[qb]) qrow[qb] = p.tq - 1;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      u32x4 raw = *(const u32x4*)(Qg + qrow[qb] * p.ldq + head * 64 + ds * 16 + g * 8);
-      if (!p.q_prescaled) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) raw[j] = pack2<T>(lo_f<T>(raw[j]) * c, hi_f<T>(raw[j]) * c);
-      }
-      qf[qb][ds] = as_vec8<T>(raw);
-    }
-  }
-
-  const int sch = tid & 7;
-  const int srow0 = tid >> 3;
-  int seg_ld = -1;
-  int64_t key_ld = 0, seg_keys = 0, seg_ldvt = 0;
-  const uint16_t* Kg = nullptr;
-  const uint16_t* Vg = nullptr;
-  auto next_segment = [&]() {
-    key_ld = 0;
-    seg_keys = 0;
-    for (++seg_ld; seg_ld < p.n_seg; ++seg_ld)
-      if (p.seg_len[seg_ld] > 0) {
-        seg_keys = p.seg_len[seg_ld];
-        seg_ldvt = p.ldvt[seg_ld];
-        Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64 + sch * 8;
-        Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt + sch * 8;
-        break;
-      }
-  };
-  next_segment();
-  u32x4 rk[CPT], rv[CPT];
-  int valid_ld = 0;
-  auto load_next = [&]() -> bool {
-    if (seg_keys == 0) return false;
-    const int64_t rem = seg_keys - key_ld;
-    valid_ld = rem < AT_KB ? (int)rem : AT_KB;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      u32x4 z = {0u, 0u, 0u, 0u};
-      rk[i] = z;
-      if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key_ld + srow) * p.ldk);
-      rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
-    }
-    key_ld += AT_KB;
-    if (key_ld >= seg_keys) next_segment();
-    return true;
-  };
-  auto store_tile = [&](int buf) {
-    uint16_t* kt = lds + buf * 2 * AT_TILE;
-    uint16_t* vt = kt + AT_TILE;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
-      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
-    }
-  };
-
-  float16v o[QPW][2];
-  float16v negm[QPW];  // 16 copies of -(running max) in exp2 units: the C operand of the first MFMA of a score block
-  float l_run[QPW];
-#pragma unroll
-  for (int qb = 0; qb < QPW; ++qb) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; negm[qb][i] = 0.f; }
-    l_run[qb] = 0.f;
-  }
-  const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-
-  load_next();
-  int valid_cur = valid_ld;
-  store_tile(0);
-  __syncthreads();
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and tile 0 have landed (see attn_kernel)
-  int cur = 0;
-  bool have = true;
-  bool first = true;
-  while (have) {
-    const int valid = valid_cur;
-    const bool more = load_next();
-    const uint16_t* kt = lds + cur * 2 * AT_TILE;
-    const uint16_t* vt = kt + AT_TILE;
-
-    float16v s[QPW][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(kt + aswz(kb * 32 + krow_pi, ds * 2 + g)));
-#pragma unroll
-        for (int qb = 0; qb < QPW; ++qb) s[qb][kb] = T::mfma32(a, qf[qb][ds], ds == 0 ? negm[qb] : s[qb][kb]);
-      }
-    if (valid < AT_KB) {
-#pragma unroll
-      for (int qb = 0; qb < QPW; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
-            if (key >= valid) s[qb][kb][r] = -1e30f;
-          }
-    }
-    typename T::vec8 pf[QPW][4];
-#pragma unroll
-    for (int qb = 0; qb < QPW; ++qb) {
-      // max of s' (relative to the running max): 4 short chains instead of one long one
-      float m0 = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);
-      float m1 = fmaxf(fmaxf(s[qb][0][8], s[qb][0][9]), s[qb][0][10]);
-      float m2 = fmaxf(fmaxf(s[qb][1][0], s[qb][1][1]), s[qb][1][2]);
-      float m3 = fmaxf(fmaxf(s[qb][1][8], s[qb][1][9]), s[qb][1][10]);
-#pragma unroll
-      for (int r = 3; r < 7; r += 2) {
-        m0 = fmaxf(fmaxf(m0, s[qb][0][r]), s[qb][0][r + 1]);
-        m1 = fmaxf(fmaxf(m1, s[qb][0][8 + r]), s[qb][0][8 + r + 1]);
-        m2 = fmaxf(fmaxf(m2, s[qb][1][r]), s[qb][1][r + 1]);
-        m3 = fmaxf(fmaxf(m3, s[qb][1][8 + r]), s[qb][1][8 + r + 1]);
-      }
-      m0 = fmaxf(fmaxf(m0, s[qb][0][7]), m1);
-      m2 = fmaxf(fmaxf(m2, s[qb][1][7]), m3);
-      float mx = fmaxf(fmaxf(m0, s[qb][0][15]), fmaxf(m2, s[qb][1][15]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      if (first || __any(mx > 0.f)) {  // wave-uniform, rare after the first tiles: re-base everything on the new max
-        const float delta = first ? mx : fmaxf(mx, 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s[qb][0][i] -= delta;
-          s[qb][1][i] -= delta;
-          o[qb][0][i] *= alpha;
-          o[qb][1][i] *= alpha;
-        }
-        l_run[qb] *= alpha;
-        const float nm = negm[qb][0] - delta;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) negm[qb][i] = nm;
-      }
-      float2v ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4 pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float2v e;
-          e[0] = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j]);
-          e[1] = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1]);
-          if (j & 1) ps1 += e; else ps0 += e;
-          pk[j] = pack2<T>(e[0], e[1]);
-        }
-        pf[qb][ks] = as_vec8<T>(pk);
-      }
-      ps0 += ps1;
-      l_run[qb] += ps0[0] + ps0[1];
-    }
-    first = false;
-
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(vt + aswz(db * 32 + lq, ks * 2 + g)));
-#pragma unroll
-        for (int qb = 0; qb < QPW; ++qb) o[qb][db] = T::mfma32(a, pf[qb][ks], o[qb][db]);
-      }
-
-    if (more) store_tile(cur ^ 1);
-    valid_cur = valid_ld;
-    __syncthreads();
-    cur ^= 1;
-    have = more;
-  }
-
-#pragma unroll
-  for (int qb = 0; qb < QPW; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (q_ok[qb]) {
-      uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow[qb] * p.ldo + head * 64;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          u32x2 w;
-          w[0] = pack2<T>(o[qb][db][rq * 4 + 0] * inv, o[qb][db][rq * 4 + 1] * inv);
-          w[1] = pack2<T>(o[qb][db][rq * 4 + 2] * inv, o[qb][db][rq * 4 + 3] * inv);
-          *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
-        }
-    }
-  }
-}
-
-template <class T, int NW, int QPW, int MINW>
-int attn_launch_v2(const f3r_attn_args& a, hipStream_t s) {
-  constexpr int QB = NW * QPW * 32;
-  const int64_t qblocks = (a.tq + QB - 1) / QB;
-  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
-  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
-  hipLaunchKernelGGL((attn_kernel_v2<T, NW, QPW, MINW>), grid, dim3(NW * 64), 0, s, a);
-  return f3r_check_launch("f3r_attn_fwd");
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// v3 body: software-pipelined.  In v1/v2 a wave runs strictly phased (QK^T MFMAs -> softmax VALU -> PV MFMAs) and
-// the matrix pipe idles during its softmax (measured: no-softmax ablation 1.30 PF/s vs 0.92 PF/s with softmax).
-// An MFMA only costs its wave one issue slot; the other ~28 of its 32 pipe cycles are free for independent VALU of
-// the SAME wave.  So iteration t issues the QK^T MFMAs of tile t+1 (into a second S accumulator set) interleaved
-// with the softmax VALU of tile t, then the P V MFMAs of tile t interleaved with the remaining exp/convert work.
-// LDS is a 3-slot ring: iteration t reads K of tile t+1 and V^T of tile t while tile t+2 lands in the third slot.
-// Q arrives pre-multiplied by scale*log2(e) (or is scaled in the prologue), scores live in exp2 units.
-template <class T, int NW, int MINW, int SGB>
-__global__ __launch_bounds__(NW * 64, MINW) void attn_kernel_v3(const f3r_attn_args p) {
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int CPT = 512 / NT;
-  typedef float float2v __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) uint16_t lds[3 * 2 * AT_TILE];  // 3 slots x [K | Vt] x 8 KB = 48 KB
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int lq = lane & 31;
-  const int g = lane >> 5;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-  const float c = p.scale * 1.44269504088896340736f;
-
-  const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
-  int64_t qrow = q0 + lq;
-  const bool q_ok = qrow < p.tq;
-  if (!q_ok) qrow = p.tq - 1;
-  typename T::vec8 qf[4];
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) {
-    u32x4 raw = *(const u32x4*)(Qg + qrow * p.ldq + head * 64 + ds * 16 + g * 8);
-    if (!p.q_prescaled) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) raw[j] = pack2<T>(lo_f<T>(raw[j]) * c, hi_f<T>(raw[j]) * c);
-    }
-    qf[ds] = as_vec8<T>(raw);
-  }
-
-  const int sch = tid & 7;
-  const int srow0 = tid >> 3;
-  int seg_ld = -1;
-  int64_t key_ld = 0, seg_keys = 0, seg_ldvt = 0;
-  const uint16_t* Kg = nullptr;
-  const uint16_t* Vg = nullptr;
-  auto next_segment = [&]() {
-    key_ld = 0;
-    seg_keys = 0;
-    for (++seg_ld; seg_ld < p.n_seg; ++seg_ld)
-      if (p.seg_len[seg_ld] > 0) {
-        seg_keys = p.seg_len[seg_ld];
-        seg_ldvt = p.ldvt[seg_ld];
-        Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64 + sch * 8;
-        Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt + sch * 8;
-        break;
-      }
-  };
-  next_segment();
-  u32x4 rk[CPT], rv[CPT];
-  int valid_ld = 0;
-  auto load_next = [&]() -> bool {
-    if (seg_keys == 0) return false;
-    const int64_t rem = seg_keys - key_ld;
-    valid_ld = rem < AT_KB ? (int)rem : AT_KB;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      u32x4 z = {0u, 0u, 0u, 0u};
-      rk[i] = z;
-      if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key_ld + srow) * p.ldk);
-      rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
-    }
-    key_ld += AT_KB;
-    if (key_ld >= seg_keys) next_segment();
-    return true;
-  };
-  auto store_tile = [&](int slot) {
-    uint16_t* kt = lds + slot * 2 * AT_TILE;
-    uint16_t* vt = kt + AT_TILE;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
-      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
-    }
-  };
-  const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-  // per-lane LDS element offsets of the fragments (slot base added per use)
-  int koff[2][4], voff[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      koff[i][j] = aswz(i * 32 + krow_pi, j * 2 + g);
-      voff[i][j] = AT_TILE + aswz(i * 32 + lq, j * 2 + g);
-    }
-
-  auto qk = [&](float16v (&sn)[2], int slot) {  // S^T = K Q^T of the tile in `slot`
-    const uint16_t* kt = lds + slot * 2 * AT_TILE;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sn[kb][i] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds)
-        sn[kb] = T::mfma32(as_vec8<T>(*(const u32x4*)(kt + koff[kb][ds])), qf[ds], sn[kb]);
-    }
-  };
-
-  float16v o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
-
-  // ---- pipeline prologue: tiles 0 and 1 staged, S(0) computed
-  load_next();
-  int valid0 = valid_ld;
-  store_tile(0);
-  bool have1 = load_next();
-  int valid1 = valid_ld;
-  if (have1) store_tile(1);
-  __syncthreads();
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q, tile 0, tile 1 have landed (see attn_kernel)
-  float16v sA[2], sB[2];
-  qk(sA, 0);
-
-  // one pipeline stage: softmax + PV of the tile in slot `st` (scores in `sc`, `vc` valid keys), QK^T of the next tile
-  // (slot `sn1`, if `have_next`) into `sx`, prefetch of tile t+2 into slot `sn2`.
-  auto stage = [&](auto has_next_tag, float16v (&sc)[2], float16v (&sx)[2], int st, int sn1, int sn2, int vc) -> bool {
-    constexpr bool have_next = decltype(has_next_tag)::value;  // compile-time: keeps the steady-state stage ONE basic block
-    const bool more = have_next ? load_next() : false;  // tile t+2 -> registers
-    if (vc < AT_KB) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
-          if (key >= vc) sc[kb][r] = -1e30f;
-        }
-    }
-    // QK^T of tile t+1 first in program order; the scheduler hints below spread these MFMAs over the softmax VALU
-    if (have_next) qk(sx, sn1);
-    // row max: 4 short chains
-    float m0 = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
-    float m1 = fmaxf(fmaxf(sc[0][8], sc[0][9]), sc[0][10]);
-    float m2 = fmaxf(fmaxf(sc[1][0], sc[1][1]), sc[1][2]);
-    float m3 = fmaxf(fmaxf(sc[1][8], sc[1][9]), sc[1][10]);
-#pragma unroll
-    for (int r = 3; r < 7; r += 2) {
-      m0 = fmaxf(fmaxf(m0, sc[0][r]), sc[0][r + 1]);
-      m1 = fmaxf(fmaxf(m1, sc[0][8 + r]), sc[0][8 + r + 1]);
-      m2 = fmaxf(fmaxf(m2, sc[1][r]), sc[1][r + 1]);
-      m3 = fmaxf(fmaxf(m3, sc[1][8 + r]), sc[1][8 + r + 1]);
-    }
-    m0 = fmaxf(fmaxf(m0, sc[0][7]), m1);
-    m2 = fmaxf(fmaxf(m2, sc[1][7]), m3);
-    float mx = fmaxf(fmaxf(m0, sc[0][15]), fmaxf(m2, sc[1][15]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-    float2v ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
-    const uint16_t* vt = lds + st * 2 * AT_TILE;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 pk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float2v e;
-        e[0] = __builtin_amdgcn_exp2f(sc[ks >> 1][(ks & 1) * 8 + 2 * j] - m_new);
-        e[1] = __builtin_amdgcn_exp2f(sc[ks >> 1][(ks & 1) * 8 + 2 * j + 1] - m_new);
-        if (j & 1) ps1 += e; else ps0 += e;
-        pk[j] = pack2<T>(e[0], e[1]);
-      }
-      const typename T::vec8 pf = as_vec8<T>(pk);
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-        o[db] = T::mfma32(as_vec8<T>(*(const u32x4*)(vt + voff[db][ks])), pf, o[db]);
-    }
-    ps0 += ps1;
-    l_run = l_run * alpha + (ps0[0] + ps0[1]);
-    if (SGB) {
-      // desired issue order: every MFMA followed by a few LDS reads and a slice of VALU, 16 times
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        __builtin_amdgcn_sched_group_barrier(0x002, SGB, 0); // SGB VALU
-      }
-    }
-    if (more) store_tile(sn2);
-    __syncthreads();
-    return more;
-  };
-
-  // ---- steady state, unrolled by two so that the S accumulator sets swap roles without copies.  Slots rotate 0,1,2.
-  bool have_next = have1;  // tile t+1 exists (staged)
-  int vc = valid0, vn = valid1;
-  int st = 0;
-  for (;;) {
-    const int s1 = st == 2 ? 0 : st + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-    if (!have_next) { stage(std::false_type{}, sA, sB, st, s1, s2, vc); break; }
-    bool more = stage(std::true_type{}, sA, sB, st, s1, s2, vc);
-    vc = vn; vn = valid_ld; have_next = more; st = s1;
-    const int t1 = st == 2 ? 0 : st + 1, t2 = t1 == 2 ? 0 : t1 + 1;
-    if (!have_next) { stage(std::false_type{}, sB, sA, st, t1, t2, vc); break; }
-    more = stage(std::true_type{}, sB, sA, st, t1, t2, vc);
-    vc = vn; vn = valid_ld; have_next = more; st = t1;
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_ok) {
-    uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow * p.ldo + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 w;
-        w[0] = pack2<T>(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
-        w[1] = pack2<T>(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
-        *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
-      }
-  }
-}
-
-template <class T, int NW, int MINW, int SGB>
-int attn_launch_v3(const f3r_attn_args& a, hipStream_t s) {
-  constexpr int QB = NW * 32;
-  const int64_t qblocks = (a.tq + QB - 1) / QB;
-  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
-  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
-  hipLaunchKernelGGL((attn_kernel_v3<T, NW, MINW, SGB>), grid, dim3(NW * 64), 0, s, a);
-  return f3r_check_launch("f3r_attn_fwd");
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// v4 body: phased like v1 (QK^T -> softmax -> PV per tile, one S set) but with every LDS fragment read hoisted a
-// phase ahead.  Measured on v1: without softmax the kernel still only reaches 52 % of the MFMA roof because each
-// "ds_read_b128 -> s_waitcnt -> 2 MFMA" step exposes the LDS latency.  Here the 8 K fragments of tile t+1 are read
-// while P V of tile t runs, and the 8 V^T fragments of tile t are read before its softmax, so both MFMA phases issue
-// back to back from registers.  That needs tile t+1 resident one iteration early: 3-slot LDS ring as in v3.
-// OPT bit 3: ABLATION (timing only) no softmax.
-template <class T, int NW, int MINW, int OPT>
-__global__ __launch_bounds__(NW * 64, MINW) void attn_kernel_v4(const f3r_attn_args p) {
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int CPT = 512 / NT;
-  typedef float float2v __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) uint16_t lds[3 * 2 * AT_TILE];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int lq = lane & 31;
-  const int g = lane >> 5;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
-  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
-  const float c = p.scale * 1.44269504088896340736f;
-
-  const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
-  int64_t qrow = q0 + lq;
-  const bool q_ok = qrow < p.tq;
-  if (!q_ok) qrow = p.tq - 1;
-  typename T::vec8 qf[4];
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) {
-    u32x4 raw = *(const u32x4*)(Qg + qrow * p.ldq + head * 64 + ds * 16 + g * 8);
-    if (!p.q_prescaled) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) raw[j] = pack2<T>(lo_f<T>(raw[j]) * c, hi_f<T>(raw[j]) * c);
-    }
-    qf[ds] = as_vec8<T>(raw);
-  }
-
-  const int sch = tid & 7;
-  const int srow0 = tid >> 3;
-  int seg_ld = -1;
-  int64_t key_ld = 0, seg_keys = 0, seg_ldvt = 0;
-  const uint16_t* Kg = nullptr;
-  const uint16_t* Vg = nullptr;
-  auto next_segment = [&]() {
-    key_ld = 0;
-    seg_keys = 0;
-    for (++seg_ld; seg_ld < p.n_seg; ++seg_ld)
-      if (p.seg_len[seg_ld] > 0) {
-        seg_keys = p.seg_len[seg_ld];
-        seg_ldvt = p.ldvt[seg_ld];
-        Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64 + sch * 8;
-        Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt + sch * 8;
-        break;
-      }
-  };
-  next_segment();
-  u32x4 rk[CPT], rv[CPT];
-  int valid_ld = 0;
-  auto load_next = [&]() -> bool {
-    if (seg_keys == 0) return false;
-    const int64_t rem = seg_keys - key_ld;
-    valid_ld = rem < AT_KB ? (int)rem : AT_KB;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      u32x4 z = {0u, 0u, 0u, 0u};
-      rk[i] = z;
-      if (srow < valid_ld) rk[i] = *(const u32x4*)(Kg + (key_ld + srow) * p.ldk);
-      rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
-    }
-    key_ld += AT_KB;
-    if (key_ld >= seg_keys) next_segment();
-    return true;
-  };
-  auto store_tile = [&](int slot) {
-    uint16_t* kt = lds + slot * 2 * AT_TILE;
-    uint16_t* vt = kt + AT_TILE;
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int srow = srow0 + i * (NT / 8);
-      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
-      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
-    }
-  };
-  const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-  int koff[2][4], voff[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      koff[i][j] = aswz(i * 32 + krow_pi, j * 2 + g);
-      voff[i][j] = AT_TILE + aswz(i * 32 + lq, j * 2 + g);
-    }
-  u32x4 kf[2][4], vf[2][4];
-  auto read_k = [&](int slot) {
-    const uint16_t* t = lds + slot * 2 * AT_TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) kf[i][j] = *(const u32x4*)(t + koff[i][j]);
-  };
-  auto read_v = [&](int slot) {
-    const uint16_t* t = lds + slot * 2 * AT_TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vf[i][j] = *(const u32x4*)(t + voff[i][j]);
-  };
-
-  float16v o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
-
-  load_next();
-  int vc = valid_ld;  // valid keys of tile t
-  store_tile(0);
-  bool have_next = load_next();
-  int vn = valid_ld;
-  if (have_next) store_tile(1);
-  __syncthreads();
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q, tiles 0 and 1 have landed (see attn_kernel)
-  read_k(0);
-  int st = 0;
-  for (;;) {
-    const int s1 = st == 2 ? 0 : st + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-    const bool more = have_next ? load_next() : false;  // tile t+2 -> registers
-    read_v(st);                                         // V^T fragments of tile t: consumed after the softmax
-    float16v s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) s[kb] = T::mfma32(as_vec8<T>(kf[kb][ds]), qf[ds], s[kb]);
-    }
-    if (have_next) read_k(s1);  // K fragments of tile t+1 (resident since the previous barrier): consumed next iteration
-    if (vc < AT_KB) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
-          if (key >= vc) s[kb][r] = -1e30f;
-        }
-    }
-    typename T::vec8 pf[4];
-    if (OPT & 8) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4 pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = pack2<T>(s[ks >> 1][(ks & 1) * 8 + 2 * j], s[ks >> 1][(ks & 1) * 8 + 2 * j + 1]);
-        pf[ks] = as_vec8<T>(pk);
-      }
-    } else {
-      float m0 = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
-      float m1 = fmaxf(fmaxf(s[0][8], s[0][9]), s[0][10]);
-      float m2 = fmaxf(fmaxf(s[1][0], s[1][1]), s[1][2]);
-      float m3 = fmaxf(fmaxf(s[1][8], s[1][9]), s[1][10]);
-#pragma unroll
-      for (int r = 3; r < 7; r += 2) {
-        m0 = fmaxf(fmaxf(m0, s[0][r]), s[0][r + 1]);
-        m1 = fmaxf(fmaxf(m1, s[0][8 + r]), s[0][8 + r + 1]);
-        m2 = fmaxf(fmaxf(m2, s[1][r]), s[1][r + 1]);
-        m3 = fmaxf(fmaxf(m3, s[1][8 + r]), s[1][8 + r + 1]);
-      }
-      m0 = fmaxf(fmaxf(m0, s[0][7]), m1);
-      m2 = fmaxf(fmaxf(m2, s[1][7]), m3);
-      float mx = fmaxf(fmaxf(m0, s[0][15]), fmaxf(m2, s[1][15]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      if (__any(m_new > m_run)) {  // exact skip: when no running max of the wave moved, alpha == 1
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-        m_run = m_new;
-      }
-      float2v ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4 pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float2v e;
-          e[0] = __builtin_amdgcn_exp2f(s[ks >> 1][(ks & 1) * 8 + 2 * j] - m_run);
-          e[1] = __builtin_amdgcn_exp2f(s[ks >> 1][(ks & 1) * 8 + 2 * j + 1] - m_run);
-          if (j & 1) ps1 += e; else ps0 += e;
-          pk[j] = pack2<T>(e[0], e[1]);
-        }
-        pf[ks] = as_vec8<T>(pk);
-      }
-      ps0 += ps1;
-      l_run += ps0[0] + ps0[1];
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int db = 0; db < 2; ++db) o[db] = T::mfma32(as_vec8<T>(vf[db][ks]), pf[ks], o[db]);
-
-    if (more) store_tile(s2);
-    __syncthreads();
-    if (!have_next) break;
-    vc = vn; vn = valid_ld; have_next = more; st = s1;
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_ok) {
-    uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow * p.ldo + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 w;
-        w[0] = pack2<T>(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
-        w[1] = pack2<T>(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
-        *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
-      }
-  }
-}
-
-template <class T, int NW, int MINW, int OPT>
-int attn_launch_v4(const f3r_attn_args& a, hipStream_t s) {
-  constexpr int QB = NW * 32;
-  const int64_t qblocks = (a.tq + QB - 1) / QB;
-  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
-  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
-  hipLaunchKernelGGL((attn_kernel_v4<T, NW, MINW, OPT>), grid, dim3(NW * 64), 0, s, a);
-  return f3r_check_launch("f3r_attn_fwd");
-}
+#include "f3r_attn_lab.h"  // experimental bodies (v2 / v3 / v4 / ping-pong): measured, correct, slower -- see DESIGN.md section 6
 
 template <class T, int NW, int QPW, int OPT, int MINW>
 int attn_launch(const f3r_attn_args& a, hipStream_t s) {
@@ -1015,6 +338,15 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
     case 25: return attn_launch<T, 8, 2, 1, 2>(a, s);  // 8 waves x 64 q (512 q / workgroup, 1 workgroup / CU)
     case 26: return attn_launch<T, 8, 2, 3, 2>(a, s);  // same + setprio
+    case 34: return attn_launch<T, 4, 2, 33, 2>(a, s);  // variant 24 + per-section s_memtime instrumentation
+    case 35: return attn_launch<T, 4, 1, 33, 3>(a, s);  // variant 5 + instrumentation
+    case 32: return attn_launch<T, 16, 1, 1, 4>(a, s); // 16 waves x 32 q, 1 workgroup / CU: 4 waves / SIMD, one staged chunk / thread
+    case 33: return attn_launch<T, 16, 1, 9, 4>(a, s); // ABLATION of 32: no softmax
+    case 29: return attn_launch<T, 4, 1, 1, 4>(a, s);  // 4 waves x 32 q, 4 workgroups / CU (<= 128 VGPR): 4 waves / SIMD
+    case 30: return attn_launch<T, 8, 1, 1, 4>(a, s);  // 8 waves x 32 q, 2 workgroups / CU: 4 waves / SIMD
+    case 31: return attn_launch<T, 4, 1, 9, 4>(a, s);  // ABLATION of 29: no softmax
+    case 27: return attn_launch_pp<T, 0>(a, s);  // ping-pong: 2 x 4 waves, matrix phase || softmax phase
+    case 28: return attn_launch_pp<T, 8>(a, s);  // ABLATION of 27: no softmax (timing only)
     case 20: return attn_launch_v4<T, 4, 2, 0>(a, s);  // v4 fragment-prefetch body, 4 waves, 2 WG/CU
     case 21: return attn_launch_v4<T, 8, 2, 0>(a, s);  // v4, 8 waves
     case 22: return attn_launch_v4<T, 4, 3, 0>(a, s);  // v4, 4 waves, 3 WG/CU (<=168 VGPR)
@@ -1042,8 +374,12 @@ int attn_variant() {
 
 }  // namespace
 
+extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 8 * sizeof(unsigned long long)) == hipSuccess ? F3R_OK : F3R_ERR_LAUNCH;
+}
+
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 26) {
+  if (variant < -1 || variant > 35) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }

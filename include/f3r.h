@@ -164,6 +164,8 @@ int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
 /* Tuning knob (measurement only): selects the workgroup shape / schedule variant of the attention kernel
  * (fast3r_amd/csrc/f3r_attn.hip, attn_dispatch); -1 restores the default.  All variants compute the same function. */
 int f3r_attn_set_variant(int variant);
+/* Measurement only: per-section cycle totals written by the instrumented variants (host buffer of 8 x u64). */
+int f3r_attn_read_prof(unsigned long long* out8);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_upsample2x: bilinear x2, align_corners=True, NHWC lowp -> NHWC lowp.
