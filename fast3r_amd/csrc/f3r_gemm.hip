@@ -14,6 +14,8 @@
 // makes every epilogue access (bias, residual, fp32/lowp stores) a 16 B / 8 B vector along n.  The V
 // third of the QKV epilogue swaps the roles so that a lane owns 4 consecutive tokens of one channel
 // and can write V transposed (vt[d][token]) with 8 B stores.
+#include <stdlib.h>
+
 #include "f3r_common.h"
 
 namespace {
@@ -24,14 +26,33 @@ constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_ELEMS * 2;     // 2 stages x (A, W) 
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact (erf) GELU, nn.GELU() default (blocks.py:84).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp,
+// five FMAs, one v_exp -- libm's erff costs ~40 instructions per element and made the fc1 epilogue as long as its K loop.
+// Branch-free in the sign so there is no cancellation for x < 0:  gelu(x) = x*Phi(x),  Phi(-|x|) = erfc(|x|/sqrt2)/2.
+// Max abs deviation from fp64 GELU over [-10, 10]: 3.4e-7 (well below the 16-bit rounding of the stored activation).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float u = poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // erfc(z)
+  const float h = 0.5f * x * u;
+  return x >= 0.f ? x - h : h;
+}
 
 struct ConvRow {  // per staged row: output pixel decomposition
   int b, oy, ox;
   bool ok;
 };
 
-template <class T, int A_MODE, int EPI>
+// GLDS: stage both operand tiles with global_load_lds (16 B per lane straight into LDS, no staging VGPRs, no ds_write
+// pass).  The DMA writes wave-uniform-base + lane*16, i.e. a linear image, so the XOR swizzle is applied to the per-lane
+// SOURCE address instead (lane l of a wave-instruction fills physical chunk l%8 of row l/8 with logical chunk
+// (l%8) ^ ((row>>1)&7)).  Only for the plain operand with K == Kpad (no zero fill needed); rows past M / N are clamped to
+// the last valid row (their products are discarded by the epilogue guards).
+template <class T, int A_MODE, int EPI, bool GLDS>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* As = smem;                    // [2][128][64]
@@ -192,17 +213,55 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
     }
   };
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) load_tile(kt + 1);
-    compute(cur);
-    if (more) store_tile(cur ^ 1);
+  if constexpr (GLDS) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    // wave w issues instructions i = 0..3 for each operand: rows (w*4 + i)*8 + lane/8 of the 128-row tile
+    const int lrow = lane >> 3, pch = lane & 7;
+    const uint16_t* asrc[4];
+    const uint16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wid * 4 + i) * 8 + lrow;
+      const int lch = pch ^ ((r >> 1) & 7);
+      int64_t m = m0 + r;
+      if (m >= p.M) m = p.M - 1;
+      int n = n0 + r;
+      if (n >= p.N) n = p.N - 1;
+      asrc[i] = Ag + m * p.lda + lch * 8;
+      wsrc[i] = Wg + (int64_t)n * p.Kpad + lch * 8;
+    }
+    auto dma_tile = [&](int kt, int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint16_t* la = As + buf * TILE_ELEMS + (wid * 4 + i) * 8 * 64;  // wave-uniform: 8 rows x 64 elements per instruction
+        uint16_t* lw = Ws + buf * TILE_ELEMS + (wid * 4 + i) * 8 * 64;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * BK), (lds_ptr_t)la, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * BK), (lds_ptr_t)lw, 16, 0, 0);
+      }
+    };
+    dma_tile(0, 0);
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) dma_tile(kt + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1) < nk;
+      if (more) load_tile(kt + 1);
+      compute(cur);
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ------------------------------------------------------------------ epilogues
@@ -342,10 +401,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
   }
 }
 
-template <class T, int A_MODE, int EPI>
+int g_gemm_glds = -1;  // -1: read F3R_GEMM_GLDS once (default on)
+bool use_glds() {
+  if (g_gemm_glds < 0) {
+    const char* e = getenv("F3R_GEMM_GLDS");
+    g_gemm_glds = e ? atoi(e) : 1;
+  }
+  return g_gemm_glds != 0;
+}
+
+template <class T, int A_MODE, int EPI, bool GLDS>
 int launch(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm_kernel<T, A_MODE, EPI>;
+  auto kern = gemm_kernel<T, A_MODE, EPI, GLDS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     attr_set = true;
@@ -361,12 +429,13 @@ template <class T>
 int dispatch(const f3r_gemm_args& a, hipStream_t stream) {
   if (a.a_mode == F3R_A_CONV3X3) {
     F3R_REQUIRE(a.epi == F3R_EPI_GENERIC, "f3r_gemm: conv3x3 supports only the generic epilogue");
-    return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC>(a, stream);
+    return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC, false>(a, stream);
   }
+  const bool glds = use_glds() && a.K == a.Kpad && a.M > 0;
   switch (a.epi) {
-    case F3R_EPI_GENERIC: return launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC>(a, stream);
-    case F3R_EPI_QKV: return launch<T, F3R_A_PLAIN, F3R_EPI_QKV>(a, stream);
-    case F3R_EPI_CONVT: return launch<T, F3R_A_PLAIN, F3R_EPI_CONVT>(a, stream);
+    case F3R_EPI_GENERIC: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, true>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false>(a, stream);
+    case F3R_EPI_QKV: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, true>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_QKV, false>(a, stream);
+    case F3R_EPI_CONVT: return launch<T, F3R_A_PLAIN, F3R_EPI_CONVT, false>(a, stream);
   }
   f3r_set_error("f3r_gemm: bad epi %d", a.epi);
   return F3R_ERR_ARG;
