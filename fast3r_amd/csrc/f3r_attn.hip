@@ -42,6 +42,8 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((ch
 //      bit 1: s_setprio 1 around the MFMA clusters
 //      bit 2: ABLATION (timing experiments only, wrong results): never reload K/V after the first tile
 //      bit 3: ABLATION (timing only): no softmax -- P = S converted to lowp
+//      bit 4: packed fp32 math (v_pk_fma_f32 / v_pk_add_f32) for the exponent argument and the row sums: a wave issues one
+//             instruction per ~5 cycles whatever it is (tools/ubench/valu_rate.hip), so halving the count of these pays
 template <class T, int NW, int QPW, int OPT, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args p) {
   constexpr int NT = NW * 64;
@@ -233,6 +235,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       const bool moved = m_new > m_run[qb];
       const float mc = m_new * c;
       float psum = 0.f;
+      if (OPT & 16) {
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        const float2v c2 = {c, c}, nmc2 = {-mc, -mc};
+        float2v ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          u32x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float2v sv = {s[qb][ks >> 1][(ks & 1) * 8 + 2 * j], s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1]};
+            const float2v t = __builtin_elementwise_fma(sv, c2, nmc2);
+            float2v e;
+            e[0] = __builtin_amdgcn_exp2f(t[0]);
+            e[1] = __builtin_amdgcn_exp2f(t[1]);
+            if (j & 1) ps1 += e; else ps0 += e;
+            pk[j] = pack2<T>(e[0], e[1]);
+          }
+          pf[qb][ks] = as_vec8<T>(pk);
+        }
+        ps0 += ps1;
+        psum = ps0[0] + ps0[1];
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         u32x4 pk;
@@ -244,6 +268,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
           pk[j] = pack2<T>(p0, p1);
         }
         pf[qb][ks] = as_vec8<T>(pk);
+      }
       }
       if (!(OPT & 1) || __any(moved)) {
         const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
@@ -338,6 +363,8 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
     case 25: return attn_launch<T, 8, 2, 1, 2>(a, s);  // 8 waves x 64 q (512 q / workgroup, 1 workgroup / CU)
     case 26: return attn_launch<T, 8, 2, 3, 2>(a, s);  // same + setprio
+    case 40: return attn_launch<T, 4, 2, 17, 2>(a, s);  // 24 + packed fp32 softmax arithmetic
+    case 41: return attn_launch<T, 8, 2, 17, 2>(a, s);  // 25 + packed
     case 34: return attn_launch<T, 4, 2, 33, 2>(a, s);  // variant 24 + per-section s_memtime instrumentation
     case 35: return attn_launch<T, 4, 1, 33, 3>(a, s);  // variant 5 + instrumentation
     case 32: return attn_launch<T, 16, 1, 1, 4>(a, s); // 16 waves x 32 q, 1 workgroup / CU: 4 waves / SIMD, one staged chunk / thread
@@ -345,6 +372,10 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 29: return attn_launch<T, 4, 1, 1, 4>(a, s);  // 4 waves x 32 q, 4 workgroups / CU (<= 128 VGPR): 4 waves / SIMD
     case 30: return attn_launch<T, 8, 1, 1, 4>(a, s);  // 8 waves x 32 q, 2 workgroups / CU: 4 waves / SIMD
     case 31: return attn_launch<T, 4, 1, 9, 4>(a, s);  // ABLATION of 29: no softmax
+    case 36: return attn_launch_sp<T, 8, 0>(a, s);  // 3-stage software pipeline with pinned issue order, 8 waves x 32 q
+    case 37: return attn_launch_sp<T, 4, 0>(a, s);
+    case 39: return attn_launch_sp<T, 4, 2>(a, s);  // occupancy experiment: 37 with ONE workgroup (1 wave / SIMD) per CU
+    case 38: return attn_launch_sp<T, 8, 1>(a, s);  // 36 + per-part s_memtime instrumentation  // same, 4 waves (2 workgroups / CU)
     case 27: return attn_launch_pp<T, 0>(a, s);  // ping-pong: 2 x 4 waves, matrix phase || softmax phase
     case 28: return attn_launch_pp<T, 8>(a, s);  // ABLATION of 27: no softmax (timing only)
     case 20: return attn_launch_v4<T, 4, 2, 0>(a, s);  // v4 fragment-prefetch body, 4 waves, 2 WG/CU
@@ -379,7 +410,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 35) {
+  if (variant < -1 || variant > 41) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }

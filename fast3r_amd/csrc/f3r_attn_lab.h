@@ -1009,3 +1009,314 @@ int attn_launch_pp(const f3r_attn_args& a, hipStream_t s) {
   return f3r_check_launch("f3r_attn_fwd");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// sp body: 3-stage software pipeline with a PINNED issue order.
+// Measured facts behind it (tools/ubench/valu_rate.hip, instrumented variant 34): one wave issues a VALU instruction every
+// ~5 cycles (v_exp_f32 ~9) no matter how many are independent, an MFMA costs its wave one such slot but occupies the matrix
+// pipe for 32 cycles, and in the phased bodies (QK^T -> softmax -> PV) the matrix pipe idles during every softmax.  So the
+// softmax of tile t (~175 VALU, ~1000 issue cycles per 32 queries) is interleaved, instruction by instruction, with the 16
+// MFMAs that do not depend on it: P V of tile t-1 (P already packed) and Q K^T of tile t+1 (second accumulator set).  The
+// order is written out by hand as 16 slots { fragment read for slot+2 ; 1 MFMA ; a slice of the softmax } separated by
+// __builtin_amdgcn_sched_barrier(0), because the compiler's own schedule clusters the MFMAs in front of the VALU (v3).
+// LDS: ring of 4 [K | V^T] tile slots (64 KB): iteration t reads V^T(t-1) and K(t+1) while tile t+2 lands and t+3 is in flight.
+#define F3R_SB() __builtin_amdgcn_sched_barrier(0)
+template <class T, int NW, int PROF>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel_sp(const f3r_attn_args p) {
+  unsigned long long ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0, nt_ = 0;
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CPT = 512 / NT;
+  // PROF == 2: occupancy experiment -- pad LDS past 80 KB so that only ONE workgroup fits on a CU
+  __shared__ __attribute__((aligned(16))) uint16_t lds[(PROF == 2 ? 6 : 4) * 2 * AT_TILE];  // 4 slots x [K | Vt] x 8 KB = 64 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int lq = lane & 31;
+  const int g = lane >> 5;
+  const int head = blockIdx.y;
+  const int b = blockIdx.z;
+  const int64_t q0 = (int64_t)blockIdx.x * QB + wid * 32;
+  const float c = p.scale * 1.44269504088896340736f;
+  if (PROF == 2 && p.tq < 0) lds[5 * 2 * AT_TILE + tid] = 0;  // keep the padding allocated
+
+  const uint16_t* Qg = (const uint16_t*)p.q + (int64_t)b * p.q_batch_stride;
+  int64_t qrow = q0 + lq;
+  const bool q_ok = qrow < p.tq;
+  if (!q_ok) qrow = p.tq - 1;
+  typename T::vec8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    u32x4 raw = *(const u32x4*)(Qg + qrow * p.ldq + head * 64 + ds * 16 + g * 8);
+    if (!p.q_prescaled) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) raw[j] = pack2<T>(lo_f<T>(raw[j]) * c, hi_f<T>(raw[j]) * c);
+    }
+    qf[ds] = as_vec8<T>(raw);
+  }
+
+  // ---- tile walker (loads) and valid-count walker (softmax), as in the other bodies
+  int n_tiles = 0;
+  for (int sg = 0; sg < p.n_seg; ++sg) n_tiles += (int)((p.seg_len[sg] + AT_KB - 1) / AT_KB);
+  const int sch = tid & 7;
+  const int srow0 = tid >> 3;
+  int seg_ld = -1;
+  int64_t key_ld = 0, seg_keys = 0, seg_ldvt = 0;
+  const uint16_t* Kg = nullptr;
+  const uint16_t* Vg = nullptr;
+  auto next_segment = [&]() {
+    key_ld = 0;
+    seg_keys = 0;
+    for (++seg_ld; seg_ld < p.n_seg; ++seg_ld)
+      if (p.seg_len[seg_ld] > 0) {
+        seg_keys = p.seg_len[seg_ld];
+        seg_ldvt = p.ldvt[seg_ld];
+        Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64 + sch * 8;
+        Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt + sch * 8;
+        break;
+      }
+  };
+  next_segment();
+  u32x4 rk[CPT], rv[CPT];
+  auto load_next = [&]() -> bool {
+    if (seg_keys == 0) return false;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int srow = srow0 + i * (NT / 8);
+      int64_t r = key_ld + srow;
+      if (r >= seg_keys) r = seg_keys - 1;  // rows past the end are masked in the softmax
+      rk[i] = *(const u32x4*)(Kg + r * p.ldk);
+      rv[i] = *(const u32x4*)(Vg + (int64_t)srow * seg_ldvt + key_ld);
+    }
+    key_ld += AT_KB;
+    if (key_ld >= seg_keys) next_segment();
+    return true;
+  };
+  auto store_tile = [&](int slot) {
+    uint16_t* kt = lds + slot * 2 * AT_TILE;
+    uint16_t* vt = kt + AT_TILE;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int srow = srow0 + i * (NT / 8);
+      *(u32x4*)(kt + aswz(srow, sch)) = rk[i];
+      *(u32x4*)(vt + aswz(srow, sch)) = rv[i];
+    }
+  };
+  int vs_seg = -1;
+  int64_t vs_key = 0, vs_len = 0;
+  auto next_valid = [&]() -> int {
+    if (vs_key >= vs_len) {
+      vs_key = 0;
+      for (++vs_seg; vs_seg < p.n_seg && p.seg_len[vs_seg] <= 0; ++vs_seg) {}
+      vs_len = vs_seg < p.n_seg ? p.seg_len[vs_seg] : 0;
+    }
+    const int64_t rem = vs_len - vs_key;
+    vs_key += AT_KB;
+    return rem < AT_KB ? (int)rem : AT_KB;
+  };
+
+  const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+  int koff[2][4], voff[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      koff[i][j] = aswz(i * 32 + krow_pi, j * 2 + g);
+      voff[i][j] = AT_TILE + aswz(i * 32 + lq, j * 2 + g);
+    }
+
+  float16v o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  float16v sA[2], sB[2];
+  typename T::vec8 pA[4], pB[4];
+
+  // ---- prologue: tiles 0, 1 resident, tile 2 in registers, S(0) computed
+  load_next();
+  store_tile(0);
+  if (load_next()) store_tile(1);
+  bool pend = load_next();  // registers hold tile 2
+  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see attn_kernel
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sA[kb][i] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) sA[kb] = T::mfma32(as_vec8<T>(*(const u32x4*)(lds + koff[kb][ds])), qf[ds], sA[kb]);
+  }
+
+  // one pipeline stage = iteration t.  sc: scores of tile t; sn: receives scores of tile t+1; pp: P(t-1); pc: receives P(t)
+  auto stage = [&](auto has_pv_tag, auto has_qk_tag, float16v (&sc)[2], float16v (&sn)[2], typename T::vec8 (&pp)[4],
+                   typename T::vec8 (&pc)[4], int t) {
+    constexpr bool HAS_PV = decltype(has_pv_tag)::value;
+    constexpr bool HAS_QK = decltype(has_qk_tag)::value;
+    const int vc = next_valid();
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (PROF == 1) c0 = __builtin_readcyclecounter();
+    if (vc < AT_KB) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
+          if (key >= vc) sc[kb][r] = -1e30f;
+        }
+    }
+    const uint16_t* vt = lds + ((t + 3) & 3) * 2 * AT_TILE;  // tile t-1
+    const uint16_t* kt = lds + ((t + 1) & 3) * 2 * AT_TILE;  // tile t+1
+    u32x4 fr[8], kf[8];
+    if (HAS_PV) {
+      fr[0] = *(const u32x4*)(vt + voff[0][0]);
+      fr[1] = *(const u32x4*)(vt + voff[1][0]);
+    }
+    F3R_SB();
+    // ---- part A: 8 x { P V MFMA of tile t-1 } interleaved with the row max of tile t
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, mx = 0.f, partner = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (HAS_PV) {
+        if (i + 2 < 8) fr[i + 2] = *(const u32x4*)(vt + voff[(i + 2) & 1][(i + 2) >> 1]);
+        o[i & 1] = T::mfma32(as_vec8<T>(fr[i]), pp[i >> 1], o[i & 1]);
+      }
+      if (HAS_QK && i >= 6) kf[i - 6] = *(const u32x4*)(kt + koff[0][i - 6]);
+      if (i == 0) {
+        m0 = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+        m1 = fmaxf(fmaxf(sc[0][8], sc[0][9]), sc[0][10]);
+        m2 = fmaxf(fmaxf(sc[1][0], sc[1][1]), sc[1][2]);
+        m3 = fmaxf(fmaxf(sc[1][8], sc[1][9]), sc[1][10]);
+      } else if (i == 1 || i == 2) {
+        const int r = 2 * i + 1;  // 3, 5
+        m0 = fmaxf(fmaxf(m0, sc[0][r]), sc[0][r + 1]);
+        m1 = fmaxf(fmaxf(m1, sc[0][8 + r]), sc[0][8 + r + 1]);
+        m2 = fmaxf(fmaxf(m2, sc[1][r]), sc[1][r + 1]);
+        m3 = fmaxf(fmaxf(m3, sc[1][8 + r]), sc[1][8 + r + 1]);
+      } else if (i == 3) {
+        m0 = fmaxf(fmaxf(m0, sc[0][7]), m1);
+        m2 = fmaxf(fmaxf(m2, sc[1][7]), m3);
+        mx = fmaxf(fmaxf(m0, sc[0][15]), fmaxf(m2, sc[1][15]));
+      } else if (i == 4) {
+        partner = __shfl_xor(mx, 32, 64);
+      } else if (i == 6) {
+        mx = fmaxf(mx, partner);
+      }
+      // anchor the slice here: IR-level sinking/hoisting would otherwise move it out of its slot (sched_barrier only pins
+      // the machine scheduler)
+      asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(mx), "+v"(partner));
+      F3R_SB();
+    }
+    if (PROF == 1) { asm volatile("" :: "v"(o[0][0]), "v"(o[1][15])); c1 = __builtin_readcyclecounter(); }
+    // ---- part B (rare after the first tiles): the running max moved -> re-base O and l
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      m_run = m_new;
+    }
+    const float mr = m_run;
+    if (PROF == 1) c2 = __builtin_readcyclecounter();
+    F3R_SB();
+    // ---- part C: 8 x { Q K^T MFMA of tile t+1 } interleaved with exp / pack / row-sum of tile t
+    float ps0 = 0.f, ps1 = 0.f;
+    u32x4 pk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (HAS_QK) {
+        if (i + 2 < 8) kf[i + 2] = *(const u32x4*)(kt + koff[(i + 2) >> 2][(i + 2) & 3]);
+        if ((i & 3) == 0) {
+#pragma unroll
+          for (int z = 0; z < 16; ++z) sn[i >> 2][z] = 0.f;
+        }
+        sn[i >> 2] = T::mfma32(as_vec8<T>(kf[i]), qf[i & 3], sn[i >> 2]);
+      }
+      const int ks = i >> 1;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = (i & 1) * 2 + jj;
+        const float e0 = __builtin_amdgcn_exp2f(sc[ks >> 1][(ks & 1) * 8 + 2 * j] - mr);
+        const float e1 = __builtin_amdgcn_exp2f(sc[ks >> 1][(ks & 1) * 8 + 2 * j + 1] - mr);
+        ps0 += e0;
+        ps1 += e1;
+        pk[j] = pack2<T>(e0, e1);
+        asm volatile("" : "+v"(ps0), "+v"(ps1), "+v"(pk[j]));  // anchor (see part A)
+      }
+      if (i & 1) pc[ks] = as_vec8<T>(pk);
+      F3R_SB();
+    }
+    l_run += ps0 + ps1;
+    if (PROF == 1) { if (HAS_QK) asm volatile("" :: "v"(sn[0][0]), "v"(sn[1][15])); c3 = __builtin_readcyclecounter(); }
+    // ---- part D: tile t+2 -> LDS, tile t+3 -> registers
+    if (pend) store_tile((t + 2) & 3);
+    pend = pend ? load_next() : false;
+    __syncthreads();
+    if (PROF == 1) {
+      const unsigned long long c4 = __builtin_readcyclecounter();
+      ta_ += c1 - c0; tb_ += c2 - c1; tc_ += c3 - c2; td_ += c4 - c3; ++nt_;
+    }
+  };
+
+  const std::true_type yes{};
+  const std::false_type no{};
+  // Stage t reads scores from sA when t is even (sB when odd) and leaves P(t) in pA when t is even (pB when odd).  The loop is
+  // unrolled by two with fixed roles so that only ONE score set and ONE P set are live across the back-edge.
+  if (n_tiles == 1) {
+    stage(no, no, sA, sB, pB, pA, 0);
+  } else {
+    stage(no, yes, sA, sB, pB, pA, 0);
+    int t = 1;
+    while (t + 2 < n_tiles) {  // neither t nor t+1 is the last tile
+      stage(yes, yes, sB, sA, pA, pB, t);
+      stage(yes, yes, sA, sB, pB, pA, t + 1);
+      t += 2;
+    }
+    if (t + 1 < n_tiles) {
+      stage(yes, yes, sB, sA, pA, pB, t);
+      stage(yes, no, sA, sB, pB, pA, t + 1);
+    } else {
+      stage(yes, no, sB, sA, pA, pB, t);
+    }
+  }
+  if (PROF == 1 && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    g_attn_prof[0] = ta_; g_attn_prof[1] = tb_; g_attn_prof[2] = tc_; g_attn_prof[3] = td_; g_attn_prof[4] = nt_;
+  }
+  // ---- drain: P V of the last tile (its P is in pA when (n_tiles - 1) is even, else pB)
+  {
+    const uint16_t* vt = lds + ((n_tiles - 1) & 3) * 2 * AT_TILE;
+    const bool evenlast = ((n_tiles - 1) & 1) == 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(vt + voff[db][ks]));
+        if (evenlast) o[db] = T::mfma32(a, pA[ks], o[db]); else o[db] = T::mfma32(a, pB[ks], o[db]);
+      }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (q_ok) {
+    uint16_t* Og = (uint16_t*)p.o + (int64_t)b * p.o_batch_stride + qrow * p.ldo + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u32x2 w;
+        w[0] = pack2<T>(o[db][rq * 4 + 0] * inv, o[db][rq * 4 + 1] * inv);
+        w[1] = pack2<T>(o[db][rq * 4 + 2] * inv, o[db][rq * 4 + 3] * inv);
+        *(u32x2*)(Og + db * 32 + 8 * rq + 4 * g) = w;
+      }
+  }
+}
+
+template <class T, int NW, int PROF>
+int attn_launch_sp(const f3r_attn_args& a, hipStream_t s) {
+  constexpr int QB = NW * 32;
+  const int64_t qblocks = (a.tq + QB - 1) / QB;
+  F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
+  dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
+  hipLaunchKernelGGL((attn_kernel_sp<T, NW, PROF>), grid, dim3(NW * 64), 0, s, a);
+  return f3r_check_launch("f3r_attn_fwd");
+}
