@@ -53,6 +53,7 @@ class AttnArgs(ctypes.Structure):
         ("ldk", _c_i64),
         ("k_batch_stride", _c_i64 * F3R_MAX_SEG), ("vt_batch_stride", _c_i64 * F3R_MAX_SEG),
         ("scale", _c_f32), ("q_prescaled", _c_i32),
+        ("st_o", _c_vp), ("st_ml", _c_vp), ("state_in", _c_i32), ("state_out", _c_i32),
     ]
 
 

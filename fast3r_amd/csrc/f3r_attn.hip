@@ -156,6 +156,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     for (int i = 0; i < 16; ++i) { o[qb][0][i] = 0.f; o[qb][1][i] = 0.f; }
     m_run[qb] = -1e30f;  // running max of the raw scores
     l_run[qb] = 0.f;     // this lane's partial row sum (its own 32 keys per tile)
+    if (p.state_in) {    // resume an online softmax started by an earlier launch over other K/V segments
+      const int64_t row = (int64_t)b * p.tq + qrow[qb];
+      const float* so = p.st_o + row * ((int64_t)p.n_heads * 64) + head * 64;
+      const float* sm = p.st_ml + (row * p.n_heads + head) * 4;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4v v = *(const float4v*)(so + db * 32 + 8 * rq + 4 * g);
+          o[qb][db][rq * 4 + 0] = v[0]; o[qb][db][rq * 4 + 1] = v[1]; o[qb][db][rq * 4 + 2] = v[2]; o[qb][db][rq * 4 + 3] = v[3];
+        }
+      m_run[qb] = sm[0];
+      l_run[qb] = sm[1 + g];
+    }
   }
   const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*c)
 
@@ -309,7 +323,27 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     g_attn_prof[0] = tq_; g_attn_prof[1] = ts_; g_attn_prof[2] = tp_; g_attn_prof[3] = tb_; g_attn_prof[4] = nt_;
   }
 
-  // ---- epilogue: normalise, store O[q][head*64 + d], d = db*32 + (r&3) + 8*(r>>2) + 4*g
+  // ---- epilogue: either hand the state to the next launch ...
+  if (p.state_out) {
+#pragma unroll
+    for (int qb = 0; qb < QPW; ++qb) {
+      if (!q_ok[qb]) continue;
+      const int64_t row = (int64_t)b * p.tq + qrow[qb];
+      float* so = p.st_o + row * ((int64_t)p.n_heads * 64) + head * 64;
+      float* sm = p.st_ml + (row * p.n_heads + head) * 4;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float4v v = {o[qb][db][rq * 4 + 0], o[qb][db][rq * 4 + 1], o[qb][db][rq * 4 + 2], o[qb][db][rq * 4 + 3]};
+          *(float4v*)(so + db * 32 + 8 * rq + 4 * g) = v;
+        }
+      if (g == 0) sm[0] = m_run[qb];
+      sm[1 + g] = l_run[qb];
+    }
+    return;
+  }
+  // ---- ... or normalise and store O[q][head*64 + d], d = db*32 + (r&3) + 8*(r>>2) + 4*g
 #pragma unroll
   for (int qb = 0; qb < QPW; ++qb) {
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
@@ -441,8 +475,12 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
     total += a.seg_len[s];
   }
   F3R_REQUIRE(total > 0, "f3r_attn_fwd: no keys");
+  if (a.state_in || a.state_out) {
+    F3R_REQUIRE(a.st_o && a.st_ml && (((uintptr_t)a.st_o) & 15) == 0 && (((uintptr_t)a.st_ml) & 15) == 0, "f3r_attn_fwd: state buffers null/misaligned");
+  }
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int variant = attn_variant();
+  int variant = attn_variant();
+  if ((a.state_in || a.state_out) && !(variant == 24 || variant == 25 || variant == 3 || variant == 5 || variant == 0)) variant = AT_DEFAULT_VARIANT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

@@ -5,9 +5,10 @@ naturally -- the encoder, every LayerNorm / Linear / MLP of the fusion blocks an
 view-local -- and only softmax(Q K^T) V couples views.  Rank r owns a contiguous range of views, i.e. a
 contiguous range of token rows; per fusion layer it contributes its K [T_r][D] and V^T [D][T_r] and needs
 everybody else's.  The exchange is ONE all-gather per tensor per layer (24 x 2 per forward) of equal-size padded
-buffers; the attention kernel then walks the R segments in rank order (f3r_attn_args.k_seg / vt_seg), which is
-the same key order the single-GPU kernel sees, so sharded == unsharded up to the tile boundaries of the online
-softmax.  xGMI is point-to-point (7 links per GPU), so a direct all-gather uses every link at once; at N=320 /
+buffers, launched asynchronously right after the QKV GEMM; meanwhile the attention kernel attends over the LOCAL
+shard and parks its online-softmax state (m, l, un-normalised O in fp32); once the gathers have landed a second
+launch resumes from that state over the remote segments (f3r_attn_args.k_seg / vt_seg, st_o / st_ml) and writes
+the normalised output.  Softmax is order-independent, so sharded == unsharded up to fp32 summation order.  xGMI is point-to-point (7 links per GPU), so a direct all-gather uses every link at once; at N=320 /
 8 GPUs a layer moves 7 x 168 MB into each GPU (~1.1 ms at 153 GB/s per link) against >= 22 ms of attention math.
 
 Nothing else crosses GPUs: image ids are drawn once on rank 0 and broadcast (the reference's `seed + rank`
@@ -45,6 +46,12 @@ class KVExchange:
         self.vt_loc = torch.zeros((1, D, self.ldvt), dtype=dtype, device=device)
         self.k_all = torch.empty((world, t_max, D), dtype=dtype, device=device)
         self.vt_all = torch.empty((world, D, self.ldvt), dtype=dtype, device=device)
+        self.has_remote = any(t > 0 for r, t in enumerate(self.t_all) if r != rank)
+        # parked online-softmax state of the local-shard launch (fp32 O accumulators + {m, l0, l1, -} per query and head)
+        self.state = None
+        if self.has_remote and t_loc > 0:
+            self.state = (torch.empty((t_loc, D), dtype=torch.float32, device=device),
+                          torch.empty((t_loc, D // 64, 4), dtype=torch.float32, device=device))
 
     def _all_gather(self, out2d, in2d):
         """RCCL moves device buffers directly.  Any other backend (gloo: CPU tests, and the 2-process single-GPU
@@ -57,11 +64,36 @@ class KVExchange:
             dist.all_gather_into_tensor(out2d, in2d, group=self.group)
 
     def exchange(self):
-        """All-gather this layer's K and V^T; returns the attention segments in rank order:
+        """All-gather this layer's K and V^T (blocking); returns the attention segments of ALL ranks in rank order:
         [(k [T_r][D], vt [D][ldvt], T_r, k_batch_stride, vt_batch_stride)]."""
-        self._all_gather(self.k_all.view(self.world * self.t_max, self.D), self.k_loc)
-        self._all_gather(self.vt_all.view(self.world * self.D, self.ldvt), self.vt_loc.view(self.D, self.ldvt))
+        self.start()
+        self.finish()
         return [(self.k_all[r], self.vt_all[r], self.t_all[r], 0, 0) for r in range(self.world) if self.t_all[r] > 0]
+
+    # ---- split form: the gather runs while the attention kernel works on the local shard
+    def local_segment(self):
+        return (self.k_loc, self.vt_loc.view(self.D, self.ldvt), self.t_loc, 0, 0)
+
+    def start(self):
+        """Launch both all-gathers.  With RCCL they are asynchronous (their own stream, ordered after the QKV GEMM that
+        produced k_loc / vt_loc on the current stream); other backends gather synchronously through the host."""
+        self._works = []
+        if self.k_all.is_cuda and dist.get_backend(self.group) == "nccl":
+            self._works.append(dist.all_gather_into_tensor(self.k_all.view(self.world * self.t_max, self.D), self.k_loc,
+                                                           group=self.group, async_op=True))
+            self._works.append(dist.all_gather_into_tensor(self.vt_all.view(self.world * self.D, self.ldvt),
+                                                           self.vt_loc.view(self.D, self.ldvt), group=self.group, async_op=True))
+        else:
+            self._all_gather(self.k_all.view(self.world * self.t_max, self.D), self.k_loc)
+            self._all_gather(self.vt_all.view(self.world * self.D, self.ldvt), self.vt_loc.view(self.D, self.ldvt))
+
+    def finish(self):
+        """Make the current stream wait for the gathers; returns the segments of the OTHER ranks, in rank order."""
+        for w in getattr(self, "_works", []):
+            w.wait()
+        self._works = []
+        return [(self.k_all[r], self.vt_all[r], self.t_all[r], 0, 0) for r in range(self.world)
+                if r != self.rank and self.t_all[r] > 0]
 
 
 class ViewSharding:

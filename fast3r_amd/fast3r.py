@@ -390,13 +390,24 @@ class Fast3R(nn.Module):
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
         ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E)
-        if kv_exchange is None:
-            segs = [(k, vt, seq_len, seq_len * D, D * ldvt)]
-        else:
-            segs = kv_exchange.exchange()
         o = h  # LN output is dead: reuse as the attention output buffer
-        ops.attention(q, o, n_heads, scale, segs, tq=seq_len, batch=n_seq, q_batch_stride=seq_len * D, o_batch_stride=seq_len * D,
-                      q_prescaled=True)
+        if kv_exchange is None:
+            ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * D, D * ldvt)], tq=seq_len, batch=n_seq,
+                          q_batch_stride=seq_len * D, o_batch_stride=seq_len * D, q_prescaled=True)
+        else:
+            # view-sharded: the all-gather of the remote K / V^T runs while the kernel attends over the local shard; the
+            # online-softmax state (m, l, O) is parked in fp32 and resumed over the remote segments once they have landed
+            kv_exchange.start()
+            if seq_len == 0:
+                kv_exchange.finish()  # a rank without tokens still takes part in the collective
+            elif kv_exchange.has_remote:
+                ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True,
+                              state=kv_exchange.state, state_out=True)
+                ops.attention(q, o, n_heads, scale, kv_exchange.finish(), tq=seq_len, q_prescaled=True,
+                              state=kv_exchange.state, state_in=True)
+            else:
+                kv_exchange.finish()
+                ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o)
         _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)
@@ -485,6 +496,8 @@ class Fast3R(nn.Module):
         sh = self.sharding
         N_total = len(views)
         v_lo, v_hi = (0, N_total) if sh is None else sh.my_range(N_total)
+        if sh is not None and N_total < sh.world:
+            raise ValueError(f"view sharding needs at least one view per rank ({N_total} views, {sh.world} ranks)")
         my_views = views[v_lo:v_hi]
         B = views[0]["img"].shape[0]
 

@@ -191,7 +191,14 @@ def convT(x, w, bias_tiled, s, cout):
     return out
 
 
-def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False):
+def attention_state(tq_total: int, n_heads: int, device):
+    """Buffers for an online softmax carried across launches: (st_o fp32 [tq][heads*64], st_ml fp32 [tq][heads][4])."""
+    return (torch.empty((tq_total, n_heads * 64), dtype=torch.float32, device=device),
+            torch.empty((tq_total, n_heads, 4), dtype=torch.float32, device=device))
+
+
+def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
+              state=None, state_in=False, state_out=False):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][heads*64][ldvt]."""
     require_gpu(q, "q")
@@ -211,6 +218,9 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
         a.ldk = k.stride(-2)
     a.scale = float(scale)
     a.q_prescaled = int(q_prescaled)
+    if state is not None:
+        a.st_o, a.st_ml = ptr(state[0]), ptr(state[1])
+        a.state_in, a.state_out = int(state_in), int(state_out)
     if ATTN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

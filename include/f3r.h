@@ -157,6 +157,16 @@ typedef struct f3r_attn_args {
   float scale; /* 0.125, or 0.160192 for the fusion decoder in eval mode (blocks.py:119-124,151-154) */
   int32_t q_prescaled; /* != 0: q was already multiplied by scale*log2(e) (F3R_EPI_QKV with q_scale) before its one
                           rounding to lowp, so the kernel exponentiates with exp2 directly; `scale` is then unused */
+  /* Online-softmax state carried between launches over different K/V segments of the SAME queries (view-sharded path:
+     launch 1 attends over the local shard while the all-gather of the remote shards is in flight and writes the state,
+     launch 2 resumes from it over the remote shards and writes the normalised output).
+       st_o  : fp32 [batch][tq][n_heads*64]   un-normalised O accumulators
+       st_ml : fp32 [batch][tq][n_heads][4]   {running max, partial row sum of lane half 0, of lane half 1, unused}
+     state_in != 0: start from the state instead of (O=0, m=-inf, l=0).  state_out != 0: write the state and NOT o. */
+  float* st_o;
+  float* st_ml;
+  int32_t state_in;
+  int32_t state_out;
 } f3r_attn_args;
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);

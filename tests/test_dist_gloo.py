@@ -57,6 +57,12 @@ def _worker(rank, world, port, ret):
             full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
             assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
             assert float(kvx.vt_loc[0, :, t_loc:].abs().sum()) == 0.0  # padding stays zero
+            # split form used by the model: local shard first (while the gather is in flight), then the remote segments
+            kvx.start()
+            loc, rem = kvx.local_segment(), kvx.finish()
+            assert kvx.has_remote and loc[2] == t_loc and [s[2] for s in rem] == [2 * P if rank == 0 else 3 * P]
+            out2 = _segment_attention(qf[r0:r0 + t_loc], [loc] + rem, 0.16)  # softmax is order independent
+            assert torch.allclose(out2, full[r0:r0 + t_loc], atol=1e-5)
         res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
         assert len(res) == hi - lo  # outputs stay sharded by default
         sh.gather_outputs = True

@@ -272,3 +272,25 @@ def test_attention_online_softmax_rescale_is_forced(built_lib, dt):
     o = torch.empty((T, 64), dtype=dt, device=DEV)
     ops.attention(q.to(DEV), o, H, 0.125, [(k.to(DEV), _vt_of(v, H).to(DEV), T, 0, 0)])
     assert_close(o.float(), _attn_ref(q, k, v, H, 0.125), 2 * lp_tol(dt), "forced rescale")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_state_carried_across_launches(built_lib, dt):
+    """Launch 1 over the local segment parks (m, l, O); launch 2 resumes over the remote segments: must equal ONE launch
+    over [local, remote...] bit for bit (same tiles in the same order, state kept in fp32), and the fp64 reference."""
+    H, Tq = 2, 300
+    lens = [192, 100, 257]
+    q = rnd((Tq, H * 64), dt, 70)
+    ks = [rnd((n, H * 64), dt, 71 + i) for i, n in enumerate(lens)]
+    vs = [rnd((n, H * 64), dt, 81 + i) for i, n in enumerate(lens)]
+    segs = [(kk.to(DEV), _vt_of(vv, H).to(DEV), n, 0, 0) for kk, vv, n in zip(ks, vs, lens)]
+    one = torch.empty((Tq, H * 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), one, H, 0.125, segs)
+    two = torch.empty((Tq, H * 64), dtype=dt, device=DEV)
+    state = ops.attention_state(Tq, H, DEV)
+    two.fill_(float("nan"))
+    ops.attention(q.to(DEV), two, H, 0.125, segs[:1], state=state, state_out=True)
+    assert torch.isnan(two.float()).all()  # the first launch must not write the output
+    ops.attention(q.to(DEV), two, H, 0.125, segs[1:], state=state, state_in=True)
+    assert torch.equal(one, two)
+    assert_close(two.float(), _attn_ref(q, torch.cat(ks), torch.cat(vs), H, 0.125), 2 * lp_tol(dt), "state carry")
