@@ -42,6 +42,10 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((ch
 //      bit 1: s_setprio 1 around the MFMA clusters
 //      bit 2: ABLATION (timing experiments only, wrong results): never reload K/V after the first tile
 //      bit 3: ABLATION (timing only): no softmax -- P = S converted to lowp
+//      bit 7: static priority: one s_setprio 1 for the younger half of an 8-wave workgroup (waves 4-7) before the loop
+//             (issue arbitration is by priority, then age: MI355X_MICROARCH.md "Two waves per SIMD")
+//      bit 6: stage K / V^T tiles with global_load_lds (HBM -> LDS DMA, swizzle applied to the per-lane source address)
+//             instead of through registers: no staging VGPRs, no ds_write pass, no vmcnt -> ds_write chain before the barrier
 //      bit 4: packed fp32 math (v_pk_fma_f32 / v_pk_add_f32) for the exponent argument and the row sums: a wave issues one
 //             instruction per ~5 cycles whatever it is (tools/ubench/valu_rate.hip), so halving the count of these pays
 template <class T, int NW, int QPW, int OPT, int MINW>
@@ -133,6 +137,34 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     if (key_ld >= seg_keys) next_segment();
     return true;
   };
+  // DMA form of load_next + store_tile: every wave-instruction fills 8 rows x 128 B of the K (resp. V^T) image of `buf`
+  constexpr bool DMA = (OPT & 64) != 0;
+  constexpr int DPW = 8 / NW;  // DMA instructions per wave and per tile (8 x 1 KB = one 8 KB tile)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  auto dma_next = [&](int buf) -> bool {
+    if (seg_keys == 0) return false;
+    const int64_t rem = seg_keys - key_ld;
+    valid_ld = rem < AT_KB ? (int)rem : AT_KB;
+    uint16_t* kt = lds + buf * 2 * AT_TILE;
+    uint16_t* vt = kt + AT_TILE;
+    const int lrow = lane >> 3, pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int blk = wid * DPW + i;  // 8-row block of the tile (wave-uniform)
+      const int row = blk * 8 + lrow;
+      const int lch = pch ^ ((row >> 1) & 7);
+      const int krow = row < valid_ld ? row : valid_ld - 1;  // rows past the segment end are masked in the softmax
+      // Kg / Vg carry the staging thread's own (sch * 8) offset: take it out again, this path addresses by lane
+      const uint16_t* ks = Kg - sch * 8 + (key_ld + krow) * p.ldk + lch * 8;
+      const uint16_t* vs = Vg - sch * 8 + (int64_t)row * seg_ldvt + key_ld + lch * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)ks, (lds_ptr_t)(kt + blk * 8 * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)vs, (lds_ptr_t)(vt + blk * 8 * 64), 16, 0, 0);
+    }
+    key_ld += AT_KB;
+    if (key_ld >= seg_keys) next_segment();
+    return true;
+  };
   auto store_tile = [&](int buf) {
     uint16_t* kt = lds + buf * 2 * AT_TILE;
     uint16_t* vt = kt + AT_TILE;
@@ -176,9 +208,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   // pi: swap bits 2 and 3 of the key row index fed to the MFMA A operand
   const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
 
-  load_next();  // tile 0 always exists
+  if (DMA) {
+    dma_next(0);  // tile 0 always exists
+  } else {
+    load_next();
+  }
   int valid_cur = valid_ld;
-  store_tile(0);
+  if (!DMA) store_tile(0);
   __syncthreads();
   // Everything loaded so far (Q fragments, tile 0) has landed.  Say so with a waitcnt the compiler models: without it
   // the loop body waits for the loop-invariant Q registers with vmcnt(N) counts that, in steady state, land on the
@@ -186,10 +222,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
   int cur = 0;
   bool have = true;
+  if ((OPT & 128) && NW == 8) {
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+  }
   unsigned long long tq_ = 0, ts_ = 0, tp_ = 0, tb_ = 0, nt_ = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   while (have) {
     const int valid = valid_cur;
-    const bool more = load_next();
+    const bool more = DMA ? dma_next(cur ^ 1) : load_next();  // DMA: buffer cur^1 was released by the barrier that ended iteration t-1
     if (OPT & 32) c0 = __builtin_readcyclecounter();
     const uint16_t* kt = lds + cur * 2 * AT_TILE;
     const uint16_t* vt = kt + AT_TILE;
@@ -309,9 +348,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     if (OPT & 2) __builtin_amdgcn_s_setprio(0);
 
     if (OPT & 32) { asm volatile("" :: "v"(o[0][0][0]), "v"(o[QPW - 1][1][15])); c3 = __builtin_readcyclecounter(); }
-    if (more) store_tile(cur ^ 1);
+    if (!DMA && more) store_tile(cur ^ 1);
     valid_cur = valid_ld;
-    __syncthreads();
+    __syncthreads();  // (DMA: the compiler drains vmcnt before the barrier, i.e. the next tile has landed for every wave)
     if (OPT & 32) {
       const unsigned long long c4 = __builtin_readcyclecounter();
       tq_ += c1 - c0; ts_ += c2 - c1; tp_ += c3 - c2; tb_ += c4 - c3; ++nt_;
@@ -397,6 +436,12 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
     case 25: return attn_launch<T, 8, 2, 1, 2>(a, s);  // 8 waves x 64 q (512 q / workgroup, 1 workgroup / CU)
     case 26: return attn_launch<T, 8, 2, 3, 2>(a, s);  // same + setprio
+    case 45: return attn_launch<T, 8, 2, 129, 2>(a, s);  // 25 + static priority for the younger half
+    case 46: return attn_launch<T, 8, 2, 193, 2>(a, s);  // 43 (DMA) + static priority
+    case 47: return attn_launch<T, 8, 1, 129, 2>(a, s);  // 8 waves x 32 q + static priority
+    case 42: return attn_launch<T, 4, 2, 65, 2>(a, s);  // 24 + global_load_lds staging
+    case 43: return attn_launch<T, 8, 2, 65, 2>(a, s);  // 25 + global_load_lds staging
+    case 44: return attn_launch<T, 4, 2, 97, 2>(a, s);  // 42 + per-section instrumentation
     case 40: return attn_launch<T, 4, 2, 17, 2>(a, s);  // 24 + packed fp32 softmax arithmetic
     case 41: return attn_launch<T, 8, 2, 17, 2>(a, s);  // 25 + packed
     case 34: return attn_launch<T, 4, 2, 33, 2>(a, s);  // variant 24 + per-section s_memtime instrumentation
@@ -406,6 +451,7 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 29: return attn_launch<T, 4, 1, 1, 4>(a, s);  // 4 waves x 32 q, 4 workgroups / CU (<= 128 VGPR): 4 waves / SIMD
     case 30: return attn_launch<T, 8, 1, 1, 4>(a, s);  // 8 waves x 32 q, 2 workgroups / CU: 4 waves / SIMD
     case 31: return attn_launch<T, 4, 1, 9, 4>(a, s);  // ABLATION of 29: no softmax
+    case 48: return attn_launch_sp<T, 8, 3>(a, s);  // 36 + static priority for the younger half
     case 36: return attn_launch_sp<T, 8, 0>(a, s);  // 3-stage software pipeline with pinned issue order, 8 waves x 32 q
     case 37: return attn_launch_sp<T, 4, 0>(a, s);
     case 39: return attn_launch_sp<T, 4, 2>(a, s);  // occupancy experiment: 37 with ONE workgroup (1 wave / SIMD) per CU
@@ -444,7 +490,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 41) {
+  if (variant < -1 || variant > 48) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }

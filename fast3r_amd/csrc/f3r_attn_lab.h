@@ -1258,6 +1258,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel_sp(const f3r_attn_args
     }
   };
 
+  if (PROF == 3 && NW == 8) {
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+  }
   const std::true_type yes{};
   const std::false_type no{};
   // Stage t reads scores from sA when t is even (sB when odd) and leaves P(t) in pA when t is even (pB when odd).  The loop is
