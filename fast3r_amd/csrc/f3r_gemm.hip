@@ -52,7 +52,7 @@ struct ConvRow {  // per staged row: output pixel decomposition
 // SOURCE address instead (lane l of a wave-instruction fills physical chunk l%8 of row l/8 with logical chunk
 // (l%8) ^ ((row>>1)&7)).  Only for the plain operand with K == Kpad (no zero fill needed); rows past M / N are clamped to
 // the last valid row (their products are discarded by the epilogue guards).
-template <class T, int A_MODE, int EPI, bool GLDS>
+template <class T, int A_MODE, int EPI, int GLDS>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   uint16_t* As = smem;                    // [2][128][64]
@@ -213,7 +213,70 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
     }
   };
 
-  if constexpr (GLDS) {
+  if constexpr (GLDS == 2) {
+    // ---- 4-stage ring of 32-deep k-tiles, counted vmcnt: three tiles of DMA stay in flight across the barriers, so the
+    // HBM/L2 latency of a tile is covered by the MFMAs of the two tiles in front of it (cdna_hip_programming.md T3/T4).
+    // Stage = A [128][32] | W [128][32] = 16 KB; 64-byte rows; 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3)
+    // (conflict-free for the ds_read_b128 lane groups at this row stride).  A wave-instruction of the DMA fills 16 rows.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    constexpr int ST = 4, SE = 128 * 32;  // stages, elements per operand per stage
+    uint16_t* const A4 = smem;            // [ST][128][32]
+    uint16_t* const W4 = smem + ST * SE;  // [ST][128][32]
+    const int lrow = lane >> 2, pch = lane & 3;
+    const uint16_t* asrc[2];
+    const uint16_t* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wid * 2 + i) * 16 + lrow;
+      const int lch = pch ^ ((-(r >> 2)) & 3);
+      int64_t m = m0 + r;
+      if (m >= p.M) m = p.M - 1;
+      int n = n0 + r;
+      if (n >= p.N) n = p.N - 1;
+      asrc[i] = Ag + m * p.lda + lch * 8;
+      wsrc[i] = Wg + (int64_t)n * p.Kpad + lch * 8;
+    }
+    auto dma = [&](int kt32) {
+      const int st = kt32 & (ST - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt32 * 32), (lds_ptr_t)(A4 + st * SE + (wid * 2 + i) * 16 * 32), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt32 * 32), (lds_ptr_t)(W4 + st * SE + (wid * 2 + i) * 16 * 32), 16, 0, 0);
+      }
+    };
+    const int nk32 = p.Kpad / 32;
+    const int offA4 = swap_roles ? 0 : ST * SE, offB4 = swap_roles ? ST * SE : 0;
+    int foff[4];  // fragment offsets inside a stage: row (f*16 + fr) of the wave's 64-row slice, k-chunk fg
+#pragma unroll
+    for (int f = 0; f < 4; ++f) foff[f] = (f * 16 + fr) * 32 + ((fg ^ ((-((f * 16 + fr) >> 2)) & 3)) << 3);
+    const int rbaseA = (swap_roles ? wm : wn) * 64 * 32, rbaseB = (swap_roles ? wn : wm) * 64 * 32;
+#pragma unroll
+    for (int t = 0; t < ST - 1; ++t)
+      if (t < nk32) dma(t);
+    for (int kt = 0; kt < nk32; ++kt) {
+      // tile kt must have landed: at most the DMAs of the (ST-2) younger tiles may still be in flight
+      if (kt + ST - 2 < nk32) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);   // vmcnt(8) = 2 tiles x 4 DMA instructions per wave
+      else if (kt + 1 < nk32) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // tail: one younger tile
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                          // last tile: everything
+      __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed AND every wave is done reading tile kt-1
+      if (kt + ST - 1 < nk32) dma(kt + ST - 1);  // refill the slot tile kt-1 just left
+      const int st = kt & (ST - 1);
+      const uint16_t* ta = smem + offA4 + st * SE + rbaseA;
+      const uint16_t* tb = smem + offB4 + st * SE + rbaseB;
+      typename T::vec8 fa[4], fb[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fa[f] = as_vec8<T>(*(const u32x4*)(ta + foff[f]));
+        fb[f] = as_vec8<T>(*(const u32x4*)(tb + foff[f]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  } else if constexpr (GLDS == 1) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     // wave w issues instructions i = 0..3 for each operand: rows (w*4 + i)*8 + lane/8 of the 128-row tile
@@ -401,16 +464,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
   }
 }
 
-int g_gemm_glds = -1;  // -1: read F3R_GEMM_GLDS once (default on)
-bool use_glds() {
+int g_gemm_glds = -1;  // -1: read F3R_GEMM_GLDS once: 0 register staging, 1 DMA double buffer (BK 64), 2 DMA 4-stage ring (BK 32)
+int glds_mode() {
   if (g_gemm_glds < 0) {
     const char* e = getenv("F3R_GEMM_GLDS");
     g_gemm_glds = e ? atoi(e) : 1;
   }
-  return g_gemm_glds != 0;
+  return g_gemm_glds;
 }
 
-template <class T, int A_MODE, int EPI, bool GLDS>
+template <class T, int A_MODE, int EPI, int GLDS>
 int launch(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
   auto kern = gemm_kernel<T, A_MODE, EPI, GLDS>;
@@ -429,13 +492,17 @@ template <class T>
 int dispatch(const f3r_gemm_args& a, hipStream_t stream) {
   if (a.a_mode == F3R_A_CONV3X3) {
     F3R_REQUIRE(a.epi == F3R_EPI_GENERIC, "f3r_gemm: conv3x3 supports only the generic epilogue");
-    return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC, false>(a, stream);
+    return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC, 0>(a, stream);
   }
-  const bool glds = use_glds() && a.K == a.Kpad && a.M > 0;
+  const int glds = (a.K == a.Kpad && a.M > 0) ? glds_mode() : 0;
   switch (a.epi) {
-    case F3R_EPI_GENERIC: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, true>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false>(a, stream);
-    case F3R_EPI_QKV: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, true>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_QKV, false>(a, stream);
-    case F3R_EPI_CONVT: return launch<T, F3R_A_PLAIN, F3R_EPI_CONVT, false>(a, stream);
+    case F3R_EPI_GENERIC:
+      return glds == 2 ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 2>(a, stream)
+           : glds == 1 ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 0>(a, stream);
+    case F3R_EPI_QKV:
+      return glds == 2 ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 2>(a, stream)
+           : glds == 1 ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 0>(a, stream);
+    case F3R_EPI_CONVT: return launch<T, F3R_A_PLAIN, F3R_EPI_CONVT, 0>(a, stream);
   }
   f3r_set_error("f3r_gemm: bad epi %d", a.epi);
   return F3R_ERR_ARG;
