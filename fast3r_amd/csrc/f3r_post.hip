@@ -1,0 +1,284 @@
+// Post-forward alignment of the local pointmaps to the global frame:
+// MultiViewDUSt3RLitModule.align_local_pts3d_to_global, fast3r/models/multiview_dust3r_module.py:427-549.
+// Per (view, sample) "problem" of npix pixels:
+//   1. thr = torch.quantile(conf, q)                       -> exact order statistics by 3-pass radix select + fp32 lerp
+//   2. mask = (conf >= thr) & valid; fall back to valid if fewer than 3 points survive, to identity if still fewer (:495-510)
+//   3. (R, t, s) = roma.rigid_points_registration(local[mask], global[mask], compute_scaling=True): Umeyama -> masked raw
+//      moments in fp64 (one pass), then a 3x3 SVD by Jacobi rotations (one thread per problem)
+//   4. out = s * (local @ R^T) + t for ALL pixels (:514)
+// Everything here is HBM-bound byte / index work plus a 3x3 solve: no MFMA.  One workgroup per problem for steps 1-3 (a problem is
+// 1-3 MB; hundreds of problems run side by side), a flat grid for step 4.
+#include "f3r_common.h"
+
+namespace {
+
+constexpr int PNT = 1024;  // threads per problem workgroup
+
+// float -> unsigned key with the same ordering (handles negatives too; conf is >= vmin > 0 in practice)
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, u);
+}
+
+// k-th smallest key (0-based) of conf[0..n) by radix select over 11 + 11 + 10 bits; all threads return the same value.
+__device__ uint32_t select_kth(const float* __restrict__ conf, int64_t n, int64_t k, uint32_t* hist /*2048*/, int64_t* sh_i64 /*2*/) {
+  uint32_t prefix = 0, prefix_mask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = threadIdx.x; i < nb; i += PNT) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += PNT) {
+      const uint32_t key = fkey(conf[i]);
+      if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t acc = 0;
+      int b = 0;
+      for (; b < nb; ++b) {
+        if (acc + hist[b] > k) break;
+        acc += hist[b];
+      }
+      sh_i64[0] = b;
+      sh_i64[1] = k - acc;
+    }
+    __syncthreads();
+    const uint32_t b = (uint32_t)sh_i64[0];
+    k = sh_i64[1];
+    prefix |= b << shifts[pass];
+    prefix_mask |= (uint32_t)(nb - 1) << shifts[pass];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// workspace per problem: 40 doubles: [0..16] moments of mask A (conf & valid), [17..33] of mask B (valid), [34] thr (as double)
+constexpr int WS_PER = 40;
+
+__global__ __launch_bounds__(PNT) void align_stats_kernel(const float* __restrict__ conf, const float* __restrict__ loc,
+                                                          const float* __restrict__ glob, const uint8_t* __restrict__ valid,
+                                                          double* __restrict__ ws, int64_t npix, float q) {
+  __shared__ uint32_t hist[2048];
+  __shared__ int64_t sh_i64[2];
+  __shared__ double red[16][34];
+  __shared__ float sh_thr;
+  const int64_t prob = blockIdx.x;
+  const float* cf = conf + prob * npix;
+  const float* pl = loc + prob * npix * 3;
+  const float* pg = glob + prob * npix * 3;
+  const uint8_t* vm = valid ? valid + prob * npix : nullptr;
+
+  // ---- 1. quantile, exactly as torch.quantile (linear): rank = q*(n-1) in fp32, lerp between the two order statistics
+  const float rank = q * (float)(npix - 1);
+  const float rlo = floorf(rank);
+  const int64_t klo = (int64_t)rlo;
+  const int64_t khi = (int64_t)ceilf(rank);
+  const float vlo = fkey_inv(select_kth(cf, npix, klo, hist, sh_i64));
+  float vhi = vlo;
+  if (khi != klo) vhi = fkey_inv(select_kth(cf, npix, khi, hist, sh_i64));
+  if (threadIdx.x == 0) {
+    const float w = rank - rlo;
+    const float d = vhi - vlo;
+    sh_thr = (w < 0.5f) ? vlo + w * d : vhi - d * (1.0f - w);  // at::lerp
+  }
+  __syncthreads();
+  const float thr = sh_thr;
+
+  // ---- 2./3. masked raw moments in fp64: n, sum x(3), sum y(3), sum y_i x_j (9), sum |x|^2   for both masks
+  double mA[17], mB[17];
+#pragma unroll
+  for (int i = 0; i < 17; ++i) { mA[i] = 0.0; mB[i] = 0.0; }
+  for (int64_t i = threadIdx.x; i < npix; i += PNT) {
+    const bool v = vm ? (vm[i] != 0) : true;
+    if (!v) continue;
+    const bool a = cf[i] >= thr;
+    const double x0 = pl[i * 3 + 0], x1 = pl[i * 3 + 1], x2 = pl[i * 3 + 2];
+    const double y0 = pg[i * 3 + 0], y1 = pg[i * 3 + 1], y2 = pg[i * 3 + 2];
+    const double t[17] = {1.0, x0, x1, x2, y0, y1, y2, y0 * x0, y0 * x1, y0 * x2, y1 * x0, y1 * x1, y1 * x2, y2 * x0, y2 * x1, y2 * x2,
+                          x0 * x0 + x1 * x1 + x2 * x2};
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+      mB[j] += t[j];
+      if (a) mA[j] += t[j];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 17; ++j) {
+    double a = mA[j], b = mB[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      b += __shfl_xor(b, off, 64);
+    }
+    if (lane == 0) { red[wv][j] = a; red[wv][17 + j] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 34) {
+    double s = 0.0;
+    for (int w = 0; w < PNT / 64; ++w) s += red[w][threadIdx.x];
+    ws[prob * WS_PER + threadIdx.x] = s;
+  }
+  if (threadIdx.x == 0) ws[prob * WS_PER + 34] = (double)thr;
+}
+
+// 3x3 SVD of M by two-sided use of the Jacobi eigen-decomposition of M^T M:  M = U diag(s) V^T, s sorted descending.
+__device__ void svd3(const double M[3][3], double U[3][3], double S[3], double V[3][3]) {
+  double A[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += M[k][i] * M[k][j];
+      A[i][j] = a;
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {  // A <- A J
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {  // A <- J^T A
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {  // V <- V J
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq;
+          V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double ev[3] = {A[0][0], A[1][1], A[2][2]};
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (ev[idx[j]] > ev[idx[i]]) { const int tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; }
+  double Vs[3][3];
+  for (int c = 0; c < 3; ++c) {
+    S[c] = sqrt(fmax(ev[idx[c]], 0.0));
+    for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][idx[c]];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) V[r][c] = Vs[r][c];
+  // U columns: M v_c / s_c; complete a deficient basis by Gram-Schmidt / cross products
+  const double tol = 1e-12 * fmax(S[0], 1e-300);
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += M[r][k] * V[k][c];
+      U[r][c] = (S[c] > tol) ? a / S[c] : 0.0;
+    }
+  }
+  auto norm3 = [](double* v0, double* v1, double* v2) {
+    const double n = sqrt(*v0 * *v0 + *v1 * *v1 + *v2 * *v2);
+    if (n > 0) { *v0 /= n; *v1 /= n; *v2 /= n; }
+    return n;
+  };
+  if (S[0] <= tol) { U[0][0] = 1; U[1][0] = 0; U[2][0] = 0; }
+  if (S[1] <= tol) {  // any unit vector orthogonal to u0
+    const double a0 = fabs(U[0][0]), a1 = fabs(U[1][0]), a2 = fabs(U[2][0]);
+    double e[3] = {0, 0, 0};
+    e[(a0 <= a1 && a0 <= a2) ? 0 : (a1 <= a2 ? 1 : 2)] = 1.0;
+    const double d = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0];
+    U[0][1] = e[0] - d * U[0][0]; U[1][1] = e[1] - d * U[1][0]; U[2][1] = e[2] - d * U[2][0];
+    norm3(&U[0][1], &U[1][1], &U[2][1]);
+  }
+  if (S[2] <= tol) {  // u2 = u0 x u1 (the sign is fixed by the determinant correction of the caller)
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+}
+
+__device__ __forceinline__ double det3(const double A[3][3]) {
+  return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+         A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+}
+
+// one thread per problem: moments -> (R, t, s) as 13 floats [R row-major (9) | t (3) | s]
+__global__ void align_solve_kernel(const double* __restrict__ ws, float* __restrict__ rts, int n_prob) {
+  const int prob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (prob >= n_prob) return;
+  const double* m = ws + (int64_t)prob * WS_PER;
+  if (m[0] < 3.0) m += 17;  // fewer than 3 confident points: use the valid mask only (:495-503)
+  float* o = rts + prob * 13;
+  if (m[0] < 3.0) {  // identity (:506-510)
+    for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? 1.f : 0.f;
+    o[9] = o[10] = o[11] = 0.f;
+    o[12] = 1.f;
+    return;
+  }
+  const double n = m[0];
+  const double xm[3] = {m[1] / n, m[2] / n, m[3] / n}, ym[3] = {m[4] / n, m[5] / n, m[6] / n};
+  double M[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i][j] = m[7 + i * 3 + j] - n * ym[i] * xm[j];
+  const double sx2 = m[16] - n * (xm[0] * xm[0] + xm[1] * xm[1] + xm[2] * xm[2]);
+  double U[3][3], S[3], V[3][3];
+  svd3(M, U, S, V);
+  const double d = (det3(U) * det3(V) < 0) ? -1.0 : 1.0;
+  double R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = U[i][0] * V[j][0] + U[i][1] * V[j][1] + d * U[i][2] * V[j][2];
+  const double scale = (S[0] + S[1] + d * S[2]) / sx2;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o[i * 3 + j] = (float)R[i][j];
+    o[9 + i] = (float)(ym[i] - scale * (R[i][0] * xm[0] + R[i][1] * xm[1] + R[i][2] * xm[2]));
+  }
+  o[12] = (float)scale;
+}
+
+// out = s * (x R^T) + t, fp32, the reference's own operation order (scale the rotated point, then translate)
+__global__ void align_apply_kernel(const float* __restrict__ loc, const float* __restrict__ rts, float* __restrict__ out, int64_t npix,
+                                   int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float* r = rts + (i / npix) * 13;
+  const float x0 = loc[i * 3 + 0], x1 = loc[i * 3 + 1], x2 = loc[i * 3 + 2];
+  const float s = r[12];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[i * 3 + c] = s * (x0 * r[c * 3 + 0] + x1 * r[c * 3 + 1] + x2 * r[c * 3 + 2]) + r[9 + c];
+}
+
+__global__ void align_thr_kernel(const double* __restrict__ ws, float* __restrict__ o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (float)ws[(int64_t)i * WS_PER + 34];
+}
+
+}  // namespace
+
+extern "C" size_t f3r_align_workspace_bytes(int n_prob) { return (size_t)(n_prob > 0 ? n_prob : 0) * WS_PER * sizeof(double); }
+
+extern "C" int f3r_align_local_to_global(const float* conf, const float* pts_local, const float* pts_global, const uint8_t* valid_mask,
+                                         float* out, float* rts, float* thr_out, void* workspace, size_t ws_bytes, int n_prob,
+                                         int64_t npix, float quantile, f3r_stream_t stream) {
+  F3R_REQUIRE(conf && pts_local && pts_global && out && rts && workspace, "f3r_align_local_to_global: null pointer");
+  F3R_REQUIRE(n_prob >= 0 && npix > 0, "f3r_align_local_to_global: bad sizes");
+  F3R_REQUIRE(quantile >= 0.f && quantile <= 1.f, "f3r_align_local_to_global: quantile %f outside [0, 1]", (double)quantile);
+  F3R_REQUIRE(ws_bytes >= f3r_align_workspace_bytes(n_prob) && (((uintptr_t)workspace) & 7) == 0, "f3r_align_local_to_global: workspace too small / misaligned");
+  if (n_prob == 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  double* ws = (double*)workspace;
+  hipLaunchKernelGGL(align_stats_kernel, dim3(n_prob), dim3(PNT), 0, s, conf, pts_local, pts_global, valid_mask, ws, npix, quantile);
+  hipLaunchKernelGGL(align_solve_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, s, ws, rts, n_prob);
+  const int64_t total = (int64_t)n_prob * npix;
+  hipLaunchKernelGGL(align_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pts_local, rts, out, npix, total);
+  if (thr_out) hipLaunchKernelGGL(align_thr_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, s, ws, thr_out, n_prob);
+  return f3r_check_launch("f3r_align_local_to_global");
+}

@@ -4,10 +4,12 @@ The reference class is a LightningModule whose training / validation / metric ma
 path.  What inference callers use is kept with the same names:
     lit = MultiViewDUSt3RLitModule.load_for_inference(net)   (:119-123)
     lit.eval(); lit(views) == net(views)                     (:125-126)
-The post-processing helpers (estimate_camera_poses :807-869, align_local_pts3d_to_global :427-549) are the "next"
-rows of SURVEY.md section 8f and raise NotImplementedError until they are built.
+`align_local_pts3d_to_global` (:427-549) runs on the GPU (fast3r_amd/align.py, SURVEY.md section 8f rank 1);
+`estimate_camera_poses` (:807-869, rank 2) raises NotImplementedError until it is built.
 """
 import torch
+
+from .align import align_local_pts3d_to_global as _align
 
 
 class MultiViewDUSt3RLitModule(torch.nn.Module):
@@ -33,7 +35,6 @@ class MultiViewDUSt3RLitModule(torch.nn.Module):
         raise NotImplementedError("estimate_camera_poses is a post-processing step outside the MI355X hot path "
                                   "(SURVEY.md section 8f, rank 2); not built yet")
 
-    @staticmethod
-    def align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=0):
-        raise NotImplementedError("align_local_pts3d_to_global is a post-processing step outside the MI355X hot path "
-                                  "(SURVEY.md section 8f, rank 1); not built yet")
+    def align_local_pts3d_to_global(self, preds, views, min_conf_thr_percentile=0):
+        """Adds `pts3d_local_aligned_to_global` to every pred (reference :427-549); preds must be on the GPU."""
+        _align(preds, views, min_conf_thr_percentile)

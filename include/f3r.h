@@ -202,6 +202,21 @@ int f3r_dpt_final(const void* x, const float* w, const float* b, float* pts3d, f
  */
 int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dtype, f3r_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f3r_align_local_to_global: similarity alignment of the local pointmap of every (view, sample) to its global pointmap.
+ * Replaces MultiViewDUSt3RLitModule.align_local_pts3d_to_global (fast3r/models/multiview_dust3r_module.py:427-549), i.e. per
+ * problem p of npix pixels: thr = torch.quantile(conf, quantile) (:476); mask = conf >= thr & valid (:479-482), falling back
+ * to valid alone below 3 points and to the identity below 3 valid points (:495-510); (R, t, s) =
+ * roma.rigid_points_registration(local[mask], global[mask], compute_scaling=True) (:509-511; Umeyama); out = s*(local R^T) + t (:514).
+ *   conf [n_prob][npix] fp32, pts_local / pts_global / out [n_prob][npix][3] fp32, valid_mask [n_prob][npix] bytes or NULL,
+ *   rts [n_prob][13] fp32 = {R row-major (9), t (3), s}, thr_out [n_prob] fp32 or NULL,
+ *   workspace: f3r_align_workspace_bytes(n_prob) bytes, 8-byte aligned.
+ */
+size_t f3r_align_workspace_bytes(int n_prob);
+int f3r_align_local_to_global(const float* conf, const float* pts_local, const float* pts_global, const uint8_t* valid_mask,
+                              float* out, float* rts, float* thr_out, void* workspace, size_t ws_bytes, int n_prob,
+                              int64_t npix, float quantile, f3r_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

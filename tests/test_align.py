@@ -1,0 +1,152 @@
+"""align_local_pts3d_to_global (reference fast3r/models/multiview_dust3r_module.py:427-549).
+The reference function is not importable and its solver lives in the un-vendored, un-pinned `roma` package, so parity for this
+row is UNPINNED against the reference; it is anchored on (a) construction properties of the oracle restatement (CPU, below) and
+(b) HIP path == oracle on the same inputs (GPU): quantile thresholds bit-exact vs torch.quantile, transforms / points to fp32 noise."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from oracle.align_oracle import align_local_pts3d_to_global as align_oracle
+from oracle.align_oracle import rigid_points_registration
+
+
+def random_rotation(g):
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    if torch.det(q) < 0:
+        q[:, 0] *= -1
+    return q
+
+
+def make_preds(n_views, B, H, W, seed, noise=0.02, shapes=None):
+    """Local pointmaps = inverse similarity of the global ones + noise, so a known (R, t, s) maps local -> global."""
+    g = torch.Generator().manual_seed(seed)
+    preds, truth = [], []
+    for i in range(n_views):
+        h, w = (H, W) if shapes is None else shapes[i]
+        glob = torch.randn(B, h, w, 3, generator=g) * 2.0 + torch.tensor([0.5, -1.0, 4.0])
+        R, s, t = random_rotation(g), float(0.5 + 2 * torch.rand(1, generator=g)), torch.randn(3, generator=g)
+        loc = ((glob - t) @ R) / s  # global = s * R loc + t
+        loc = loc + noise * torch.randn(loc.shape, generator=g)
+        conf = 1 + torch.exp(torch.randn(B, h, w, generator=g))
+        preds.append({"pts3d_local": loc, "conf_local": conf.clone(), "pts3d_in_other_view": glob, "conf": conf})
+        truth.append((R, s, t))
+    return preds, truth
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle properties
+def test_oracle_recovers_exact_similarity():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(500, 3, generator=g)
+    R, s, t = random_rotation(g), 1.7, torch.tensor([0.3, -2.0, 5.0])
+    Rh, th, sh = rigid_points_registration(x, s * x @ R.t() + t)
+    assert torch.allclose(Rh, R, atol=1e-5) and abs(float(sh) - s) < 1e-5 and torch.allclose(th, t, atol=1e-4)
+    # reflection-only data still yields a proper rotation (det = +1): special Procrustes
+    Rr, _, _ = rigid_points_registration(x, x * torch.tensor([1.0, 1.0, -1.0]))
+    assert abs(float(torch.det(Rr)) - 1.0) < 1e-5
+
+
+def test_oracle_control_flow_and_errors():
+    preds, truth = make_preds(2, 2, 8, 12, seed=1, noise=0.0)
+    views = [{}, {"valid_mask": torch.zeros(2, 8, 12, dtype=torch.bool)}]  # view 1: nothing valid -> identity (:506-510)
+    out = align_oracle([dict(p) for p in preds], views, min_conf_thr_percentile=85)
+    assert out[0]["pts3d_local_aligned_to_global"].shape == (2, 8, 12, 3)
+    assert torch.allclose(out[0]["pts3d_local_aligned_to_global"], preds[0]["pts3d_in_other_view"], atol=1e-4)
+    assert torch.equal(out[1]["pts3d_local_aligned_to_global"], preds[1]["pts3d_local"])
+    bad = [dict(preds[0])]
+    del bad[0]["conf"]
+    with pytest.raises(ValueError):
+        align_oracle(bad, [{}])
+
+
+def test_product_raises_like_reference_and_has_no_cpu_path(built_lib):
+    from fast3r_amd import align_local_pts3d_to_global
+    from fast3r_amd._lib import F3RError
+    preds, _ = make_preds(1, 1, 4, 4, seed=2)
+    bad = [dict(preds[0])]
+    del bad[0]["pts3d_local"]
+    with pytest.raises(ValueError, match="pts3d_local"):
+        align_local_pts3d_to_global(bad, [{}])
+    with pytest.raises(F3RError):
+        align_local_pts3d_to_global(preds, [{}])  # CPU tensors: no fallback
+    assert built_lib.f3r_align_workspace_bytes(3) == 3 * 40 * 8
+    assert built_lib.f3r_align_local_to_global(0x1000, 0x1000, 0x1000, None, 0x1000, 0x1000, None, 0x1000, 8, 1, 16, ctypes.c_float(1.5), None) == -1
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP path == oracle
+def _to_gpu(preds):
+    return [{k: v.cuda() for k, v in p.items()} for p in preds]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pct", [0, 50, 85, 100])
+def test_align_matches_oracle(built_lib, pct):
+    from fast3r_amd import align_local_pts3d_to_global
+    preds, truth = make_preds(4, 2, 48, 64, seed=3 + pct)
+    views = [{} for _ in preds]
+    ref = align_oracle([dict(p) for p in preds], views, min_conf_thr_percentile=pct)
+    got, tr = align_local_pts3d_to_global(_to_gpu(preds), views, min_conf_thr_percentile=pct, return_transforms=True)
+    for i, (r, o) in enumerate(zip(ref, got)):
+        a, b = o["pts3d_local_aligned_to_global"].cpu(), r["pts3d_local_aligned_to_global"]
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (i, float((a - b).abs().max()))
+        for bb in range(2):  # and the solution is the planted similarity up to the noise level
+            R = tr[i][bb, :9].view(3, 3).cpu()
+            assert torch.allclose(R, truth[i][0], atol=5e-3) and abs(float(tr[i][bb, 12]) - truth[i][1]) < 5e-3 * truth[i][1]
+
+
+@pytest.mark.gpu
+def test_quantile_threshold_is_bit_exact(built_lib):
+    from fast3r_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    n_prob, npix = 5, 3001
+    conf = (1 + torch.exp(torch.randn(n_prob, npix, generator=g))).cuda()
+    conf[1, :100] = conf[1, 0]  # ties around the cut
+    pts = torch.randn(n_prob, npix, 3, generator=g).cuda()
+    out, rts, thr = torch.empty_like(pts), torch.empty(n_prob, 13).cuda(), torch.empty(n_prob).cuda()
+    ws = torch.empty(n_prob * 40, dtype=torch.float64).cuda()
+    for q in (0.0, 0.123, 0.5, 0.85, 0.999, 1.0):
+        _lib.check(_lib.lib().f3r_align_local_to_global(conf.data_ptr(), pts.data_ptr(), pts.data_ptr(), None, out.data_ptr(), rts.data_ptr(),
+                                                       thr.data_ptr(), ws.data_ptr(), ws.numel() * 8, n_prob, npix, q,
+                                                       torch.cuda.current_stream().cuda_stream))
+        ref = torch.quantile(conf.cpu(), q, dim=1)
+        assert torch.equal(thr.cpu(), ref), (q, thr.cpu(), ref)
+
+
+@pytest.mark.gpu
+def test_align_masks_fallbacks_and_mixed_resolution(built_lib):
+    from fast3r_amd import align_local_pts3d_to_global
+    shapes = [(32, 48), (16, 16), (32, 48)]
+    preds, _ = make_preds(3, 1, 0, 0, seed=21, shapes=shapes)
+    g = torch.Generator().manual_seed(5)
+    vm0 = torch.rand(1, 32, 48, generator=g) > 0.4
+    vm2 = torch.zeros(1, 32, 48, dtype=torch.bool)
+    vm2[0, 0, :2] = True  # only 2 valid points -> identity
+    views = [{"valid_mask": vm0}, {}, {"valid_mask": vm2}]
+    ref = align_oracle([dict(p) for p in preds], views, min_conf_thr_percentile=70)
+    got = align_local_pts3d_to_global(_to_gpu(preds), [{k: v.cuda() for k, v in vw.items()} for vw in views], min_conf_thr_percentile=70)
+    for r, o in zip(ref, got):
+        a, b = o["pts3d_local_aligned_to_global"].cpu(), r["pts3d_local_aligned_to_global"]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    assert torch.equal(got[2]["pts3d_local_aligned_to_global"].cpu(), preds[2]["pts3d_local"])
+
+
+@pytest.mark.gpu
+def test_align_after_forward_via_lit_module(built_lib):
+    """The demo flow (fast3r/viz/demo.py:420-461): forward -> lit_module.align_local_pts3d_to_global(preds, views, 85)."""
+    from helpers import golden_model_inputs, load_golden, views_to
+    from fast3r_amd import Fast3R, MultiViewDUSt3RLitModule
+    fix = load_golden("tiny_3x64")
+    enc, dec, head, sd, views = golden_model_inputs(fix)
+    m = Fast3R(enc, dec, head).eval()
+    m.load_state_dict(sd)
+    lit = MultiViewDUSt3RLitModule.load_for_inference(m.cuda())
+    with torch.no_grad():
+        torch.manual_seed(fix["rng_seed"])
+        preds = lit(views_to(views, "cuda"))
+    lit.align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=85)
+    ref = align_oracle([{k: v.cpu() for k, v in p.items()} for p in preds], views, min_conf_thr_percentile=85)
+    for r, o in zip(ref, preds):
+        a, b = o["pts3d_local_aligned_to_global"].cpu(), r["pts3d_local_aligned_to_global"]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())

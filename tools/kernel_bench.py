@@ -140,6 +140,32 @@ def bench_conv(dt, B, H, W, Ci, Co, name, stride=1):
                       "tflops": round(2.0 * B * oh * ow * 9 * Ci * Co / med / 1e9, 1)}), flush=True)
 
 
+def bench_align(n_views=320, H=512, W=512, pct=85):
+    """align_local_pts3d_to_global at the headline shape: HBM-bound.  Algorithmic bytes per view: conf 4 B x (6 radix passes + 1)
+    + local/global points 2 x 12 B (moments) + local 12 B + out 12 B (apply) = 76 B per pixel."""
+    import time
+    from fast3r_amd import align_local_pts3d_to_global
+    from oracle.align_oracle import align_local_pts3d_to_global as align_oracle
+    g = torch.Generator().manual_seed(0)
+    base = {"pts3d_local": torch.randn(1, H, W, 3, generator=g), "pts3d_in_other_view": torch.randn(1, H, W, 3, generator=g),
+            "conf": 1 + torch.exp(torch.randn(1, H, W, generator=g))}
+    base["conf_local"] = base["conf"]
+    preds = [{k: v.cuda() + 0.001 * i for k, v in base.items()} for i in range(n_views)]
+    views = [{} for _ in range(n_views)]
+
+    def f():
+        align_local_pts3d_to_global(preds, views, pct)
+    f()
+    med, mn = time_ms(f, rounds=3, inner=1)
+    nbytes = n_views * H * W * 76.0
+    t0 = time.perf_counter()
+    align_oracle([{k: v.cpu() for k, v in preds[i].items()} for i in range(4)], views[:4], pct)
+    cpu_s = (time.perf_counter() - t0) / 4
+    print(json.dumps({"kernel": "align_local_to_global", "views": n_views, "HW": [H, W], "percentile": pct, "ms": round(med, 3),
+                      "views_per_s": round(n_views / med * 1e3, 1), "GBps_algorithmic": round(nbytes / med / 1e6, 1),
+                      "cpu_oracle_ms_per_view": round(cpu_s * 1e3, 1), "note": "ms includes torch.stack of the inputs (3 copies)"}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="attn,gemm,conv")
@@ -165,6 +191,8 @@ if __name__ == "__main__":
         bench_gemm(dt, M, 1024, 768, "patch_embed")
         bench_qkv(dt, M, 1024, 1024)
         bench_qkv(dt, M, 1024, M)
+    if "align" in args.what:
+        bench_align()
     if "conv" in args.what:
         bench_conv(dt, 8, 128, 128, 256, 256, "refinenet1 rcu")
         bench_conv(dt, 8, 256, 256, 256, 128, "head0")
