@@ -42,6 +42,13 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((ch
 //      bit 1: s_setprio 1 around the MFMA clusters
 //      bit 2: ABLATION (timing experiments only, wrong results): never reload K/V after the first tile
 //      bit 3: ABLATION (timing only): no softmax -- P = S converted to lowp
+//      bit 9: the running max enters the scores through the MFMA itself: a fifth k-step whose K-side fragment is the constant
+//             (1, 1, 0, ...) and whose Q-side fragment is (-m_hi, -m_lo, 0, ...) per query (the max kept as an exact sum of two
+//             lowp numbers), with Q pre-multiplied by scale*log2(e).  Scores then come out as s' = q.k*c - m and P = exp2(s')
+//             needs no per-element subtract/fma: -64 VALU for +4 MFMA per 64 x 64 tile.  Implies bits 0 and 8.
+//      bit 8: fewer instructions per tile (the per-wave issue rate is the measured bound): row sums by v_dot2c on the packed P
+//             (2 elements per instruction; the sum then is over the ROUNDED probabilities, i.e. exactly what P V multiplies),
+//             and pointer-increment addressing of the K / V^T staging loads instead of a 64-bit multiply-add per chunk and tile
 //      bit 7: static priority: one s_setprio 1 for the younger half of an 8-wave workgroup (waves 4-7) before the loop
 //             (issue arbitration is by priority, then age: MI355X_MICROARCH.md "Two waves per SIMD")
 //      bit 6: stage K / V^T tiles with global_load_lds (HBM -> LDS DMA, swizzle applied to the per-lane source address)
@@ -76,8 +83,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     q_ok[qb] = qrow[qb] < p.tq;
     if (!q_ok[qb]) qrow[qb] = p.tq - 1;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
-      qf[qb][ds] = as_vec8<T>(*(const u32x4*)(Qg + qrow[qb] * p.ldq + head * 64 + ds * 16 + g * 8));
+    for (int ds = 0; ds < 4; ++ds) {
+      u32x4 raw = *(const u32x4*)(Qg + qrow[qb] * p.ldq + head * 64 + ds * 16 + g * 8);
+      if ((OPT & 512) && !p.q_prescaled) {  // the fifth k-step needs the scores in exp2 units
+        const float cq = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = pack2<T>(lo_f<T>(raw[j]) * cq, hi_f<T>(raw[j]) * cq);
+      }
+      qf[qb][ds] = as_vec8<T>(raw);
+    }
   }
 
   // ---- staging role: chunk ids tid + i*NT of the combined [K tile | V^T tile] chunk space (id < 512: K, else V^T);
@@ -92,6 +106,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   int64_t seg_keys = 0, seg_ldvt = 0;
   const uint16_t* Kg = nullptr;
   const uint16_t* Vg = nullptr;
+  const uint16_t* kp[SPLIT ? 1 : 512 / NT];  // OPT bit 8: per-chunk running pointers into the current tile
+  const uint16_t* vp[SPLIT ? 1 : 512 / NT];
+  const int64_t kstep = (int64_t)AT_KB * p.ldk;
   auto next_segment = [&]() {
     key_ld = 0;
     seg_keys = 0;
@@ -101,6 +118,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
         seg_ldvt = p.ldvt[seg_ld];
         Kg = (const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64 + sch * 8;
         Vg = (const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt + sch * 8;
+        if (OPT & 256) {
+#pragma unroll
+          for (int i = 0; i < (SPLIT ? 1 : 512 / NT); ++i) {
+            const int srow = srow0 + i * (NT / 8);
+            kp[i] = Kg + (int64_t)srow * p.ldk;
+            vp[i] = Vg + (int64_t)srow * seg_ldvt;
+          }
+        }
         break;
       }
   };
@@ -120,6 +145,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
           if (srow0 < valid_ld) rk[0] = *(const u32x4*)(Kg + (key_ld + srow0) * p.ldk);
         } else {
           rk[0] = *(const u32x4*)(Vg + (int64_t)srow0 * seg_ldvt + key_ld);
+        }
+      } else if (OPT & 256) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+          const int srow = srow0 + i * (NT / 8);
+          u32x4 z = {0u, 0u, 0u, 0u};
+          rk[i] = z;
+          if (srow < valid_ld) rk[i] = *(const u32x4*)kp[i];
+          rv[i] = *(const u32x4*)vp[i];
+          kp[i] += kstep;
+          vp[i] += AT_KB;
         }
       } else {
 #pragma unroll
@@ -203,7 +239,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       l_run[qb] = sm[1 + g];
     }
   }
-  const float c = p.q_prescaled ? 1.0f : p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*c)
+  const float c = (p.q_prescaled || (OPT & 512)) ? 1.0f : p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*c)
+  // OPT bit 9: running max as m = mh + ml (both exactly representable in the operand type), fragments of the fifth k-step
+  constexpr bool MX = (OPT & 512) != 0;
+  constexpr bool LAZY = (OPT & 1024) != 0;  // OPT bit 10: no per-tile max, re-base on a row-sum trigger (needs MX)
+  constexpr float AT_REBASE_SUM = 64.f;
+  // (the bias step is a 32x32x8 MFMA: 2-register operands, lane (row, g) supplies k-slots 4g..4g+3, so slots 0,1 sit in g == 0)
+  u32x2 mfrag[QPW];
+  const u32x2 onesfrag = {g == 0 ? pack2<T>(1.0f, 1.0f) : 0u, 0u};
+  bool first_tile = true;
+#pragma unroll
+  for (int qb = 0; qb < QPW; ++qb) {
+    mfrag[qb] = u32x2{0u, 0u};
+    if (MX) {
+      if (p.state_in) {  // resumed state: m_run holds mh + ml; split it again (exact: it was stored as such a sum)
+        const float h = from_lp<T>(to_lp<T>(m_run[qb]));
+        if (g == 0) mfrag[qb][0] = pack2<T>(-h, -(m_run[qb] - h));
+        first_tile = false;
+      } else {
+        m_run[qb] = 0.f;  // reference max of the bias step; the first tile always re-bases it
+      }
+    }
+  }
 
   // pi: swap bits 2 and 3 of the key row index fed to the MFMA A operand
   const int krow_pi = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
@@ -239,9 +296,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int qb = 0; qb < QPW; ++qb)
+      for (int qb = 0; qb < QPW; ++qb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
+        if (MX) s[qb][kb] = T::mfma32k8(onesfrag, mfrag[qb], s[qb][kb]);  // s' starts at -(mh + ml)
+      }
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
         const typename T::vec8 a = as_vec8<T>(*(const u32x4*)(kt + aswz(kb * 32 + krow_pi, ds * 2 + g)));
@@ -275,6 +334,111 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
           for (int j = 0; j < 4; ++j) pk[j] = pack2<T>(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j], s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1]);
           pf[qb][ks] = as_vec8<T>(pk);
         }
+    } else if (MX && LAZY) {
+      // The reference m only has to keep P = exp2(s - m) inside the operand type's range; softmax is invariant to it.
+      // So no per-tile max at all: compute P against the current reference, and only if a lane's 32-key partial sum
+      // reaches AT_REBASE_SUM (some P may have grown past 2, none can have passed 64 otherwise) take the rare path that
+      // finds the true tile max, moves the reference there and recomputes P.  The first tile always takes it.
+#pragma unroll
+      for (int qb = 0; qb < QPW; ++qb) {
+        auto probs = [&](const float delta) -> float {
+          float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float p0 = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j] - delta);
+              const float p1 = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1] - delta);
+              pk[j] = pack2<T>(p0, p1);
+              if (j & 1) ps1 = T::sum2(pk[j], ps1); else ps0 = T::sum2(pk[j], ps0);
+            }
+            pf[qb][ks] = as_vec8<T>(pk);
+          }
+          return ps0 + ps1;
+        };
+        float psum = 0.f;
+        bool redo = first_tile;
+        if (!first_tile) {
+          psum = probs(0.f);
+          redo = __any(psum >= AT_REBASE_SUM);
+        }
+        if (redo) {
+          float mx = s[qb][0][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float target = m_run[qb] + (first_tile ? mx : fmaxf(mx, 0.f));
+          const float nh = from_lp<T>(to_lp<T>(target));
+          const float nl = from_lp<T>(to_lp<T>(target - nh));
+          const float delta = (nh + nl) - m_run[qb];
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] = nh + nl;
+          if (g == 0) mfrag[qb][0] = pack2<T>(-nh, -nl);
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            o[qb][0][i] *= alpha;
+            o[qb][1][i] *= alpha;
+          }
+          psum = probs(delta);
+        }
+        l_run[qb] += psum;
+      }
+      first_tile = false;
+    } else if (MX) {
+#pragma unroll
+      for (int qb = 0; qb < QPW; ++qb) {
+        float m0 = fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), s[qb][0][2]);
+        float m1 = fmaxf(fmaxf(s[qb][0][8], s[qb][0][9]), s[qb][0][10]);
+        float m2 = fmaxf(fmaxf(s[qb][1][0], s[qb][1][1]), s[qb][1][2]);
+        float m3 = fmaxf(fmaxf(s[qb][1][8], s[qb][1][9]), s[qb][1][10]);
+#pragma unroll
+        for (int r = 3; r < 7; r += 2) {
+          m0 = fmaxf(fmaxf(m0, s[qb][0][r]), s[qb][0][r + 1]);
+          m1 = fmaxf(fmaxf(m1, s[qb][0][8 + r]), s[qb][0][8 + r + 1]);
+          m2 = fmaxf(fmaxf(m2, s[qb][1][r]), s[qb][1][r + 1]);
+          m3 = fmaxf(fmaxf(m3, s[qb][1][8 + r]), s[qb][1][8 + r + 1]);
+        }
+        m0 = fmaxf(fmaxf(m0, s[qb][0][7]), m1);
+        m2 = fmaxf(fmaxf(m2, s[qb][1][7]), m3);
+        float mx = fmaxf(fmaxf(m0, s[qb][0][15]), fmaxf(m2, s[qb][1][15]));  // max of s' = max score - (mh + ml)
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (first_tile || __any(mx > 0.f)) {  // wave-uniform and rare after the first tiles: move the reference max
+          const float target = m_run[qb] + (first_tile ? mx : fmaxf(mx, 0.f));
+          const float nh = from_lp<T>(to_lp<T>(target));
+          const float nl = from_lp<T>(to_lp<T>(target - nh));
+          const float delta = (nh + nl) - m_run[qb];  // what the reference really moved by
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] = nh + nl;  // exact: the sum of two operand-type numbers (this is also what a state_out epilogue stores)
+          if (g == 0) mfrag[qb][0] = pack2<T>(-nh, -nl);
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            s[qb][0][i] -= delta;
+            s[qb][1][i] -= delta;
+            o[qb][0][i] *= alpha;
+            o[qb][1][i] *= alpha;
+          }
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          u32x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p0 = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j]);
+            const float p1 = __builtin_amdgcn_exp2f(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1]);
+            pk[j] = pack2<T>(p0, p1);
+            if (j & 1) ps1 = T::sum2(pk[j], ps1); else ps0 = T::sum2(pk[j], ps0);
+          }
+          pf[qb][ks] = as_vec8<T>(pk);
+        }
+        l_run[qb] += ps0 + ps1;
+      }
+      first_tile = false;
     } else
 #pragma unroll
     for (int qb = 0; qb < QPW; ++qb) {
@@ -287,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       const float m_new = fmaxf(m_run[qb], mx);
       const bool moved = m_new > m_run[qb];
       const float mc = m_new * c;
-      float psum = 0.f;
+      float psum = 0.f, psum2 = 0.f;
       if (OPT & 16) {
         typedef float float2v __attribute__((ext_vector_type(2)));
         const float2v c2 = {c, c}, nmc2 = {-mc, -mc};
@@ -317,11 +481,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
         for (int j = 0; j < 4; ++j) {
           const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j], c, -mc));
           const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][ks >> 1][(ks & 1) * 8 + 2 * j + 1], c, -mc));
-          psum += p0 + p1;
           pk[j] = pack2<T>(p0, p1);
+          if (OPT & 256) {
+            if (j & 1) psum2 = T::sum2(pk[j], psum2); else psum = T::sum2(pk[j], psum);
+          } else {
+            psum += p0 + p1;
+          }
         }
         pf[qb][ks] = as_vec8<T>(pk);
       }
+      psum += psum2;
       }
       if (!(OPT & 1) || __any(moved)) {
         const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
@@ -436,6 +605,12 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
     case 25: return attn_launch<T, 8, 2, 1, 2>(a, s);  // 8 waves x 64 q (512 q / workgroup, 1 workgroup / CU)
     case 26: return attn_launch<T, 8, 2, 3, 2>(a, s);  // same + setprio
+    case 51: return attn_launch<T, 4, 2, 769, 2>(a, s);  // 49 + running max through a fifth MFMA k-step
+    case 52: return attn_launch<T, 8, 2, 769, 2>(a, s);  // 50 + the same
+    case 53: return attn_launch<T, 4, 2, 1793, 2>(a, s);  // 51 + lazy reference max (row-sum trigger)
+    case 54: return attn_launch<T, 8, 2, 1793, 2>(a, s);  // 52 + the same
+    case 49: return attn_launch<T, 4, 2, 257, 2>(a, s);  // 24 + dot2 row sums + pointer-increment staging
+    case 50: return attn_launch<T, 8, 2, 257, 2>(a, s);  // 25 + the same
     case 45: return attn_launch<T, 8, 2, 129, 2>(a, s);  // 25 + static priority for the younger half
     case 46: return attn_launch<T, 8, 2, 193, 2>(a, s);  // 43 (DMA) + static priority
     case 47: return attn_launch<T, 8, 1, 129, 2>(a, s);  // 8 waves x 32 q + static priority
@@ -471,15 +646,21 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
   }
 }
 
-constexpr int AT_DEFAULT_VARIANT = 24;
+// Product default (variant "auto"): the lazy-reference body, 4 waves / 256 queries per workgroup, or 8 waves / 512 queries
+// once the key stream is long enough that halving the K / V^T staging traffic per query wins (measured crossover between
+// 102 400 and 327 680 keys: 1079 vs 1040 TF/s at 102 400, 1072 vs 1089 at 327 680).  Both share one state layout.
+constexpr int AT_AUTO = -2;
+constexpr int64_t AT_LONG_KEYS = 196608;
 
-int g_variant = -1;
+int g_variant = -1;  // -1: not initialised yet
 
-int attn_variant() {
-  if (g_variant < 0) {
+int attn_variant(int64_t total_keys) {
+  if (g_variant == -1) {
     const char* e = getenv("F3R_ATTN_VARIANT");
-    g_variant = e ? atoi(e) : AT_DEFAULT_VARIANT;
+    g_variant = e ? atoi(e) : AT_AUTO;
+    if (g_variant < 0) g_variant = AT_AUTO;
   }
+  if (g_variant == AT_AUTO) return total_keys >= AT_LONG_KEYS ? 54 : 53;
   return g_variant;
 }
 
@@ -490,11 +671,11 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 48) {
+  if (variant < -1 || variant > 54) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
-  g_variant = variant < 0 ? AT_DEFAULT_VARIANT : variant;
+  g_variant = variant < 0 ? AT_AUTO : variant;
   return F3R_OK;
 }
 
@@ -526,7 +707,8 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   }
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
-  int variant = attn_variant();
-  if ((a.state_in || a.state_out) && !(variant == 24 || variant == 25 || variant == 3 || variant == 5 || variant == 0)) variant = AT_DEFAULT_VARIANT;  // only the product body carries state
+  int variant = attn_variant(total);
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 54);
+  if ((a.state_in || a.state_out) && !product_body) variant = 53;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

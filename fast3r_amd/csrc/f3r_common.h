@@ -6,12 +6,12 @@
 
 #include "../../include/f3r.h"
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct F16 {
   typedef _Float16 elem;
@@ -23,6 +23,17 @@ struct F16 {
   static __device__ __forceinline__ float16v mfma32(vec8 a, vec8 b, float16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  // 32 x 32 x 8 MFMA (2-register operands; lane (row, g = l >> 5) supplies k = 4 g .. 4 g + 3): used for a 2-slot bias step
+  static __device__ __forceinline__ float16v mfma32k8(u32x2 a, u32x2 b, float16v c) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(h4, a), __builtin_bit_cast(h4, b), c, 0, 0, 0);
+  }
+  // acc + lo(pk) + hi(pk): one v_dot2c_f32_f16 against (1, 1)
+  static __device__ __forceinline__ float sum2(uint32_t pk, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pk), ones, acc, false);
+  }
 };
 struct BF16 {
   typedef __bf16 elem;
@@ -33,6 +44,15 @@ struct BF16 {
   }
   static __device__ __forceinline__ float16v mfma32(vec8 a, vec8 b, float16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float16v mfma32k8(u32x2 a, u32x2 b, float16v c) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float sum2(uint32_t pk, float acc) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, pk), ones, acc, false);
   }
 };
 

@@ -275,6 +275,36 @@ def test_attention_online_softmax_rescale_is_forced(built_lib, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pattern", ["drift_up", "stairs", "outlier_first", "all_equal"])
+def test_attention_lazy_reference_patterns(built_lib, dt, pattern):
+    """The product kernel keeps a LAZY softmax reference (no per-tile max; it re-bases when a tile's row sum says P has
+    grown): score sequences built to sit on that trigger.  Keys are multiples of one direction u, queries too, so the
+    score of (query i, key j) is a_i * b_j * |u|^2 * scale and each pattern is a choice of b over the 10 key tiles."""
+    T, H, scale = 640, 1, 0.125
+    g = torch.Generator().manual_seed(90)
+    u = torch.randn(64, generator=g)
+    u = u / u.norm()
+    a = torch.linspace(0.5, 8.0, T)  # per-query gain (incl. rows whose logits span > 60 in exp2 units)
+    tile = torch.arange(T) // 64
+    if pattern == "drift_up":      # every tile a little above the previous one: many small re-bases / rows riding below the trigger
+        b = 0.35 * tile.float() + 0.01 * torch.randn(T, generator=g)
+    elif pattern == "stairs":      # long plateaus, two big jumps (one inside a tile)
+        b = torch.where(torch.arange(T) < 200, 0.0, torch.where(torch.arange(T) < 500, 6.0, 15.0)) + 0.05 * torch.randn(T, generator=g)
+    elif pattern == "outlier_first":  # the maximum is key 3; everything later is far below it (P underflows to 0 in both)
+        b = -4.0 + 0.5 * torch.randn(T, generator=g)
+        b[3] = 12.0
+    else:                          # identical scores: every P equals 1 against an exact reference, row sum 32 per lane and tile
+        b = torch.full((T,), 1.5)
+    q = (a[:, None] * u[None, :] * 8.0).to(dt)
+    k = (b[:, None] * u[None, :]).to(dt)
+    v = rnd((T, 64), dt, 91)
+    o = torch.empty((T, 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, scale, [(k.to(DEV), _vt_of(v, H).to(DEV), T, 0, 0)])
+    assert torch.isfinite(o.float()).all()
+    assert_close(o.float(), _attn_ref(q, k, v, H, scale), 2 * lp_tol(dt), f"lazy reference {pattern}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_attention_state_carried_across_launches(built_lib, dt):
     """Launch 1 over the local segment parks (m, l, O); launch 2 resumes over the remote segments: must equal ONE launch
     over [local, remote...] bit for bit (same tiles in the same order, state kept in fp32), and the fp64 reference."""
