@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];  // [buf][K | Vt][64][64] = 32 KB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wid = tid >> 6;
+  const int wid = (OPT & 64) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);  // scalar for the DMA path's M0 / block math
   const int lq = lane & 31;
   const int g = lane >> 5;
 
@@ -173,32 +173,56 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     if (key_ld >= seg_keys) next_segment();
     return true;
   };
-  // DMA form of load_next + store_tile: every wave-instruction fills 8 rows x 128 B of the K (resp. V^T) image of `buf`
+  // DMA form of load_next + store_tile (OPT bit 6): every wave-instruction fills 8 rows x 128 B of the K (resp. V^T) image
+  // of `buf` straight from HBM/L2 (global_load_lds): no staging registers, no ds_write pass.  Addressing is a wave-uniform
+  // tile base (scalar pointer, advanced per tile on the SALU) plus a lane-constant 32-bit byte offset, so the per-tile cost
+  // is the DMA instructions themselves; only the ragged last tile of a segment recomputes its K offsets (row clamp).
   constexpr bool DMA = (OPT & 64) != 0;
-  constexpr int DPW = 8 / NW;  // DMA instructions per wave and per tile (8 x 1 KB = one 8 KB tile)
+  constexpr int DPW = NW >= 8 ? 1 : 8 / NW;  // DMA instructions per wave and per tile (8 x 1 KB = one 8 KB tile; DMA bodies use NW <= 8)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int d_lrow = lane >> 3;
+  uint32_t dk_off[DPW], dv_off[DPW], d_lch[DPW];
+  const char* dKb = nullptr;  // wave-uniform: first K row of the next tile, this head
+  const char* dVb = nullptr;  // wave-uniform: V^T row head * 64, first key of the next tile
+  auto dma_segment = [&]() {  // after next_segment(): bases and per-lane offsets of the new segment
+    if (seg_keys == 0) return;
+    dKb = (const char*)((const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64);
+    dVb = (const char*)((const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt);
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int row = (wid * DPW + i) * 8 + d_lrow;
+      d_lch[i] = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+      dk_off[i] = (uint32_t)row * (uint32_t)p.ldk * 2u + d_lch[i];
+      dv_off[i] = (uint32_t)row * (uint32_t)seg_ldvt * 2u + d_lch[i];
+    }
+  };
+  if (DMA) dma_segment();
   auto dma_next = [&](int buf) -> bool {
     if (seg_keys == 0) return false;
     const int64_t rem = seg_keys - key_ld;
     valid_ld = rem < AT_KB ? (int)rem : AT_KB;
     uint16_t* kt = lds + buf * 2 * AT_TILE;
     uint16_t* vt = kt + AT_TILE;
-    const int lrow = lane >> 3, pch = lane & 7;
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int blk = wid * DPW + i;  // 8-row block of the tile (wave-uniform)
-      const int row = blk * 8 + lrow;
-      const int lch = pch ^ ((row >> 1) & 7);
-      const int krow = row < valid_ld ? row : valid_ld - 1;  // rows past the segment end are masked in the softmax
-      // Kg / Vg carry the staging thread's own (sch * 8) offset: take it out again, this path addresses by lane
-      const uint16_t* ks = Kg - sch * 8 + (key_ld + krow) * p.ldk + lch * 8;
-      const uint16_t* vs = Vg - sch * 8 + (int64_t)row * seg_ldvt + key_ld + lch * 8;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)ks, (lds_ptr_t)(kt + blk * 8 * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)vs, (lds_ptr_t)(vt + blk * 8 * 64), 16, 0, 0);
+      uint32_t ko = dk_off[i];
+      if (valid_ld < AT_KB) {  // rows past the segment end: re-read the last valid row (masked in the softmax)
+        const int row = blk * 8 + d_lrow;
+        const int krow = row < valid_ld ? row : valid_ld - 1;
+        ko = (uint32_t)krow * (uint32_t)p.ldk * 2u + d_lch[i];
+      }
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dKb + ko), (lds_ptr_t)(kt + blk * 8 * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dVb + dv_off[i]), (lds_ptr_t)(vt + blk * 8 * 64), 16, 0, 0);
     }
+    dKb += kstep * 2;
+    dVb += AT_KB * 2;
     key_ld += AT_KB;
-    if (key_ld >= seg_keys) next_segment();
+    if (key_ld >= seg_keys) {
+      next_segment();
+      dma_segment();
+    }
     return true;
   };
   auto store_tile = [&](int buf) {
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
   }
   unsigned long long tq_ = 0, ts_ = 0, tp_ = 0, tb_ = 0, nt_ = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const unsigned long long t_loop0 = (OPT & 32) ? __builtin_readcyclecounter() : 0ull;
   while (have) {
     const int valid = valid_cur;
     const bool more = DMA ? dma_next(cur ^ 1) : load_next();  // DMA: buffer cur^1 was released by the barrier that ended iteration t-1
@@ -308,18 +333,33 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
         for (int qb = 0; qb < QPW; ++qb) s[qb][kb] = T::mfma32(a, qf[qb][ds], s[qb][kb]);
       }
     }
+    if (OPT & 2048) {
+      // OPT bit 11: pin the K-fragment reads two steps ahead of the MFMAs that consume them.  Left alone, the scheduler
+      // keeps ONE fragment register quad here (read, lgkmcnt(0), 2 MFMAs, read, ...): ~100 cycles of LDS latency per
+      // 64 cycles of MFMA work, which only the other wave of the SIMD can fill.
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if (MX) __builtin_amdgcn_sched_group_barrier(0x008, QPW, 0);  // bias steps (one per query block after CSE)
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        if (st + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, QPW, 0);
+      }
+    }
     if (OPT & 2) __builtin_amdgcn_s_setprio(0);
     if (OPT & 32) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[QPW - 1][1][15])); c1 = __builtin_readcyclecounter(); }
     // register r of block kb is key  kb*32 + 16*(r>>3) + 8*g + (r&7)  of the tile
     if (valid < AT_KB) {
+      // compare compile-time key indices against one lane value (valid - 8 g): nothing loop-invariant for the compiler to
+      // hoist into 30 registers held across the whole loop for the sake of this once-per-segment block
+      const int vg = valid - 8 * g;
 #pragma unroll
       for (int qb = 0; qb < QPW; ++qb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + 16 * (r >> 3) + 8 * g + (r & 7);
-            if (key >= valid) s[qb][kb][r] = -1e30f;
+            const int kc = kb * 32 + 16 * (r >> 3) + (r & 7);
+            if (kc >= vg) s[qb][kb][r] = -1e30f;
           }
     }
     // ---- online softmax (fp32)
@@ -529,6 +569,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   }
   if ((OPT & 32) && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
     g_attn_prof[0] = tq_; g_attn_prof[1] = ts_; g_attn_prof[2] = tp_; g_attn_prof[3] = tb_; g_attn_prof[4] = nt_;
+    g_attn_prof[5] = __builtin_readcyclecounter() - t_loop0;  // whole loop (the rest = issuing the next tile's loads)
   }
 
   // ---- epilogue: either hand the state to the next launch ...
@@ -609,6 +650,14 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 52: return attn_launch<T, 8, 2, 769, 2>(a, s);  // 50 + the same
     case 53: return attn_launch<T, 4, 2, 1793, 2>(a, s);  // 51 + lazy reference max (row-sum trigger)
     case 54: return attn_launch<T, 8, 2, 1793, 2>(a, s);  // 52 + the same
+    case 55: return attn_launch<T, 4, 2, 1857, 2>(a, s);  // 53 + LDS-DMA staging (scalar tile base + lane-constant offsets)
+    case 56: return attn_launch<T, 8, 2, 1857, 2>(a, s);  // 54 + the same
+    case 57: return attn_launch<T, 4, 2, 3905, 2>(a, s);  // 55 + K-fragment reads pinned two steps ahead
+    case 58: return attn_launch<T, 8, 2, 3905, 2>(a, s);  // 56 + the same
+    case 59: return attn_launch<T, 4, 2, 3841, 2>(a, s);  // 53 + the same
+    case 60: return attn_launch<T, 8, 2, 3841, 2>(a, s);  // 54 + the same
+    case 61: return attn_launch<T, 4, 2, 1889, 2>(a, s);  // 55 + per-section s_memtime instrumentation
+    case 62: return attn_launch<T, 8, 2, 1889, 2>(a, s);  // 56 + the same
     case 49: return attn_launch<T, 4, 2, 257, 2>(a, s);  // 24 + dot2 row sums + pointer-increment staging
     case 50: return attn_launch<T, 8, 2, 257, 2>(a, s);  // 25 + the same
     case 45: return attn_launch<T, 8, 2, 129, 2>(a, s);  // 25 + static priority for the younger half
@@ -646,11 +695,10 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
   }
 }
 
-// Product default (variant "auto"): the lazy-reference body, 4 waves / 256 queries per workgroup, or 8 waves / 512 queries
-// once the key stream is long enough that halving the K / V^T staging traffic per query wins (measured crossover between
-// 102 400 and 327 680 keys: 1079 vs 1040 TF/s at 102 400, 1072 vs 1089 at 327 680).  Both share one state layout.
+// Product default (variant "auto"): the lazy-reference body with LDS-DMA staging, 4 waves / 256 queries per workgroup
+// (variant 55; on one box: 1.18x variant 24 at 102 400 and at 327 680 keys, the 8-wave form 56 is 1-4 % behind at both).
 constexpr int AT_AUTO = -2;
-constexpr int64_t AT_LONG_KEYS = 196608;
+constexpr int AT_PRODUCT = 55;
 
 int g_variant = -1;  // -1: not initialised yet
 
@@ -660,7 +708,8 @@ int attn_variant(int64_t total_keys) {
     g_variant = e ? atoi(e) : AT_AUTO;
     if (g_variant < 0) g_variant = AT_AUTO;
   }
-  if (g_variant == AT_AUTO) return total_keys >= AT_LONG_KEYS ? 54 : 53;
+  (void)total_keys;
+  if (g_variant == AT_AUTO) return AT_PRODUCT;
   return g_variant;
 }
 
@@ -671,7 +720,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 54) {
+  if (variant < -1 || variant > 62) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
@@ -708,7 +757,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   int variant = attn_variant(total);
-  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 54);
-  if ((a.state_in || a.state_out) && !product_body) variant = 53;  // only the product body carries state
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 62);
+  if ((a.state_in || a.state_out) && !product_body) variant = AT_PRODUCT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

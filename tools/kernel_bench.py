@@ -61,7 +61,7 @@ def bench_attn(dt, views, variants, H=16):
         print(json.dumps({"kernel": "attn", "dtype": str(dt).split(".")[-1], "views": views, "T": T, "variant": v, "ms": round(ms, 3),
                           "tflops": round(flops / ms / 1e9, 1)}), flush=True)
     for v in variants:
-        if v in (34, 35, 38, 44):
+        if v in (34, 35, 38, 44, 61, 62):
             import ctypes
             fns[v]()
             torch.cuda.synchronize()
@@ -69,7 +69,8 @@ def bench_attn(dt, views, variants, H=16):
             _lib.lib().f3r_attn_read_prof(buf)
             n = max(1, buf[4])
             print(json.dumps({"kernel": "attn_sections", "variant": v, "tiles": int(buf[4]), "cycles_per_tile": {
-                "qk": round(buf[0] / n), "softmax": round(buf[1] / n), "pv": round(buf[2] / n), "stage+barrier": round(buf[3] / n)}}), flush=True)
+                "qk": round(buf[0] / n), "softmax": round(buf[1] / n), "pv": round(buf[2] / n), "stage+barrier": round(buf[3] / n),
+                "whole_loop": round(buf[5] / n)}}), flush=True)
     _lib.lib().f3r_attn_set_variant(-1)
 
 
