@@ -612,6 +612,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   }
 }
 
+#include "f3r_attn_xp.h"   // software-pipelined body (half-tile stages, pinned issue order)
 #include "f3r_attn_lab.h"  // experimental bodies (v2 / v3 / v4 / ping-pong): measured, correct, slower -- see DESIGN.md section 6
 
 template <class T, int NW, int QPW, int OPT, int MINW>
@@ -658,6 +659,10 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 60: return attn_launch<T, 8, 2, 3841, 2>(a, s);  // 54 + the same
     case 61: return attn_launch<T, 4, 2, 1889, 2>(a, s);  // 55 + per-section s_memtime instrumentation
     case 62: return attn_launch<T, 8, 2, 1889, 2>(a, s);  // 56 + the same
+    case 63: return attn_launch_xp<T, 4, 0, 2>(a, s);  // xp: P V(h-1) / Q K^T(h+1) MFMAs with the softmax of half h in their shadows
+    case 64: return attn_launch_xp<T, 4, 1, 2>(a, s);  // 63 + loop timing
+    case 65: return attn_launch_xp<T, 4, 0, 1>(a, s);  // xp with one wave per SIMD (512 registers, no spills)
+    case 66: return attn_launch_xp<T, 4, 1, 1>(a, s);  // 65 + loop timing
     case 49: return attn_launch<T, 4, 2, 257, 2>(a, s);  // 24 + dot2 row sums + pointer-increment staging
     case 50: return attn_launch<T, 8, 2, 257, 2>(a, s);  // 25 + the same
     case 45: return attn_launch<T, 8, 2, 129, 2>(a, s);  // 25 + static priority for the younger half
@@ -720,7 +725,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 62) {
+  if (variant < -1 || variant > 66) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
@@ -757,7 +762,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   int variant = attn_variant(total);
-  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 62);
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 66);
   if ((a.state_in || a.state_out) && !product_body) variant = AT_PRODUCT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

@@ -80,6 +80,36 @@ __device__ void run_role(float* out, uint64_t* cyc, int slot, const uint32_t* ld
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  } else if (ROLE == 9) {  // the xp slot mix with independent operands: MFMA, cvt_pk, exp, exp, dot2 (x F)
+    float d0 = 0.f, d1 = 0.f;
+    for (int s = 0; s < STEPS / 4; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa), __builtin_bit_cast(bf8, fb), acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(fb[(j + i) & 1 ? 2 : 3]) : "v"(a[4]), "v"(a[5]));
+          asm volatile("v_exp_f32 %0, %1" : "=v"(a[(2 * j) & 3]) : "v"(a[6]));
+          asm volatile("v_exp_f32 %0, %1" : "=v"(a[(2 * j + 1) & 3]) : "v"(a[7]));
+          asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"((j + i) & 1 ? d0 : d1) : "v"(fa[1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    a[0] += d0 + d1;
+  } else if (ROLE == 10) {  // single-instruction streams: F = 0 cvt_pk_bf16, 1 dot2c, 2 v_xor, 3 v_lshl_or, 4 ds_read_b128 (no wait)
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < STEPS / 8; ++s) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (F == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(fb[i & 3]) : "v"(a[i & 7]), "v"(a[(i + 1) & 7]));
+        if (F == 1) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(d[i & 3]) : "v"(fa[i & 3]));
+        if (F == 2) asm volatile("v_xor_b32 %0, 48, %1" : "=v"(fb[i & 3]) : "v"(fa[i & 3]));
+        if (F == 3) asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(fb[i & 3]) : "v"(fa[i & 3]), "s"(s));
+      }
+    }
+    a[0] += d[0] + d[1] + d[2] + d[3];
   } else if (ROLE == 5) {
     for (int s = 0; s < STEPS / 2; ++s) {
       const u32x4 r = *(const volatile u32x4*)(lds + ((lane * 4 + s * 64) & 4095));
@@ -173,6 +203,13 @@ int main() {
   go<8, 8, 2>("two waves: MFMA + 2 x (2 exp, cvt_pk, dot2)", out, cyc, S, S);
   go<7, 7, 2>("two waves: MFMA + 2 v_exp", out, cyc, S, S);
   go<4, 7, 2>("MFMA + 2 v_fma (slot0) || MFMA + 2 v_exp (slot1)", out, cyc, S, S);
+  go<10, 0, 0>("v_cvt_pk_bf16_f32 stream alone", out, cyc, S, 1);
+  go<10, 0, 1>("v_dot2c_f32_bf16 stream alone", out, cyc, S, 1);
+  go<10, 0, 2>("v_xor_b32 stream alone", out, cyc, S, 1);
+  go<10, 0, 3>("v_lshl_or_b32 stream alone", out, cyc, S, 1);
+  go<9, 0, 1>("one wave: MFMA + (cvt, exp, exp, dot2) independent", out, cyc, S, 1);
+  go<9, 9, 1>("two waves: MFMA + (cvt, exp, exp, dot2) independent", out, cyc, S, S);
+  go<9, 0, 2>("one wave: MFMA + 2 x (cvt, exp, exp, dot2) independent", out, cyc, S, 1);
   go<5, 0, 0>("one wave: ds_read -> wait -> 2 MFMA (per 2-MFMA step)", out, cyc, S / 2, 1);
   go<6, 0, 0>("one wave: same, reads 2 steps ahead", out, cyc, S / 2, 1);
   go<5, 5, 0>("two waves: ds_read -> wait -> 2 MFMA", out, cyc, S / 2, S / 2);
