@@ -137,7 +137,8 @@ def main():
                        "operands": f"{args.dtype} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax"},
             "roofline": {"bound": "mfma", "kernel": "attn_kernel (fusion self-attention, one launch per fusion layer per rank)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "flops_per_launch": big, "avg_launch_ms": avg_ms, "launches_timed": len(fus), "traffic": load_traffic(V, world)},
+                         "flops_per_launch": big, "avg_launch_ms": avg_ms, "launches_timed": len(fus), "traffic": load_traffic(V, world),
+                         "pmc": load_pmc()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, enc, dec, head, args.cpu_views)
@@ -172,6 +173,17 @@ def load_traffic(V, world):
     try:
         d = json.load(open(path))
         return d.get(f"views={V},gpus={world}")
+    except Exception:
+        return None
+
+
+def load_pmc():
+    """Matrix-pipe utilisation in cycles + effective clock of the same kernel from the committed rocprofv3 PMC pass
+    (profiles/r01_attn_mfma_util_v55.json, tools/pmc_mfma_util.sh): `frac` above is this times clock / 2.4 GHz."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_mfma_util_v55.json")))
+        return {"mfma_util_cycles": d["mfma_util_cycles"], "mfma_util_useful_cycles": d["mfma_util_useful_cycles"],
+                "effective_clock_ghz": d["effective_clock_ghz"], "shape": "T=%d" % (1024 * d["views"])}
     except Exception:
         return None
 

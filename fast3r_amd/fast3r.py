@@ -246,6 +246,54 @@ def _pack_head(head: PixelwiseTaskWithDPT, lp):
 
 
 # ======================================================================================= the model
+class _GraphCache:
+    """Captured forwards by scene shape (see Fast3R.enable_graphs)."""
+
+    def __init__(self):
+        self.max_views = 64
+        self.entries = {}
+        self.seen = set()
+
+    def clear(self):
+        self.entries.clear()
+        self.seen.clear()
+
+    def run(self, model, views):
+        imgs = [v["img"] for v in views]
+        dev = imgs[0].device
+        shapes = {tuple(i.shape) for i in imgs}
+        if len(views) > self.max_views or len(shapes) != 1 or any(i.dtype != torch.float32 for i in imgs):
+            return None
+        for v in views:  # the eager path's argument check (utils/misc.py:69), done on the host before replay
+            ts = v.get("true_shape", None)
+            if ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
+                raise AssertionError("true_shape must be all identical")
+        key = (len(views), tuple(imgs[0].shape), str(dev), model.compute_dtype, model.max_parallel_views_for_head, model.training)
+        dec = model.decoder
+        B = imgs[0].shape[0]
+        if key not in self.entries:
+            if key not in self.seen:  # first sight of a shape: plain eager forward (also warms the packed weights / RoPE tables)
+                self.seen.add(key)
+                return None
+            static_imgs = [torch.empty_like(i) for i in imgs]
+            static_emb = torch.zeros((B, len(views), dec.embed_dim), dtype=torch.float32, device=dev)
+            static_views = [{"img": t} for t in static_imgs]
+            for t, i in zip(static_imgs, imgs):
+                t.copy_(i)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                outs = model._forward_eager(static_views, False, _emb_rows=static_emb)
+            self.entries[key] = (graph, static_imgs, static_emb, outs)
+        graph, static_imgs, static_emb, outs = self.entries[key]
+        for t, i in zip(static_imgs, imgs):
+            t.copy_(i, non_blocking=True)
+        ids = dec.draw_image_ids(B, len(views))
+        static_emb.copy_(dec.image_idx_emb.to(dev)[ids.to(dev)])
+        graph.replay()
+        return [{k: v.clone() for k, v in r.items()} for r in outs]
+
+
 class Fast3R(nn.Module):
     def __init__(self, encoder_args: dict, decoder_args: dict, head_args: dict, freeze="none",
                  compute_dtype: torch.dtype = torch.float16):
@@ -261,6 +309,8 @@ class Fast3R(nn.Module):
         self.compute_dtype = compute_dtype
         self.sharding = None  # set by shard_views(): view-sharded multi-GPU execution (fast3r_amd/dist.py)
         self.debug_taps = None  # set to a dict to capture the lowp DPT inputs (hooks 0, L/2, 3L/4, L) per sample
+        self.use_graphs = False  # enable_graphs(): hipGraph replay of small scenes
+        self._graphs = _GraphCache()
         self._packed = None
         self._rope_cache = {}
         self.set_freeze(freeze)
@@ -338,15 +388,17 @@ class Fast3R(nn.Module):
 
     # ---------------------------------------------------------------- packed weights
     def load_state_dict(self, ckpt, **kw):
-        self._packed = None
+        self.invalidate_packed_weights()
         return super().load_state_dict(ckpt, **kw)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self.invalidate_packed_weights()
         return super()._apply(fn, *a, **k)
 
     def invalidate_packed_weights(self):
         self._packed = None
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs.clear()  # captured graphs hold pointers into the packed weights
 
     def _pack(self, device):
         lp = self.compute_dtype
@@ -486,6 +538,23 @@ class Fast3R(nn.Module):
         """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device."""
         if len(views) == 0:
             return ([], {}) if profiling else []
+        if self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None:
+            out = self._graphs.run(self, views)
+            if out is not None:
+                return out
+        return self._forward_eager(views, profiling)
+
+    def enable_graphs(self, on=True, max_views=64):
+        """Opt-in hipGraph replay for launch-bound scenes (a forward of N <= max_views same-size views is a chain of
+        ~400 + 30 N short launches; below N of about 20 the host cannot issue them as fast as the GPU retires them).  The
+        first forward of a new (N, B, H, W) shape runs eagerly once and is then captured; later forwards of that shape copy
+        the images into the captured input buffers, draw the image ids on the host exactly like the eager path and replay.
+        Same kernels, same order, same results."""
+        self.use_graphs = bool(on)
+        self._graphs.max_views = max_views
+        return self
+
+    def _forward_eager(self, views, profiling=False, _emb_rows=None):
         dev = views[0]["img"].device
         if dev.type != "cuda":
             raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (views are on {dev}); there is no CPU fallback")
@@ -506,7 +575,7 @@ class Fast3R(nn.Module):
         shapes = [tuple(v["img"].shape[-2:]) for v in views]
         for v in views:
             ts = v.get("true_shape", None)
-            if ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
+            if _emb_rows is None and ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
                 raise AssertionError("true_shape must be all identical")  # utils/misc.py:69
         same = all(s == shapes[0] for s in shapes)
         feats, Ps, grids = [], [], []
@@ -528,10 +597,13 @@ class Fast3R(nn.Module):
 
         # ---- image ids (fast3r.py:339-348 / 702-743): drawn once for all N views (rank 0 decides when sharded)
         t1 = time.time()
-        ids = dec.draw_image_ids(B, N_total)
-        if sh is not None:
-            ids = sh.broadcast_ids(ids, dev)
-        emb_rows = dec.image_idx_emb.to(dev)[ids.to(dev)]  # (B, N_total, D) fp32 rows of the table
+        if _emb_rows is not None:  # graph capture / replay: the rows sit in a captured buffer the caller fills before each replay
+            emb_rows = _emb_rows
+        else:
+            ids = dec.draw_image_ids(B, N_total)
+            if sh is not None:
+                ids = sh.broadcast_ids(ids, dev)
+            emb_rows = dec.image_idx_emb.to(dev)[ids.to(dev)]  # (B, N_total, D) fp32 rows of the table
         if profiling:
             prof["pos_emb_time"] = time.time() - t1
 
