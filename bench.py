@@ -179,9 +179,9 @@ def load_traffic(V, world):
 
 def load_pmc():
     """Matrix-pipe utilisation in cycles + effective clock of the same kernel from the committed rocprofv3 PMC pass
-    (profiles/r01_attn_mfma_util_v55.json, tools/pmc_mfma_util.sh): `frac` above is this times clock / 2.4 GHz."""
+    (profiles/r01_attn_mfma_util.json, tools/pmc_mfma_util.sh): `frac` above is this times clock / 2.4 GHz."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_mfma_util_v55.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_mfma_util.json")))
         return {"mfma_util_cycles": d["mfma_util_cycles"], "mfma_util_useful_cycles": d["mfma_util_useful_cycles"],
                 "effective_clock_ghz": d["effective_clock_ghz"], "shape": "T=%d" % (1024 * d["views"])}
     except Exception:

@@ -313,14 +313,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   const unsigned long long t_loop0 = (OPT & 32) ? __builtin_readcyclecounter() : 0ull;
   while (have) {
     const int valid = valid_cur;
-    const bool more = DMA ? dma_next(cur ^ 1) : load_next();  // DMA: buffer cur^1 was released by the barrier that ended iteration t-1
+    // OPT bits 13-14: WHERE in the iteration the next tile's DMA is issued (its issue cost depends on what else the phase is doing):
+    // 0 loop top, 1 after the Q K^T MFMAs, 2 between the two query blocks of the softmax, 3 after the softmax
+    constexpr int DMA_AT = DMA ? ((OPT >> 13) & 3) : 0;
+    constexpr int PRIO_HI = (OPT & 262144) ? 3 : 1;  // bit 18: priority 3 instead of 1
+    // bits 15 / 16: no s_setprio around the P V / Q K^T cluster (bit 1 set)
+    bool more = false;
+    if (DMA_AT == 0) more = DMA ? dma_next(cur ^ 1) : load_next();  // DMA: buffer cur^1 was released by the barrier that ended iteration t-1
     if (OPT & 32) c0 = __builtin_readcyclecounter();
     const uint16_t* kt = lds + cur * 2 * AT_TILE;
     const uint16_t* vt = kt + AT_TILE;
 
     // ---- S^T = K Q^T
     float16v s[QPW][2];
-    if (OPT & 2) __builtin_amdgcn_s_setprio(1);
+    if ((OPT & 2) && !(OPT & 65536)) __builtin_amdgcn_s_setprio(PRIO_HI);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
         __builtin_amdgcn_sched_group_barrier(0x008, QPW, 0);
       }
     }
-    if (OPT & 2) __builtin_amdgcn_s_setprio(0);
+    if ((OPT & 2) && !(OPT & 65536) && !(OPT & 131072)) __builtin_amdgcn_s_setprio(0);
     if (OPT & 32) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[QPW - 1][1][15])); c1 = __builtin_readcyclecounter(); }
     // register r of block kb is key  kb*32 + 16*(r>>3) + 8*g + (r&7)  of the tile
     if (valid < AT_KB) {
@@ -365,6 +371,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
             if (kc >= vg) s[qb][kb][r] = -1e30f;
           }
     }
+    if (DMA_AT == 1) more = dma_next(cur ^ 1);
+    if ((OPT & 2) && (OPT & 131072)) __builtin_amdgcn_s_setprio(0);  // bit 17: the DMA is issued before the priority drops
     // ---- online softmax (fp32)
     typename T::vec8 pf[QPW][4];
     if (OPT & 8) {
@@ -384,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
       // finds the true tile max, moves the reference there and recomputes P.  The first tile always takes it.
 #pragma unroll
       for (int qb = 0; qb < QPW; ++qb) {
+        if (DMA_AT == 2 && qb == QPW - 1) more = dma_next(cur ^ 1);
         auto probs = [&](const float delta) -> float {
           float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
@@ -547,8 +556,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     }
 
     if (OPT & 32) { asm volatile("" :: "v"(pf[0][0]), "v"(pf[QPW - 1][3])); c2 = __builtin_readcyclecounter(); }
+    if (DMA_AT == 3) more = dma_next(cur ^ 1);
     // ---- O^T += V^T P^T
-    if (OPT & 2) __builtin_amdgcn_s_setprio(1);
+    if ((OPT & 2) && !(OPT & 32768)) __builtin_amdgcn_s_setprio(PRIO_HI);
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
 #pragma unroll
         for (int qb = 0; qb < QPW; ++qb) o[qb][db] = T::mfma32(a, pf[qb][ks], o[qb][db]);
       }
-    if (OPT & 2) __builtin_amdgcn_s_setprio(0);
+    if ((OPT & 2) && !(OPT & 32768)) __builtin_amdgcn_s_setprio(0);
 
     if (OPT & 32) { asm volatile("" :: "v"(o[0][0][0]), "v"(o[QPW - 1][1][15])); c3 = __builtin_readcyclecounter(); }
     if (!DMA && more) store_tile(cur ^ 1);
@@ -658,6 +668,10 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
               // the batched (encoder, 1024 keys per sequence) launches their own kernel name, so that a rocprofv3 --stats line
               // of attn_kernel<.., 1857, ..> averages the fusion launches alone (the roofline kernel of bench.py)
       return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857, 2>(a, s);
+    case 71:  // 55 with the next tile's DMA issued after the Q K^T MFMAs (+1 %); same kernel-name split as 55
+      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192, 2>(a, s);
+    case 72:  // product: 71 + s_setprio 1 around both MFMA clusters (= variant 70 with the kernel-name split)
+      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 2 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);
     case 56: return attn_launch<T, 8, 2, 1857, 2>(a, s);  // 54 + the same
     case 57: return attn_launch<T, 4, 2, 3905, 2>(a, s);  // 55 + K-fragment reads pinned two steps ahead
     case 58: return attn_launch<T, 8, 2, 3905, 2>(a, s);  // 56 + the same
@@ -665,6 +679,18 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 60: return attn_launch<T, 8, 2, 3841, 2>(a, s);  // 54 + the same
     case 61: return attn_launch<T, 4, 2, 1889, 2>(a, s);  // 55 + per-section s_memtime instrumentation
     case 62: return attn_launch<T, 8, 2, 1889, 2>(a, s);  // 56 + the same
+    case 67: return attn_launch<T, 4, 2, 1857 + 8192, 2>(a, s);   // 55 with the DMA issued after the Q K^T MFMAs
+    case 68: return attn_launch<T, 4, 2, 1857 + 16384, 2>(a, s);  // ... between the two query blocks of the softmax
+    case 69: return attn_launch<T, 4, 2, 1857 + 24576, 2>(a, s);  // ... after the softmax
+    case 70: return attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);  // 67 + s_setprio around the MFMA clusters
+    case 73: return attn_launch<T, 4, 2, 1857 + 2, 2>(a, s);          // 55 + s_setprio (DMA at the loop top)
+    case 74: return attn_launch<T, 4, 2, 1857 + 16384 + 2, 2>(a, s);  // 68 + s_setprio (DMA between the softmax query blocks)
+    case 75: return attn_launch<T, 8, 2, 1857 + 8192 + 2, 2>(a, s);   // 8 waves, DMA after Q K^T, s_setprio
+    case 76: return attn_launch<T, 4, 2, 1857 + 24576 + 2, 2>(a, s);  // 69 + s_setprio (DMA after the softmax)
+    case 77: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 32768, 2>(a, s);   // 70 with s_setprio around Q K^T only
+    case 78: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 65536, 2>(a, s);   // 70 with s_setprio around P V only
+    case 79: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 131072, 2>(a, s);  // 70 with the DMA issued before the priority drops
+    case 80: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 262144, 2>(a, s);  // 70 with priority 3
     case 63: return attn_launch_xp<T, 4, 0, 2>(a, s);  // xp: P V(h-1) / Q K^T(h+1) MFMAs with the softmax of half h in their shadows
     case 64: return attn_launch_xp<T, 4, 1, 2>(a, s);  // 63 + loop timing
     case 65: return attn_launch_xp<T, 4, 0, 1>(a, s);  // xp with one wave per SIMD (512 registers, no spills)
@@ -707,9 +733,11 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
 }
 
 // Product default (variant "auto"): the lazy-reference body with LDS-DMA staging, 4 waves / 256 queries per workgroup
-// (variant 55; on one box: 1.18x variant 24 at 102 400 and at 327 680 keys, the 8-wave form 56 is 1-4 % behind at both).
+// (variant 55 = 1.18x variant 24 at 102 400 and at 327 680 keys, the 8-wave form 56 is 1-4 % behind at both; 71 = 55 with the
+// next tile's DMA issued after the Q K^T MFMAs instead of at the loop top, another +1 %; 72 = 71 + s_setprio 1 around the two
+// MFMA clusters, +4 % -- only in this combination: with the DMA at the loop top the same s_setprio costs 3 %).
 constexpr int AT_AUTO = -2;
-constexpr int AT_PRODUCT = 55;
+constexpr int AT_PRODUCT = 72;
 
 int g_variant = -1;  // -1: not initialised yet
 
@@ -731,7 +759,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 66) {
+  if (variant < -1 || variant > 80) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
@@ -768,7 +796,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   int variant = attn_variant(total);
-  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 66);
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 80);
   if ((a.state_in || a.state_out) && !product_body) variant = AT_PRODUCT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

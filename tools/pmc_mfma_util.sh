@@ -3,7 +3,7 @@
 #   GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (8 x the kernel's cycles; check: /8/duration = the sclk rocm-smi shows);
 #   MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs);  effective clock = GRBM_GUI_ACTIVE / 8 / duration
 # usage (GPU box): tools/pmc_mfma_util.sh [variant] [views]
-V=${1:-55}; VIEWS=${2:-100}
+V=${1:-72}; VIEWS=${2:-100}
 mkdir -p gpurun_out/pmcu
 export TMPDIR=/tmp
 CMD="python tools/kernel_bench.py --what attnonly --variants $V --views $VIEWS"

@@ -3,7 +3,7 @@
 VIEWS=${1:-320}
 mkdir -p gpurun_out/traffic
 export TMPDIR=/tmp
-CMD="python tools/kernel_bench.py --what attnonly --variants ${F3R_PMC_VARIANT:-55} --views $VIEWS"
+CMD="python tools/kernel_bench.py --what attnonly --variants ${F3R_PMC_VARIANT:-72} --views $VIEWS"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/traffic/f_$VIEWS --output-format csv -- $CMD > gpurun_out/traffic/f_$VIEWS.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/traffic/w_$VIEWS --output-format csv -- $CMD > gpurun_out/traffic/w_$VIEWS.log 2>&1
 python - <<PY
