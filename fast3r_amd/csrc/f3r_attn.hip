@@ -201,6 +201,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
     }
   };
   if (DMA) dma_segment();
+  uint32_t dv_off_v[DPW];
+  const char* dVb_v = nullptr;
+  auto dma_next_v = [&](int buf) {
+    uint16_t* vt = lds + buf * 2 * AT_TILE + AT_TILE;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dVb_v + dv_off_v[i]), (lds_ptr_t)(vt + (wid * DPW + i) * 8 * 64), 16, 0, 0);
+  };
   auto dma_next = [&](int buf) -> bool {
     if (seg_keys == 0) return false;
     const int64_t rem = seg_keys - key_ld;
@@ -217,8 +225,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
         ko = (uint32_t)krow * (uint32_t)p.ldk * 2u + d_lch[i];
       }
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(dKb + ko), (lds_ptr_t)(kt + blk * 8 * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(dVb + dv_off[i]), (lds_ptr_t)(vt + blk * 8 * 64), 16, 0, 0);
+      if (!(OPT & 524288)) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(dVb + dv_off[i]), (lds_ptr_t)(vt + blk * 8 * 64), 16, 0, 0);
+      } else {
+        dv_off_v[i] = dv_off[i];  // OPT bit 19: the V^T pieces of this tile are issued later in the iteration (dma_next_v)
+      }
     }
+    dVb_v = dVb;
     dKb += kstep * 2;
     dVb += AT_KB * 2;
     key_ld += AT_KB;
@@ -294,6 +307,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
 
   if (DMA) {
     dma_next(0);  // tile 0 always exists
+    if (OPT & 524288) dma_next_v(0);
   } else {
     load_next();
   }
@@ -557,6 +571,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
 
     if (OPT & 32) { asm volatile("" :: "v"(pf[0][0]), "v"(pf[QPW - 1][3])); c2 = __builtin_readcyclecounter(); }
     if (DMA_AT == 3) more = dma_next(cur ^ 1);
+    if (DMA && (OPT & 524288) && more) dma_next_v(cur ^ 1);
     // ---- O^T += V^T P^T
     if ((OPT & 2) && !(OPT & 32768)) __builtin_amdgcn_s_setprio(PRIO_HI);
 #pragma unroll
@@ -691,6 +706,8 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 78: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 65536, 2>(a, s);   // 70 with s_setprio around P V only
     case 79: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 131072, 2>(a, s);  // 70 with the DMA issued before the priority drops
     case 80: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 262144, 2>(a, s);  // 70 with priority 3
+    case 81: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 2048, 2>(a, s);    // 70 + K fragments pinned two steps ahead
+    case 82: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 524288, 2>(a, s);  // 70 with the V^T pieces issued after the softmax
     case 63: return attn_launch_xp<T, 4, 0, 2>(a, s);  // xp: P V(h-1) / Q K^T(h+1) MFMAs with the softmax of half h in their shadows
     case 64: return attn_launch_xp<T, 4, 1, 2>(a, s);  // 63 + loop timing
     case 65: return attn_launch_xp<T, 4, 0, 1>(a, s);  // xp with one wave per SIMD (512 registers, no spills)
@@ -759,7 +776,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 80) {
+  if (variant < -1 || variant > 82) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
@@ -796,7 +813,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   int variant = attn_variant(total);
-  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 80);
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 82);
   if ((a.state_in || a.state_out) && !product_body) variant = AT_PRODUCT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }
