@@ -708,6 +708,7 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 80: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 262144, 2>(a, s);  // 70 with priority 3
     case 81: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 2048, 2>(a, s);    // 70 + K fragments pinned two steps ahead
     case 82: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 524288, 2>(a, s);  // 70 with the V^T pieces issued after the softmax
+    case 84: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 32, 2>(a, s);  // 70 + per-section s_memtime instrumentation
     case 63: return attn_launch_xp<T, 4, 0, 2>(a, s);  // xp: P V(h-1) / Q K^T(h+1) MFMAs with the softmax of half h in their shadows
     case 64: return attn_launch_xp<T, 4, 1, 2>(a, s);  // 63 + loop timing
     case 65: return attn_launch_xp<T, 4, 0, 1>(a, s);  // xp with one wave per SIMD (512 registers, no spills)
@@ -776,7 +777,7 @@ extern "C" int f3r_attn_read_prof(unsigned long long* out8) {
 }
 
 extern "C" int f3r_attn_set_variant(int variant) {
-  if (variant < -1 || variant > 82) {
+  if (variant < -1 || variant > 84) {
     f3r_set_error("f3r_attn_set_variant: unknown variant %d", variant);
     return F3R_ERR_ARG;
   }
@@ -813,7 +814,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   int variant = attn_variant(total);
-  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 82);
+  const bool product_body = variant == 0 || variant == 3 || variant == 5 || variant == 24 || variant == 25 || (variant >= 49 && variant <= 84);
   if ((a.state_in || a.state_out) && !product_body) variant = AT_PRODUCT;  // only the product body carries state
   return a.dtype == F3R_F16 ? attn_dispatch<F16>(a, s, variant) : attn_dispatch<BF16>(a, s, variant);
 }

@@ -61,7 +61,7 @@ def bench_attn(dt, views, variants, H=16):
         print(json.dumps({"kernel": "attn", "dtype": str(dt).split(".")[-1], "views": views, "T": T, "variant": v, "ms": round(ms, 3),
                           "tflops": round(flops / ms / 1e9, 1)}), flush=True)
     for v in variants:
-        if v in (34, 35, 38, 44, 61, 62, 64, 66):
+        if v in (34, 35, 38, 44, 61, 62, 64, 66, 84):
             import ctypes
             fns[v]()
             torch.cuda.synchronize()
