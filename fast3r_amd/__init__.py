@@ -4,3 +4,4 @@ from .fast3r import Fast3R  # noqa: F401
 from .inference_multiview import inference  # noqa: F401
 from .multiview_dust3r_module import MultiViewDUSt3RLitModule  # noqa: F401
 from .align import align_local_pts3d_to_global  # noqa: F401
+from .focal import estimate_focal, estimate_focals  # noqa: F401

@@ -261,6 +261,117 @@ __global__ void align_thr_kernel(const double* __restrict__ ws, float* __restric
   if (i < n) o[i] = (float)ws[(int64_t)i * WS_PER + 34];
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Focal estimation (first half): estimate_focal, fast3r/models/multiview_dust3r_module.py:1081-1109,
+// = torch.quantile threshold on the confidence + the "weiszfeld" branch of estimate_focal_knowing_depth_and_confidence_mask,
+// fast3r/dust3r/post_process.py:77-142 (closed-form L2 start, then n_iter re-weighted least-squares steps).  One 1024-thread
+// workgroup per view: pass 0 writes (px, py, x/z, y/z) of the points above the threshold into the workspace (zeros elsewhere:
+// such a point weighs 1e8 on two zero terms), every iteration is then one pass over that 16-byte-per-pixel image (it stays in L2)
+// with fp32 per-point arithmetic in the reference's operation order (no fma contraction) and fp64 block sums.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double (*red)[2], double* out2) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if (lane == 0) { red[wv][0] = a; red[wv][1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < PNT / 64; ++w) { s0 += red[w][0]; s1 += red[w][1]; }
+    out2[0] = s0;
+    out2[1] = s1;
+  }
+  __syncthreads();
+  a = out2[0];
+  b = out2[1];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PNT) void focal_kernel(const float* __restrict__ pts, const float* __restrict__ conf, float4v* __restrict__ work,
+                                                    float* __restrict__ focal_out, float* __restrict__ thr_out, int H, int W, float q,
+                                                    float ppx, float ppy, int n_iter, float min_focal, float max_focal) {
+  __shared__ uint32_t hist[2048];
+  __shared__ int64_t sh_i64[2];
+  __shared__ double red[PNT / 64][2];
+  __shared__ double out2[2];
+  __shared__ float sh_thr;
+  const int64_t npix = (int64_t)H * W;
+  const int64_t prob = blockIdx.x;
+  const float* cf = conf + prob * npix;
+  const float* pt = pts + prob * npix * 3;
+  float4v* wk = work + prob * npix;
+
+  // ---- threshold = torch.quantile(conf, q) (linear interpolation, fp32 rank and at::lerp; as in align_stats_kernel)
+  const float rank = q * (float)(npix - 1);
+  const float rlo = floorf(rank);
+  const int64_t klo = (int64_t)rlo;
+  const int64_t khi = (int64_t)ceilf(rank);
+  const float vlo = fkey_inv(select_kth(cf, npix, klo, hist, sh_i64));
+  float vhi = vlo;
+  if (khi != klo) vhi = fkey_inv(select_kth(cf, npix, khi, hist, sh_i64));
+  if (threadIdx.x == 0) {
+    const float w = rank - rlo;
+    const float d = vhi - vlo;
+    sh_thr = (w < 0.5f) ? vlo + w * d : vhi - d * (1.0f - w);
+  }
+  __syncthreads();
+  const float thr = sh_thr;
+  if (threadIdx.x == 0 && thr_out) thr_out[prob] = thr;
+
+  // ---- pass 0: per-point terms + the closed-form start  focal = mean(dot_xy_px) / mean(dot_xy_xy)  (post_process.py:121-128)
+  double s_px = 0.0, s_xx = 0.0;
+  double cnt = 0.0, dummy = 0.0;
+  for (int64_t i = threadIdx.x; i < npix; i += PNT) {
+    float4v rec = {0.f, 0.f, 0.f, 0.f};
+    if (cf[i] >= thr) {
+      const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+      const float X = pt[i * 3 + 0], Y = pt[i * 3 + 1], Z = pt[i * 3 + 2];
+      float xz = __fdiv_rn(X, Z), yz = __fdiv_rn(Y, Z);
+      if (!(fabsf(xz) <= 3.402823466e38f)) xz = 0.f;  // nan_to_num(posinf=0, neginf=0): nan, +inf, -inf -> 0
+      if (!(fabsf(yz) <= 3.402823466e38f)) yz = 0.f;
+      const float px = (float)x - ppx, py = (float)y - ppy;
+      rec = float4v{px, py, xz, yz};
+      s_px += (double)__fadd_rn(__fmul_rn(xz, px), __fmul_rn(yz, py));
+      s_xx += (double)__fadd_rn(__fmul_rn(xz, xz), __fmul_rn(yz, yz));
+      cnt += 1.0;
+    }
+    wk[i] = rec;
+  }
+  block_sum2(s_px, s_xx, red, out2);
+  block_sum2(cnt, dummy, red, out2);
+  const float focal_base = (float)((H > W ? H : W) / (2.0 * 0.57735026918962576451));  // max(H, W) / (2 tan(30 deg))
+  if (cnt == 0.0) {  // post_process.py:102-105
+    if (threadIdx.x == 0) focal_out[prob] = focal_base;
+    return;
+  }
+  float focal = (float)(s_px / cnt) / (float)(s_xx / cnt);
+
+  // ---- iteratively re-weighted least squares (post_process.py:131-136)
+  for (int it = 0; it < n_iter; ++it) {
+    double num = 0.0, den = 0.0;
+    for (int64_t i = threadIdx.x; i < npix; i += PNT) {
+      const float4v r = wk[i];
+      const float dx = __fsub_rn(r[0], __fmul_rn(focal, r[2]));
+      const float dy = __fsub_rn(r[1], __fmul_rn(focal, r[3]));
+      const float dis = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      const float w = __fdiv_rn(1.0f, fmaxf(dis, 1e-8f));
+      const float dpx = __fadd_rn(__fmul_rn(r[2], r[0]), __fmul_rn(r[3], r[1]));
+      const float dxx = __fadd_rn(__fmul_rn(r[2], r[2]), __fmul_rn(r[3], r[3]));
+      num += (double)__fmul_rn(w, dpx);
+      den += (double)__fmul_rn(w, dxx);
+    }
+    block_sum2(num, den, red, out2);
+    focal = (float)num / (float)den;
+  }
+  if (threadIdx.x == 0) {
+    const float lo = min_focal * focal_base, hi = max_focal * focal_base;
+    focal_out[prob] = fminf(fmaxf(focal, lo), hi);  // post_process.py:140-142
+  }
+}
+
 }  // namespace
 
 extern "C" size_t f3r_align_workspace_bytes(int n_prob) { return (size_t)(n_prob > 0 ? n_prob : 0) * WS_PER * sizeof(double); }
@@ -281,4 +392,21 @@ extern "C" int f3r_align_local_to_global(const float* conf, const float* pts_loc
   hipLaunchKernelGGL(align_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pts_local, rts, out, npix, total);
   if (thr_out) hipLaunchKernelGGL(align_thr_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, s, ws, thr_out, n_prob);
   return f3r_check_launch("f3r_align_local_to_global");
+}
+
+extern "C" size_t f3r_focal_workspace_bytes(int n_views, int H, int W) {
+  return (n_views > 0 && H > 0 && W > 0) ? (size_t)n_views * (size_t)H * (size_t)W * 16u : 0u;
+}
+
+extern "C" int f3r_estimate_focal(const float* pts3d, const float* conf, float* focal, float* thr_out, void* workspace, size_t ws_bytes,
+                                  int n_views, int H, int W, float quantile, float ppx, float ppy, int n_iter, float min_focal,
+                                  float max_focal, f3r_stream_t stream) {
+  F3R_REQUIRE(pts3d && conf && focal && workspace, "f3r_estimate_focal: null pointer");
+  F3R_REQUIRE(n_views >= 0 && H > 0 && W > 0 && n_iter >= 0, "f3r_estimate_focal: bad sizes");
+  F3R_REQUIRE(quantile >= 0.f && quantile <= 1.f, "f3r_estimate_focal: quantile %f outside [0, 1]", (double)quantile);
+  F3R_REQUIRE(ws_bytes >= f3r_focal_workspace_bytes(n_views, H, W) && (((uintptr_t)workspace) & 15) == 0, "f3r_estimate_focal: workspace too small / misaligned");
+  if (n_views == 0) return F3R_OK;
+  hipLaunchKernelGGL(focal_kernel, dim3(n_views), dim3(PNT), 0, (hipStream_t)stream, pts3d, conf, (float4v*)workspace, focal, thr_out, H, W,
+                     quantile, ppx, ppy, n_iter, min_focal, max_focal);
+  return f3r_check_launch("f3r_estimate_focal");
 }

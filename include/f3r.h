@@ -217,6 +217,21 @@ int f3r_align_local_to_global(const float* conf, const float* pts_local, const f
                               float* out, float* rts, float* thr_out, void* workspace, size_t ws_bytes, int n_prob,
                               int64_t npix, float quantile, f3r_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f3r_estimate_focal: robust focal length of every view from its pointmap + confidence.
+ * Replaces estimate_focal (fast3r/models/multiview_dust3r_module.py:1081-1109): thr = torch.quantile(conf, quantile) (:1089-1093),
+ * mask = conf >= thr (:1096), then the "weiszfeld" branch of estimate_focal_knowing_depth_and_confidence_mask
+ * (fast3r/dust3r/post_process.py:77-142): closed-form start mean(xy/z . px) / mean(|xy/z|^2) (:121-128), n_iter re-weighted
+ * least-squares steps with weights 1 / max(|px - f xy/z|, 1e-8) (:131-136; the reference uses 100), clip to
+ * [min_focal, max_focal] x max(H, W) / (2 tan 30deg) (:140-142).  (ppx, ppy) is the principal point; the reference default is (W/2, H/2).
+ *   pts3d [n_views][H][W][3] fp32, conf [n_views][H][W] fp32, focal [n_views] fp32, thr_out [n_views] fp32 or NULL,
+ *   workspace: f3r_focal_workspace_bytes(n_views, H, W) bytes, 16-byte aligned.
+ */
+size_t f3r_focal_workspace_bytes(int n_views, int H, int W);
+int f3r_estimate_focal(const float* pts3d, const float* conf, float* focal, float* thr_out, void* workspace, size_t ws_bytes,
+                       int n_views, int H, int W, float quantile, float ppx, float ppy, int n_iter, float min_focal, float max_focal,
+                       f3r_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,29 @@ def bench_align(n_views=320, H=512, W=512, pct=85):
                       "cpu_oracle_ms_per_view": round(cpu_s * 1e3, 1), "note": "ms includes torch.stack of the inputs (3 copies)"}), flush=True)
 
 
+def bench_focal(n_views=320, H=512, W=512, pct=10):
+    """estimate_focal at the headline shape.  Algorithmic bytes per pixel: conf 4 B x (6 radix passes + 1) + points 12 B + workspace
+    16 B written once and read 100 times (L2-resident: 4 MB per view) = 1656 B; HBM-side only the first 56 B."""
+    import time
+    from fast3r_amd import estimate_focals
+    from oracle import focal_oracle as FO
+    g = torch.Generator().manual_seed(0)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    z = 1.5 + 3 * torch.rand(H, W, generator=g)
+    pts1 = torch.stack([(xs - W / 2) * z / 400.0, (ys - H / 2) * z / 400.0, z], -1) + 0.01 * torch.randn(H, W, 3, generator=g)
+    conf1 = 1 + 5 * torch.rand(H, W, generator=g)
+    pts = pts1[None].repeat(n_views, 1, 1, 1).cuda() * (1 + 0.001 * torch.arange(n_views).view(-1, 1, 1, 1).cuda())
+    conf = conf1[None].repeat(n_views, 1, 1).cuda()
+    out = estimate_focals(pts, conf, min_conf_thr_percentile=pct)
+    med, mn = time_ms(lambda: estimate_focals(pts, conf, min_conf_thr_percentile=pct), rounds=3, inner=1)
+    t0 = time.perf_counter()
+    ref = FO.estimate_focal(pts[:1].cpu(), conf[:1].cpu(), min_conf_thr_percentile=pct)
+    cpu_s = time.perf_counter() - t0
+    print(json.dumps({"kernel": "estimate_focal", "views": n_views, "HW": [H, W], "percentile": pct, "ms": round(med, 3),
+                      "views_per_s": round(n_views / med * 1e3, 1), "L2_GBps": round(n_views * H * W * 1656.0 / med / 1e6, 1),
+                      "focal_view0": float(out[0]), "cpu_oracle_focal_view0": ref, "cpu_oracle_ms_per_view": round(cpu_s * 1e3, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="attn,gemm,conv")
@@ -192,6 +215,8 @@ if __name__ == "__main__":
         bench_gemm(dt, M, 1024, 768, "patch_embed")
         bench_qkv(dt, M, 1024, 1024)
         bench_qkv(dt, M, 1024, M)
+    if "focal" in args.what:
+        bench_focal()
     if "align" in args.what:
         bench_align()
     if "conv" in args.what:
