@@ -47,6 +47,12 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result.  Native libraries print there too (RCCL writes its version banner to stdout when
+    # NCCL_DEBUG=VERSION is exported, as it is on the GPU boxes, and C stdio flushes it at exit, i.e. AFTER the JSON line): park the real
+    # stdout, point fd 1 at stderr for everything else, and write the result to the parked descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -57,8 +63,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # F3R_BENCH_FORCE_DIST=1: run the distributed code path (RCCL init, view sharding, barriers, MAX all-reduce) in a world of one
+    # rank -- the only way to execute it on a one-GPU box (tools/gpu_ci.sh)
+    force_dist = world == 1 and os.environ.get("F3R_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from fast3r_amd import Fast3R, ops
@@ -72,7 +86,7 @@ def main():
     sd = synth_state_dict(shapes, seed=0)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    if world > 1:
+    if distributed:
         model.shard_views()
 
     V = args.views
@@ -97,7 +111,7 @@ def main():
         workload = f"Fast3R ViT-L 512x512 end-to-end single forward pass (encoder + fusion decoder + 2 DPT heads), N={V} views"
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +128,7 @@ def main():
         timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -142,8 +156,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, enc, dec, head, args.cpu_views)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if distributed:
         dist.destroy_process_group()
 
 
