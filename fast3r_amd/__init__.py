@@ -5,3 +5,4 @@ from .inference_multiview import inference  # noqa: F401
 from .multiview_dust3r_module import MultiViewDUSt3RLitModule  # noqa: F401
 from .align import align_local_pts3d_to_global  # noqa: F401
 from .focal import estimate_focal, estimate_focals  # noqa: F401
+from .pose import estimate_camera_poses, estimate_poses  # noqa: F401

@@ -5,13 +5,14 @@ path.  What inference callers use is kept with the sa
     lit = MultiViewDUSt3RLitModule.load_for_inference(net)   (:119-123)
     lit.eval(); lit(views) == net(views)                     (:125-126)
 `align_local_pts3d_to_global` (:427-549) runs on the GPU (fast3r_amd/align.py, SURVEY.md section 8f rank 1);
-`estimate_focal` (:1081-1109, the focal half of rank 2) runs on the GPU (fast3r_amd/focal.py); the PnP half of
-`estimate_camera_poses` (:807-869; cv2.solvePnPRansac) is not built, so that method still raises NotImplementedError.
+`estimate_focal` (:1081-1109) and `estimate_camera_poses` (:807-869) run on the GPU (fast3r_amd/focal.py, fast3r_amd/pose.py;
+SURVEY.md section 8f rank 2; the PnP solver is not OpenCV's -- see pose.py).
 """
 import torch
 
 from .align import align_local_pts3d_to_global as _align
 from .focal import estimate_focal, estimate_focals  # noqa: F401  (module-level in the reference too, :1081)
+from .pose import estimate_camera_poses as _estimate_camera_poses
 
 
 class MultiViewDUSt3RLitModule(torch.nn.Module):
@@ -34,9 +35,8 @@ class MultiViewDUSt3RLitModule(torch.nn.Module):
 
     @staticmethod
     def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimation_method="individual"):
-        raise NotImplementedError("estimate_camera_poses: the focal half is available as fast3r_amd.estimate_focal / estimate_focals "
-                                  "(GPU); the PnP pose solve (cv2.solvePnPRansac in the reference) is not built yet "
-                                  "(SURVEY.md section 8f, rank 2)")
+        """Reference :807-869: returns (poses_c2w_all, estimated_focals_all), per sample and per view; preds must be on the GPU."""
+        return _estimate_camera_poses(preds, views, niter_PnP, focal_length_estimation_method)
 
     def align_local_pts3d_to_global(self, preds, views, min_conf_thr_percentile=0):
         """Adds `pts3d_local_aligned_to_global` to every pred (reference :427-549); preds must be on the GPU."""

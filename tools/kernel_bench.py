@@ -1,6 +1,7 @@
 """Kernel micro-benchmarks on the GPU box (interleaved rounds, random data, HIP events on the launch stream):
 attention variants on fusion / encoder shapes and the model's GEMM / conv shapes.  Prints one JSON line per item."""
 import argparse
+import math
 import json
 import sys
 
@@ -190,6 +191,35 @@ def bench_focal(n_views=320, H=512, W=512, pct=10):
                       "focal_view0": float(out[0]), "cpu_oracle_focal_view0": ref, "cpu_oracle_ms_per_view": round(cpu_s * 1e3, 1)}), flush=True)
 
 
+def bench_pnp(n_views=320, H=512, W=512):
+    """estimate_poses at the headline shape: ~50 passes over 16 B per pixel (L2-resident, 4 MB per view) of fp64 per-point arithmetic."""
+    import time
+    from fast3r_amd import estimate_poses
+    from oracle import pnp_oracle as PO
+    g = torch.Generator().manual_seed(0)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    z = 2 + 3 * torch.rand(H, W, generator=g)
+    Xc = torch.stack([(xs - W / 2) * z / 400.0, (ys - H / 2) * z / 400.0, z], -1)
+    c, s_ = math.cos(0.3), math.sin(0.3)
+    R = torch.tensor([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+    t = torch.tensor([0.2, -0.1, 0.5])
+    Xw = (Xc - t) @ R + 0.003 * torch.randn(H, W, 3, generator=g)
+    conf1 = 1.001 + 4 * torch.rand(H, W, generator=g)
+    pts = Xw[None].repeat(n_views, 1, 1, 1).cuda()
+    conf = conf1[None].repeat(n_views, 1, 1).cuda()
+    for mode, focal in (("focal given", 400.0), ("focal searched", None)):
+        estimate_poses(pts, conf, focal)
+        med, mn = time_ms(lambda: estimate_poses(pts, conf, focal), rounds=3, inner=1)
+        P, F, I = estimate_poses(pts[:1], conf[:1], focal)
+        t0 = time.perf_counter()
+        fo, To = PO.fast_pnp(Xw, focal, conf1 > 1.0)
+        cpu_s = time.perf_counter() - t0
+        print(json.dumps({"kernel": "estimate_poses", "mode": mode, "views": n_views, "HW": [H, W], "ms": round(med, 3),
+                          "views_per_s": round(n_views / med * 1e3, 1), "focal_view0": float(F[0]), "inliers_view0": int(I[0]),
+                          "max_abs_diff_vs_cpu_restatement": float((P[0].double().cpu() - To).abs().max()),
+                          "cpu_restatement_ms_per_view": round(cpu_s * 1e3, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="attn,gemm,conv")
@@ -217,6 +247,8 @@ if __name__ == "__main__":
         bench_qkv(dt, M, 1024, M)
     if "focal" in args.what:
         bench_focal()
+    if "pnp" in args.what:
+        bench_pnp()
     if "align" in args.what:
         bench_align()
     if "conv" in args.what:
