@@ -6,3 +6,4 @@ from .multiview_dust3r_module import MultiViewDUSt3RLitModule  # noqa: F401
 from .align import align_local_pts3d_to_global  # noqa: F401
 from .focal import estimate_focal, estimate_focals  # noqa: F401
 from .pose import estimate_camera_poses, estimate_poses  # noqa: F401
+from .image import load_images  # noqa: F401

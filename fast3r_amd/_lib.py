@@ -77,6 +77,8 @@ SYMBOLS = {
     "f3r_focal_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "f3r_estimate_focal": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           _c_f32, _c_f32, _c_f32, ctypes.c_int, _c_f32, _c_f32, _c_vp]),
+    "f3r_resample_u8": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, _c_vp]),
+    "f3r_imgnorm_u8": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, _c_vp]),
 }

@@ -182,6 +182,61 @@ __global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Input pipeline: the resize of `load_images` (fast3r/dust3r/utils/image.py:68-74: PIL LANCZOS when
+// shrinking, BICUBIC otherwise) and `ImgNorm` (:32).  Pillow's resize (src/libImaging/Resample.c) is integer work: per output
+// coordinate a window [xmin, xmin + count) and 22-bit fixed-point weights (computed on the host in double precision, as Pillow does),
+// an accumulator that starts at 1 << 21, an arithmetic shift by 22, saturation to 8 bits; horizontal pass into an 8-bit intermediate,
+// then vertical pass.  One thread per output pixel (3 channels); bit-exact with PIL (tests/test_image.py).
+__global__ void resample_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W, int axis, int out_size,
+                                   const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int ksize, int64_t n_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  // output geometry: axis 1 (horizontal): [H][out_size], axis 0 (vertical): [out_size][W]
+  const int ow = axis == 1 ? out_size : W;
+  const int oy = (int)(i / ow), ox = (int)(i - (int64_t)oy * ow);
+  const int o = axis == 1 ? ox : oy;
+  const int xmin = bounds[2 * o], cnt = bounds[2 * o + 1];
+  const int32_t* k = kk + (int64_t)o * ksize;
+  int32_t s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  if (axis == 1) {
+    const uint8_t* p = in + ((int64_t)oy * W + xmin) * 3;
+    for (int x = 0; x < cnt; ++x) {
+      const int32_t w = k[x];
+      s0 += (int32_t)p[3 * x] * w;
+      s1 += (int32_t)p[3 * x + 1] * w;
+      s2 += (int32_t)p[3 * x + 2] * w;
+    }
+  } else {
+    const uint8_t* p = in + ((int64_t)xmin * W + ox) * 3;
+    for (int y = 0; y < cnt; ++y) {
+      const int32_t w = k[y];
+      s0 += (int32_t)p[(int64_t)y * W * 3] * w;
+      s1 += (int32_t)p[(int64_t)y * W * 3 + 1] * w;
+      s2 += (int32_t)p[(int64_t)y * W * 3 + 2] * w;
+    }
+  }
+  s0 >>= 22; s1 >>= 22; s2 >>= 22;  // arithmetic shift, as Resample.c's clip8
+  uint8_t* q = out + i * 3;
+  q[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+  q[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+  q[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+}
+
+// crop box (x0, y0, w, h) of an [H][W][3] uint8 image -> fp32 [3][h][w], ((u / 255) - 0.5) / 0.5 in torchvision's operation order
+__global__ void imgnorm_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int W, int x0, int y0, int w, int h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)w * h) return;
+  const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+  const uint8_t* p = in + ((int64_t)(y0 + y) * W + (x0 + x)) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = __fdiv_rn((float)p[c], 255.0f);
+    out[(int64_t)c * w * h + i] = __fdiv_rn(__fsub_rn(v, 0.5f), 0.5f);
+  }
+}
+
 }  // namespace
 
 #define F3R_DTYPE_OK(dt) F3R_REQUIRE((dt) == F3R_F16 || (dt) == F3R_BF16, "bad dtype %d", (dt))
@@ -265,4 +320,20 @@ extern "C" int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dty
   else
     hipLaunchKernelGGL(cast_kernel<BF16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, n / 8);
   return f3r_check_launch("f3r_cast_f32_to_lp");
+}
+
+extern "C" int f3r_resample_u8(const uint8_t* in, uint8_t* out, int H, int W, int axis, int out_size, const int32_t* bounds,
+                               const int32_t* kk, int ksize, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && bounds && kk, "f3r_resample_u8: null pointer");
+  F3R_REQUIRE(H > 0 && W > 0 && out_size > 0 && ksize > 0 && (axis == 0 || axis == 1), "f3r_resample_u8: bad sizes");
+  const int64_t n = axis == 1 ? (int64_t)H * out_size : (int64_t)out_size * W;
+  hipLaunchKernelGGL(resample_u8_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, H, W, axis, out_size, bounds, kk, ksize, n);
+  return f3r_check_launch("f3r_resample_u8");
+}
+
+extern "C" int f3r_imgnorm_u8(const uint8_t* in, float* out, int H, int W, int x0, int y0, int w, int h, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out, "f3r_imgnorm_u8: null pointer");
+  F3R_REQUIRE(H > 0 && W > 0 && w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 + w <= W && y0 + h <= H, "f3r_imgnorm_u8: crop box outside the image");
+  hipLaunchKernelGGL(imgnorm_kernel, dim3(nblk((int64_t)w * h, 256)), dim3(256), 0, (hipStream_t)stream, in, out, W, x0, y0, w, h);
+  return f3r_check_launch("f3r_imgnorm_u8");
 }

@@ -247,6 +247,18 @@ int f3r_estimate_focal(const float* pts3d, const float* conf, float* focal, floa
 int f3r_estimate_poses(const float* pts3d, const float* conf, const float* focal_in, float* focal_out, float* cam_to_world, int* inliers,
                        int n_views, int H, int W, float conf_thr, float ppx, float ppy, int n_focals, f3r_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f3r_resample_u8 / f3r_imgnorm_u8: the device side of the input pipeline `load_images` (fast3r/dust3r/utils/image.py:76-159).
+ * f3r_resample_u8 is ONE pass of PIL.Image.resize for 8-bit RGB (`_resize_pil_image`, :68-74; Pillow's Resample.c): axis 1 =
+ * horizontal ([H][W][3] -> [H][out_size][3]), axis 0 = vertical ([H][W][3] -> [out_size][W][3]); bounds [out_size][2] = {first source
+ * index, count}, kk [out_size][ksize] = 22-bit fixed-point weights, both computed by the host exactly as Pillow computes them
+ * (fast3r_amd/image.py); accumulator 1 << 21, >> 22, saturate: bit-exact with PIL.  f3r_imgnorm_u8 crops (:131-139) and applies
+ * `ImgNorm` (:32: ToTensor + Normalize(0.5, 0.5)): [H][W][3] uint8 -> [3][h][w] fp32 = ((u / 255) - 0.5) / 0.5.
+ */
+int f3r_resample_u8(const uint8_t* in, uint8_t* out, int H, int W, int axis, int out_size, const int32_t* bounds, const int32_t* kk,
+                    int ksize, f3r_stream_t stream);
+int f3r_imgnorm_u8(const uint8_t* in, float* out, int H, int W, int x0, int y0, int w, int h, f3r_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,6 +220,38 @@ def bench_pnp(n_views=320, H=512, W=512):
                           "cpu_restatement_ms_per_view": round(cpu_s * 1e3, 1)}), flush=True)
 
 
+def bench_image(H=3000, W=4000, size=512, n=16):
+    """load_images' per-pixel work at a 12 MP camera frame: PIL LANCZOS resize + crop + ImgNorm on the host vs upload + GPU."""
+    import time
+    import numpy as np
+    from PIL import Image
+    from fast3r_amd.image import img_norm_crop, resize_u8, _resized_size
+    rng = np.random.default_rng(0)
+    frame = (rng.random((H, W, 3)) * 255).astype(np.uint8)
+    (nw, nh), interp = _resized_size((W, H), size)
+    pil = Image.fromarray(frame)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ref = np.asarray(pil.resize((nw, nh), Image.LANCZOS))
+        x = (np.transpose(ref, (2, 0, 1)).astype(np.float32) / 255 - 0.5) / 0.5
+    cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+    cache = {}
+    host = torch.from_numpy(frame).pin_memory()
+
+    def f():
+        u8 = host.to(DEV, non_blocking=True)
+        r = resize_u8(u8, nw, nh, interp, cache)
+        return img_norm_crop(r, (0, 0, nw - nw % 16, nh - nh % 16)), r
+    out, r = f()
+    assert np.array_equal(r.cpu().numpy(), ref)
+    med, mn = time_ms(f, rounds=3, inner=n)
+    u8 = host.to(DEV)
+    med_k, _ = time_ms(lambda: resize_u8(u8, nw, nh, interp, cache), rounds=3, inner=n)
+    print(json.dumps({"kernel": "load_images per-pixel work", "frame": [H, W], "to": [nh, nw], "gpu_ms_incl_upload": round(med, 3),
+                      "gpu_ms_resize_only": round(med_k, 3), "resize_GBps": round((H * W * 3 + H * nw * 3 * 2 + nh * nw * 3) / med_k / 1e6, 1),
+                      "pil_ms": round(cpu_ms, 1), "bit_exact_vs_pil": True}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="attn,gemm,conv")
@@ -249,6 +281,8 @@ if __name__ == "__main__":
         bench_focal()
     if "pnp" in args.what:
         bench_pnp()
+    if "image" in args.what:
+        bench_image()
     if "align" in args.what:
         bench_align()
     if "conv" in args.what:
