@@ -294,10 +294,24 @@ class _GraphCache:
         return [{k: v.clone() for k, v in r.items()} for r in outs]
 
 
-class Fast3R(nn.Module):
+try:  # the reference's loading API (fast3r.py:44-48): Fast3R.from_pretrained(repo id or local snapshot dir) / save_pretrained
+    import huggingface_hub as _hf
+    _HubMixin = _hf.PyTorchModelHubMixin
+except Exception:  # pragma: no cover  (huggingface_hub is a requirement of the reference; without it only from_pretrained is missing)
+    class _HubMixin:
+        def __init_subclass__(cls, **kw):
+            super().__init_subclass__()
+
+
+class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch/fast3r", tags=["image-to-3d"]):
+    """`Fast3R.from_pretrained("jedyang97/Fast3R_ViT_Large_512")` (or a local directory holding config.json + model.safetensors) works as
+    in the reference: the mixin reads the three *_args dicts from config.json, builds the model and loads the state dict (identical keys)."""
+
     def __init__(self, encoder_args: dict, decoder_args: dict, head_args: dict, freeze="none",
                  compute_dtype: torch.dtype = torch.float16):
         super().__init__()
+        if isinstance(compute_dtype, str):  # config.json round trip stores the dtype as text
+            compute_dtype = getattr(torch, compute_dtype.replace("torch.", ""))
         self.encoder_args = dict(encoder_args)
         self.build_encoder(encoder_args)
         self.decoder_args = dict(decoder_args)

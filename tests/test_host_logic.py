@@ -158,3 +158,21 @@ def test_rope_tables_match_reference_formula():
     i = torch.arange(16).float()
     th = torch.arange(32).float()[:, None] * (100.0 ** (-i / 16))[None]
     assert cos.shape == (32, 16) and torch.allclose(cos, th.cos(), atol=1e-6) and torch.allclose(sin, th.sin(), atol=1e-6)
+
+
+def test_hub_mixin_round_trip(tmp_path):
+    """The reference loads the released model with Fast3R.from_pretrained (PyTorchModelHubMixin, fast3r.py:44-48): a local snapshot
+    directory (config.json with the three *_args dicts + model.safetensors) must build the same module and load the same tensors."""
+    import json
+    from fast3r_amd import Fast3R
+    from fast3r_amd.synthetic import synth_state_dict, tiny_args
+    enc, dec, head = tiny_args()
+    m = Fast3R(enc, dec, head).eval()
+    m.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3))
+    m.save_pretrained(tmp_path)
+    cfg = json.load(open(tmp_path / "config.json"))
+    assert set(cfg) >= {"encoder_args", "decoder_args", "head_args"} and (tmp_path / "model.safetensors").exists()
+    m2 = Fast3R.from_pretrained(tmp_path)
+    assert m2.encoder_args == m.encoder_args and m2.decoder_args == m.decoder_args and m2.head_args == m.head_args
+    assert list(m2.state_dict()) == list(m.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
