@@ -36,7 +36,7 @@ class GemmArgs(ctypes.Structure):
         ("q", _c_vp), ("k", _c_vp), ("vt", _c_vp), ("seq_len", _c_i64), ("ldvt", _c_i64),
         ("rope_cos", _c_vp), ("rope_sin", _c_vp), ("rope_w", _c_i32), ("q_scale", _c_f32),
         ("ct_s", _c_i32), ("ct_h", _c_i32), ("ct_w", _c_i32), ("ct_cout", _c_i32),
-        ("dtype", _c_i32),
+        ("dtype", _c_i32), ("rope_mode", _c_i32),
     ]
 
 
@@ -79,6 +79,8 @@ SYMBOLS = {
                                           _c_f32, _c_f32, _c_f32, ctypes.c_int, _c_f32, _c_f32, _c_vp]),
     "f3r_resample_u8": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, ctypes.c_int, _c_vp]),
     "f3r_imgnorm_u8": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_silu_mul": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_rows_add_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, _c_vp]),
 }

@@ -237,6 +237,34 @@ __global__ void imgnorm_kernel(const uint8_t* __restrict__ in, float* __restrict
   }
 }
 
+
+// SwiGLU gate (llama.py:284): out[r][j] = silu(a) * b with a = ab[r][j], b = ab[r][hidden + j]; 8 columns per thread
+template <class T>
+__global__ void silu_mul_kernel(const uint16_t* __restrict__ ab, uint16_t* __restrict__ out, int64_t rows, int hidden, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int hv = hidden / 8;
+  const int64_t r = i / hv;
+  const int c = (int)(i - r * hv) * 8;
+  const u32x4 a = *(const u32x4*)(ab + r * 2 * hidden + c);
+  const u32x4 b = *(const u32x4*)(ab + r * 2 * hidden + hidden + c);
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a0 = lo_f<T>(a[k]), a1 = hi_f<T>(a[k]);
+    const float s0 = a0 / (1.0f + __expf(-a0)), s1 = a1 / (1.0f + __expf(-a1));
+    o[k] = pack2<T>(s0 * lo_f<T>(b[k]), s1 * hi_f<T>(b[k]));
+  }
+  *(u32x4*)(out + r * hidden + c) = o;
+}
+
+__global__ void rows_add_kernel(float* __restrict__ x, const float* __restrict__ vec, int D4, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4v* p = (float4v*)x + i;
+  *p = *p + *((const float4v*)vec + (i % D4));
+}
+
 }  // namespace
 
 #define F3R_DTYPE_OK(dt) F3R_REQUIRE((dt) == F3R_F16 || (dt) == F3R_BF16, "bad dtype %d", (dt))
@@ -336,4 +364,27 @@ extern "C" int f3r_imgnorm_u8(const uint8_t* in, float* out, int H, int W, int x
   F3R_REQUIRE(H > 0 && W > 0 && w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 + w <= W && y0 + h <= H, "f3r_imgnorm_u8: crop box outside the image");
   hipLaunchKernelGGL(imgnorm_kernel, dim3(nblk((int64_t)w * h, 256)), dim3(256), 0, (hipStream_t)stream, in, out, W, x0, y0, w, h);
   return f3r_check_launch("f3r_imgnorm_u8");
+}
+
+extern "C" int f3r_silu_mul(const void* ab, void* out, int64_t rows, int hidden, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(ab && out && al16(ab) && al16(out), "f3r_silu_mul: null/misaligned pointer");
+  F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0, "f3r_silu_mul: hidden %d must be a positive multiple of 8", hidden);
+  const int64_t n = rows * (hidden / 8);
+  if (n == 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == F3R_F16)
+    hipLaunchKernelGGL(silu_mul_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)ab, (uint16_t*)out, rows, hidden, n);
+  else
+    hipLaunchKernelGGL(silu_mul_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)ab, (uint16_t*)out, rows, hidden, n);
+  return f3r_check_launch("f3r_silu_mul");
+}
+
+extern "C" int f3r_rows_add_f32(float* x, const float* vec, int64_t rows, int D, f3r_stream_t stream) {
+  F3R_REQUIRE(x && vec && al16(x) && al16(vec), "f3r_rows_add_f32: null/misaligned pointer");
+  F3R_REQUIRE(rows >= 0 && D > 0 && D % 4 == 0, "f3r_rows_add_f32: D %d must be a positive multiple of 4", D);
+  const int64_t n = rows * (D / 4);
+  if (n == 0) return F3R_OK;
+  hipLaunchKernelGGL(rows_add_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, vec, D / 4, n);
+  return f3r_check_launch("f3r_rows_add_f32");
 }

@@ -405,11 +405,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
           // row position y, [32,64) by the column position x; dim i pairs with i+16 inside each half.
           const int pos = (int)(m % p.seq_len);
           const int py = pos / p.rope_w, px = pos - py * p.rope_w;
+          const int64_t grp = m / p.rope_w;  // rope_mode 1: one angle set per row group (LlamaDecoder: per view)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const int pp = h == 0 ? py : px;
-            const float4v c = *(const float4v*)(p.rope_cos + pp * 16 + fg * 4);
-            const float4v s = *(const float4v*)(p.rope_sin + pp * 16 + fg * 4);
+            const int64_t toff = p.rope_mode == 1 ? grp * 32 + h * 16 : (int64_t)(h == 0 ? py : px) * 16;
+            const float4v c = *(const float4v*)(p.rope_cos + toff + fg * 4);
+            const float4v s = *(const float4v*)(p.rope_sin + toff + fg * 4);
             const float4v a = v[2 * h], b = v[2 * h + 1];
             v[2 * h] = a * c - b * s;
             v[2 * h + 1] = b * c + a * s;

@@ -142,6 +142,88 @@ class Fast3RDecoder(_Params):
         return ids
 
 
+class _RMSNorm(_Params):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))  # llama.py:150-153
+
+
+class _LlamaAttention(_Params):
+    def __init__(self, dim, n_heads, n_kv_heads):
+        super().__init__()
+        hd = dim // n_heads
+        self.wq = nn.Linear(dim, n_heads * hd, bias=False)     # llama.py:195-198
+        self.wk = nn.Linear(dim, n_kv_heads * hd, bias=False)
+        self.wv = nn.Linear(dim, n_kv_heads * hd, bias=False)
+        self.wo = nn.Linear(n_heads * hd, dim, bias=False)
+
+
+class _LlamaFeedForward(_Params):
+    def __init__(self, dim, hidden_dim, multiple_of, ffn_dim_multiplier):
+        super().__init__()
+        hidden_dim = int(2 * hidden_dim / 3)                   # llama.py:273-277
+        if ffn_dim_multiplier is not None:
+            hidden_dim = int(ffn_dim_multiplier * hidden_dim)
+        hidden_dim = multiple_of * ((hidden_dim + multiple_of - 1) // multiple_of)
+        self.w1 = nn.Linear(dim, hidden_dim, bias=False)
+        self.w2 = nn.Linear(hidden_dim, dim, bias=False)
+        self.w3 = nn.Linear(dim, hidden_dim, bias=False)
+
+
+class _LlamaBlock(_Params):
+    def __init__(self, dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps):
+        super().__init__()
+        self.attention = _LlamaAttention(dim, n_heads, n_kv_heads)                       # llama.py:323-326
+        self.feed_forward = _LlamaFeedForward(dim, 4 * dim, multiple_of, ffn_dim_multiplier)  # llama.py:327-332
+        self.attention_norm = _RMSNorm(dim, norm_eps)
+        self.ffn_norm = _RMSNorm(dim, norm_eps)
+
+
+class LlamaDecoder(_Params):
+    """fast3r.py:810-968 (the `llama_dec` experiment, configs/experiment/llama_dec/llama_dec.yaml): pre-norm RMSNorm blocks with SwiGLU,
+    bias-free projections, rotary embedding of q / k by the IMAGE id of a token's view (all patches of a view share one angle set), a
+    learnable embedding added to the tokens of view 0 before every layer, final RMSNorm.  Bidirectional attention only; n_kv_heads must
+    equal n_heads (the released config) and head_dim must be 64."""
+
+    def __init__(self, random_image_idx_embedding, enc_embed_dim, embed_dim=4096, n_layers=32, n_heads=32, n_kv_heads=None,
+                 multiple_of=256, ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=False,
+                 depth_init=True, **kwargs):
+        super().__init__()
+        if embed_dim % n_heads != 0 or embed_dim // n_heads != 64:
+            raise ValueError("fast3r_amd kernels are built for head_dim 64")
+        if n_kv_heads not in (None, n_heads):
+            raise NotImplementedError("fast3r_amd LlamaDecoder: grouped-query attention (n_kv_heads != n_heads) is not built")
+        if is_causal:
+            raise NotImplementedError("fast3r_amd LlamaDecoder: causal attention is not built (the reference config is bidirectional)")
+        self.embed_dim, self.num_heads, self.depth = embed_dim, n_heads, n_layers
+        self.random_image_idx_embedding = random_image_idx_embedding
+        self.rope_theta, self.norm_eps = rope_theta, norm_eps
+        self.view0_embed = nn.Parameter(torch.zeros(embed_dim))                          # fast3r.py:841-842
+        nn.init.normal_(self.view0_embed, mean=0.0, std=0.02)
+        self.decoder_embed = nn.Linear(enc_embed_dim, embed_dim, bias=True)              # :845
+        self.layers = nn.ModuleList([_LlamaBlock(embed_dim, n_heads, n_heads, multiple_of, ffn_dim_multiplier, norm_eps)
+                                     for _ in range(n_layers)])                          # :848-852
+        self.norm = _RMSNorm(embed_dim, norm_eps)                                        # :854
+        # precompute_freqs_cis (llama.py:41-60) as [cos (32) | sin (32)] per position instead of complex64; a plain attribute, not a
+        # buffer, like the reference's precomputed_freqs_cis (fast3r.py:837)
+        hd = embed_dim // n_heads
+        freqs = 1.0 / (rope_theta ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
+        ang = torch.outer(torch.arange(max_seq_len).float(), freqs).float()
+        self.image_idx_emb = torch.cat([ang.cos(), ang.sin()], dim=1)
+
+    def attention_scale(self, training: bool) -> float:
+        return (self.embed_dim // self.num_heads) ** -0.5  # F.scaled_dot_product_attention default (llama.py:239)
+
+    draw_image_ids = Fast3RDecoder.draw_image_ids  # same RNG recipe (fast3r.py:856-897 == :702-743)
+
+
+# within a 64-wide head: destination position -> source dim, so that the reference's complex pairs (2j, 2j+1) land where the QKV
+# epilogue rotates (rope_mode 1: dims [0,32) pair i with i+16 using table columns 0-15, dims [32,64) likewise with columns 16-31).
+# The same permutation on q and k leaves every q . k unchanged.
+_ROPE_PERM = [2 * j for j in range(16)] + [2 * j + 1 for j in range(16)] + [2 * j for j in range(16, 32)] + [2 * j + 1 for j in range(16, 32)]
+
+
 class _RCU(_Params):
     def __init__(self, f):
         super().__init__()
@@ -194,7 +276,11 @@ class PixelwiseTaskWithDPT(_Params):
 
 # ======================================================================================= packed (device) weights
 class _PackedBlock:
-    __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+    __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                 "rms", "rope_mode", "swiglu_hidden")
+
+    def __init__(self):
+        self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
 
 
 def _f32(t):
@@ -209,6 +295,24 @@ def _pack_block(blk: _Block, lp):
     p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp), _f32(blk.attn.proj.bias)
     p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp), _f32(blk.mlp.fc1.bias)
     p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp), _f32(blk.mlp.fc2.bias)
+    return p
+
+
+def _pack_llama_block(blk: _LlamaBlock, n_heads, lp):
+    """LlamaDecoder layer -> the same packed fields as a ViT block: [wq; wk; wv] as one QKV matrix (q / k rows permuted per head, see
+    _ROPE_PERM), [w1; w3] stacked for one up-projection GEMM, no biases, RMSNorm weights."""
+    p = _PackedBlock()
+    p.rms, p.rope_mode = True, 1
+    p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.attention_norm.weight), None, _f32(blk.ffn_norm.weight), None
+    p.eps = blk.attention_norm.eps
+    perm = torch.tensor([h * 64 + d for h in range(n_heads) for d in _ROPE_PERM])
+    wq, wk, wv = (m.weight.detach().float() for m in (blk.attention.wq, blk.attention.wk, blk.attention.wv))
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(torch.cat([wq[perm], wk[perm], wv], dim=0), lp), None
+    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attention.wo.weight.detach().float(), lp), None
+    w1, w3 = blk.feed_forward.w1.weight.detach().float(), blk.feed_forward.w3.weight.detach().float()
+    p.swiglu_hidden = w1.shape[0]
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(torch.cat([w1, w3], dim=0), lp), None
+    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.feed_forward.w2.weight.detach().float(), lp), None
     return p
 
 
@@ -348,7 +452,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             a.pop("decoder_type", None)
             self.decoder = Fast3RDecoder(**a)
         elif dt == "llama":
-            raise ValueError("fast3r_amd: decoder_type 'llama' is outside the MI355X hot path (SURVEY.md section 2.1 #2)")
+            a = deepcopy(dict(decoder_args))
+            a.pop("decoder_type", None)
+            self.decoder = LlamaDecoder(**a)
         else:
             raise ValueError(f"Unsupported decoder type: {dt}")
 
@@ -427,8 +533,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
-        pk["dec"] = [_pack_block(b, lp) for b in dec.dec_blocks]
-        pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
+        if isinstance(dec, LlamaDecoder):
+            pk["dec"] = [_pack_llama_block(b, dec.num_heads, lp) for b in dec.layers]
+            pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
+            pk["view0"] = _f32(dec.view0_embed)
+        else:
+            pk["dec"] = [_pack_block(b, lp) for b in dec.dec_blocks]
+            pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
         pk["head"] = _pack_head(self.downstream_head, lp)
         pk["head_local"] = _pack_head(self.downstream_head_local, lp) if self.downstream_head_local is not None else None
         self._packed = pk
@@ -446,7 +557,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         lp = self.compute_dtype
         D = x.shape[1]
         T = x.shape[0]
-        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp)
+        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, rms=pb.rms)
         q = torch.empty((T, D), dtype=lp, device=x.device)
         if kv_exchange is None:
             k = torch.empty((T, D), dtype=lp, device=x.device)
@@ -455,7 +566,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 torch.empty((n_seq, D, ldvt), dtype=lp, device=x.device)
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
-        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E)
+        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode)
         o = h  # LN output is dead: reuse as the attention output buffer
         if kv_exchange is None:
             ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * D, D * ldvt)], tq=seq_len, batch=n_seq,
@@ -475,8 +586,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 kv_exchange.finish()
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x)
-        h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o)
-        _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)
+        h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
+        if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
+            _, ab = ops.gemm(h2, pb.fc1_w, want_lp=True)
+            hid = ops.silu_mul(ab, pb.swiglu_hidden)
+        else:
+            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x)
         return x
 
@@ -552,7 +667,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device."""
         if len(views) == 0:
             return ([], {}) if profiling else []
-        if self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None:
+        if self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder):
             out = self._graphs.run(self, views)
             if out is not None:
                 return out
@@ -626,7 +741,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             torch.cuda.synchronize()
         t2 = time.time()
         L = dec.depth
-        hooks = [0, L * 2 // 4, L * 3 // 4, L]
+        llama = isinstance(dec, LlamaDecoder)
+        hd_ = int(self.decoder_args["depth"]) if llama else L  # the heads read decoder_args["depth"] for both decoder types (fast3r.py:137-148)
+        hooks = [0, hd_ * 2 // 4, hd_ * 3 // 4, hd_]
         scale = dec.attention_scale(self.training)
         D = dec.embed_dim
         T_loc = sum(Ps)
@@ -636,22 +753,45 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             enc_b = torch.cat([feats[i][b] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b]
             enc_b = enc_b.contiguous()
             x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
-            if len(set(Ps)) == 1:
-                ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo:v_hi].contiguous(), rowadd_div=Ps[0], out_f32=x)
-            else:
-                r0 = 0
-                for i in range(n_loc):
-                    ops.gemm(enc_b[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo + i:v_lo + i + 1].contiguous(),
-                             rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]])
-                    r0 += Ps[i]
-            taps = {0: enc_b}
             kvx = None if sh is None else sh.make_kv_exchange(T_loc, D, lp, dev)
-            for li, pb in enumerate(pk["dec"]):
-                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
-                if (li + 1) in hooks[1:3]:
-                    taps[li + 1] = ops.cast_lp(x, lp)
-            w_, b_, eps = pk["dec_norm"]
-            taps[L], _ = ops.layernorm(x, w_, b_, eps, lp)
+            if llama:
+                # LlamaDecoder.forward (fast3r.py:924-966): embed; per layer add view0_embed to the tokens of view 0, then the block with
+                # the rotary angles of each token's view; outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
+                ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], out_f32=x)
+                rows = emb_rows[b, v_lo:v_hi]                                  # (n_loc, 64) = [cos (32) | sin (32)] of each view's id
+                if len(set(Ps)) == 1:
+                    rope = (rows[:, :32].contiguous(), rows[:, 32:].contiguous(), Ps[0])
+                else:  # mixed resolutions: one table row per token
+                    per_tok = rows.repeat_interleave(torch.tensor(Ps, device=dev), dim=0)
+                    rope = (per_tok[:, :32].contiguous(), per_tok[:, 32:].contiguous(), 1)
+                view0_rows = Ps[0] if v_lo == 0 else 0                          # view 0 lives on the rank that owns the first views
+                taps = {}
+                if 0 in hooks:
+                    taps[0] = ops.cast_lp(x, lp)
+                for li, pb in enumerate(pk["dec"]):
+                    ops.rows_add(x, pk["view0"], view0_rows)
+                    self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx)
+                    if (li + 1) in hooks and (li + 1) != L:
+                        taps[li + 1] = ops.cast_lp(x, lp)
+                if L in hooks:
+                    w_, b_, eps = pk["dec_norm"]
+                    taps[L], _ = ops.layernorm(x, w_, None, eps, lp, rms=True)
+            else:
+                if len(set(Ps)) == 1:
+                    ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo:v_hi].contiguous(), rowadd_div=Ps[0], out_f32=x)
+                else:
+                    r0 = 0
+                    for i in range(n_loc):
+                        ops.gemm(enc_b[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo + i:v_lo + i + 1].contiguous(),
+                                 rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]])
+                        r0 += Ps[i]
+                taps = {0: enc_b}
+                for li, pb in enumerate(pk["dec"]):
+                    self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
+                    if (li + 1) in hooks[1:3]:
+                        taps[li + 1] = ops.cast_lp(x, lp)
+                w_, b_, eps = pk["dec_norm"]
+                taps[L], _ = ops.layernorm(x, w_, b_, eps, lp)
             hook_toks.append([taps[hk] for hk in hooks])
             if self.debug_taps is not None:
                 self.debug_taps.setdefault("hooks", []).append([t.float().cpu() for t in hook_toks[-1]])

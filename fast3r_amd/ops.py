@@ -128,9 +128,10 @@ def vt_ld(seq_len: int) -> int:
 LOG2E = 1.4426950408889634
 
 
-def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0):
-    """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE-2D'd), v -> vt[M/seq][D][ldvt].
-    rope = (cos, sin, tokens_per_row) or None.  vt must be zero-initialised once (its padding is never written)."""
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0):
+    """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE'd), v -> vt[M/seq][D][ldvt].
+    rope = (cos, sin, tokens_per_row) or None; rope_mode 0 = RoPE-2D tables [n_pos][16], 1 = per-row-group tables [n_groups][32]
+    (rope[2] = rows per group; see f3r_gemm_args.rope_mode).  vt must be zero-initialised once (its padding is never written)."""
     require_gpu(a, "a")
     lp = a.dtype
     M = a.shape[0]
@@ -143,9 +144,28 @@ def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0):
     g.seq_len, g.ldvt = seq_len, vt.stride(-2)
     if rope is not None:
         g.rope_cos, g.rope_sin, g.rope_w = ptr(rope[0]), ptr(rope[1]), rope[2]
+        g.rope_mode = int(rope_mode)
     g.q_scale = float(q_scale)
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
+
+
+def silu_mul(ab, hidden, out=None):
+    """SwiGLU gate: ab lowp [rows][2*hidden] = [w1 x | w3 x] -> silu(w1 x) * (w3 x), lowp [rows][hidden] (llama.py:284)."""
+    require_gpu(ab, "ab")
+    assert ab.dim() == 2 and ab.shape[1] == 2 * hidden and ab.is_contiguous()
+    if out is None:
+        out = torch.empty((ab.shape[0], hidden), dtype=ab.dtype, device=ab.device)
+    check(_lib.lib().f3r_silu_mul(ptr(ab), ptr(out), ab.shape[0], hidden, dtype_id(ab.dtype), stream_ptr()), "f3r_silu_mul")
+    return out
+
+
+def rows_add(x, vec, rows):
+    """x[:rows] += vec in place (fp32 residual stream; fast3r.py:957-958 `x + view0_mask * view0_embed`)."""
+    require_gpu(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous() and vec.dtype == torch.float32 and vec.numel() == x.shape[-1]
+    check(_lib.lib().f3r_rows_add_f32(ptr(x), ptr(vec), int(rows), x.shape[-1], stream_ptr()), "f3r_rows_add_f32")
+    return x
 
 
 def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, res_lp2=None, out=None):

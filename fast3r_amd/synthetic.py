@@ -31,7 +31,7 @@ def vit_large_args(img_size=512, attn_implementation="flash_attention", random_i
 
 def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64, with_local_head=True,
               random_image_idx_embedding=True, attn_implementation="pytorch_naive",
-              attn_bias_for_inference_enabled=True):
+              attn_bias_for_inference_enabled=True, decoder_type="fast3r", llama_layers=12):
     """Small model of the same family (head_dim stays 64; decoder depth must be > 9, fast3r.py:137)."""
     encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls="PatchEmbedDust3R",
                         embed_dim=embed_dim, num_heads=num_heads, depth=enc_depth, mlp_ratio=4, pos_embed="RoPE100",
@@ -41,6 +41,13 @@ def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64
                         mlp_ratio=4.0, qkv_bias=True, drop=0.0, attn_drop=0.0,
                         attn_implementation=attn_implementation,
                         attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)
+    if decoder_type == "llama":
+        # configs/experiment/llama_dec/llama_dec.yaml:52-66 merged over configs/model/fast3r.yaml: the base keys stay in the dict (they
+        # disappear into LlamaDecoder's **kwargs) and `depth` -- not n_layers -- is what the heads read (fast3r.py:137-148)
+        decoder_args = dict(decoder_type="llama", random_image_idx_embedding=random_image_idx_embedding, enc_embed_dim=embed_dim,
+                            embed_dim=embed_dim, n_layers=llama_layers, n_heads=num_heads, n_kv_heads=None, multiple_of=64,
+                            ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=False,
+                            depth_init=True, depth=dec_depth, num_heads=num_heads, mlp_ratio=4.0, qkv_bias=True)
     head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=False,
                      depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],
                      patch_size=16, with_local_head=with_local_head)

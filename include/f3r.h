@@ -122,6 +122,12 @@ typedef struct f3r_gemm_args {
      columns n = (dy*ct_s + dx)*ct_cout + co  ->  out_lp[b][y*ct_s+dy][x*ct_s+dx][co] */
   int32_t ct_s, ct_h, ct_w, ct_cout;
   int32_t dtype;     /* f3r_dtype */
+  int32_t rope_mode; /* QKV with rope_cos != NULL.  0: RoPE-2D of the CroCo encoder as described above.  1: one rotation angle set per
+                        ROW GROUP (LlamaDecoder, fast3r/models/components/llama.py:96-122 with freqs_cis gathered per view,
+                        fast3r.py:872-922): rope_cos / rope_sin are [n_groups][32] (32 complex pairs of a 64-wide head), row m uses
+                        group m / rope_w (rope_w = tokens per view, or 1 with one table row per token); the first 32 dims of a head
+                        rotate with table columns 0-15 (dim i pairs with i+16), the last 32 with columns 16-31 -- the host permutes
+                        the q / k weight rows so that the reference's interleaved pairs (2j, 2j+1) land on these positions */
 } f3r_gemm_args;
 
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
@@ -258,6 +264,16 @@ int f3r_estimate_poses(const float* pts3d, const float* conf, const float* focal
 int f3r_resample_u8(const uint8_t* in, uint8_t* out, int H, int W, int axis, int out_size, const int32_t* bounds, const int32_t* kk,
                     int ksize, f3r_stream_t stream);
 int f3r_imgnorm_u8(const uint8_t* in, float* out, int H, int W, int x0, int y0, int w, int h, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LlamaDecoder variant (fast3r/models/fast3r.py:810-968, fast3r/models/components/llama.py): RMSNorm is f3r_layernorm with rms = 1;
+ * f3r_silu_mul: SwiGLU gate of FeedForward.forward (llama.py:284), out[r][j] = silu(ab[r][j]) * ab[r][hidden + j], lowp in / out
+ * ([rows][2*hidden] -> [rows][hidden]; the two projections w1, w3 are one GEMM with stacked weights);
+ * f3r_rows_add_f32: x[r][:] += vec for r < rows -- `x + view0_mask * view0_embed` before every layer (fast3r.py:957-958; the view-0
+ * tokens are the first rows of the sequence).
+ */
+int f3r_silu_mul(const void* ab, void* out, int64_t rows, int hidden, int dtype, f3r_stream_t stream);
+int f3r_rows_add_f32(float* x, const float* vec, int64_t rows, int D, f3r_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ CASES = {
     "tiny_b2_seqids": (dict(random_image_idx_embedding=False, with_local_head=False), [(32, 48)] * 4, 2, 2, 7, "default"),
     "tiny_oddgrid": (dict(enc_depth=1, attn_bias_for_inference_enabled=False), [(112, 160)] * 2, 1, 3, 5, "default"),
     "tiny_hot_3x64": (dict(), [(64, 64)] * 3, 1, 0, 1234, "hot"),
+    "tiny_llama_3x64": (dict(decoder_type="llama"), [(64, 64)] * 3, 1, 4, 31, "default"),
+    "tiny_llama_seqids_b2": (dict(decoder_type="llama", random_image_idx_embedding=False, enc_depth=1, llama_layers=14), [(32, 48)] * 4, 2, 5, 3, "default"),
 }
 
 

@@ -159,6 +159,60 @@ def test_gemm_qkv_epilogue(built_lib, dt, n_seq, gh, gw, D, use_rope):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows_per_group", [24, 1])
+def test_gemm_qkv_rope_by_row_group(built_lib, dt, rows_per_group):
+    """rope_mode 1 (LlamaDecoder): one angle set per row group, complex pairs (2j, 2j+1) of the reference (llama.py:96-122) realised
+    as a row permutation of the q / k weights + the half-split rotation of the epilogue.  Scores q . k must be those of the reference."""
+    from fast3r_amd.fast3r import _ROPE_PERM
+    n_groups, D, K = 5, 128, 128
+    M = n_groups * 24
+    a = rnd((M, K), dt, 21)
+    wq, wk, wv = (rnd((D, K), dt, 22 + i, K ** -0.5) for i in range(3))
+    perm = torch.tensor([h * 64 + d for h in range(D // 64) for d in _ROPE_PERM])
+    wp = ops.pack_linear_weight(torch.cat([wq.float()[perm], wk.float()[perm], wv.float()]), dt).to(DEV)
+    n_tab = M // rows_per_group
+    ang = torch.rand(n_tab, 32, generator=torch.Generator().manual_seed(5)) * 6.0
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q = torch.empty((M, D), dtype=dt, device=DEV)
+    k = torch.empty((M, D), dtype=dt, device=DEV)
+    vt = torch.zeros((1, D, ops.vt_ld(M)), dtype=dt, device=DEV)
+    ops.gemm_qkv(a.to(DEV), wp, None, q, k, vt, M, (cos.to(DEV), sin.to(DEV), rows_per_group), rope_mode=1)
+
+    def ref_rot(w):  # reference arithmetic in fp64: view_as_complex on adjacent pairs, times cis(angle of the row's group)
+        x = (a.double() @ w.double().t()).reshape(M, D // 64, 32, 2)
+        g = torch.arange(M) // rows_per_group
+        c, s_ = cos.double()[g][:, None, :], sin.double()[g][:, None, :]
+        return torch.stack([x[..., 0] * c - x[..., 1] * s_, x[..., 0] * s_ + x[..., 1] * c], dim=-1).reshape(M, D)
+    rq, rk = ref_rot(wq), ref_rot(wk)
+    assert_close(q.float().cpu()[:, torch.argsort(perm)], rq, lp_tol(dt), "q (un-permuted)")
+    assert_close(k.float().cpu()[:, torch.argsort(perm)], rk, lp_tol(dt), "k (un-permuted)")
+    sc = (q.float().cpu().reshape(M, 2, 64).transpose(0, 1) @ k.float().cpu().reshape(M, 2, 64).transpose(0, 1).transpose(1, 2))
+    sc_ref = rq.reshape(M, 2, 64).transpose(0, 1) @ rk.reshape(M, 2, 64).transpose(0, 1).transpose(1, 2)
+    assert_close(sc, sc_ref, 4 * lp_tol(dt), "scores are permutation invariant")
+    assert_close(vt[0, :, :M].float().cpu().t(), a.double() @ wv.double().t(), lp_tol(dt), "v^T")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_silu_mul_and_rows_add_and_rmsnorm(built_lib, dt):
+    rows, hidden = 37, 192
+    ab = rnd((rows, 2 * hidden), dt, 31, 2.0)
+    out = ops.silu_mul(ab.to(DEV), hidden)
+    ref = F.silu(ab[:, :hidden].double()) * ab[:, hidden:].double()
+    assert_close(out.float(), ref, lp_tol(dt), "silu_mul")
+    x = torch.randn(50, 128)
+    vec = torch.randn(128)
+    xg = x.clone().to(DEV)
+    ops.rows_add(xg, vec.to(DEV), 13)
+    exp = x.clone()
+    exp[:13] += vec
+    assert torch.equal(xg.cpu(), exp)
+    w = 1 + 0.1 * torch.randn(128)
+    y, _ = ops.layernorm(xg, w.to(DEV), None, 1e-5, dt, rms=True)
+    refn = exp.double() * torch.rsqrt(exp.double().pow(2).mean(-1, keepdim=True) + 1e-5) * w.double()
+    assert_close(y.float(), refn, lp_tol(dt), "rmsnorm")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 8, 8, 256, 256, 1), (1, 16, 12, 96, 256, 1), (2, 9, 7, 768, 128, 2), (1, 32, 32, 128, 128, 1), (3, 5, 5, 192, 64, 2)])
 def test_conv3x3(built_lib, dt, B, H, W, Ci, Co, stride):
     x = rnd((B, H, W, Ci), dt, 13)
