@@ -640,8 +640,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void attn_kernel(const f3r_attn_args
   }
 }
 
+#ifdef F3R_ATTN_LAB
 #include "f3r_attn_xp.h"   // software-pipelined body (half-tile stages, pinned issue order)
 #include "f3r_attn_lab.h"  // experimental bodies (v2 / v3 / v4 / ping-pong): measured, correct, slower -- see DESIGN.md section 6
+#endif
 
 template <class T, int NW, int QPW, int OPT, int MINW>
 int attn_launch(const f3r_attn_args& a, hipStream_t s) {
@@ -657,6 +659,21 @@ int attn_launch(const f3r_attn_args& a, hipStream_t s) {
 template <class T>
 int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
   switch (variant) {
+    // ---- always built: the product (72), its predecessors quoted in DESIGN.md section 6 and the instrumented product (84)
+    case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
+    case 53: return attn_launch<T, 4, 2, 1793, 2>(a, s);  // 51 + lazy reference max (row-sum trigger)
+    case 55:  // 53 + LDS-DMA staging (scalar tile base + lane-constant offsets).  OPT bit 12 changes nothing in the body: it only gives
+              // the batched (encoder, 1024 keys per sequence) launches their own kernel name, so that a rocprofv3 --stats line
+              // of attn_kernel<.., 1857, ..> averages the fusion launches alone (the roofline kernel of bench.py)
+      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857, 2>(a, s);
+    case 71:  // 55 with the next tile's DMA issued after the Q K^T MFMAs (+1 %); same kernel-name split as 55
+      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192, 2>(a, s);
+    case 72:  // product: 71 + s_setprio 1 around both MFMA clusters (= variant 70 with the kernel-name split)
+      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 2 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);
+    case 70: return attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);  // 67 + s_setprio around the MFMA clusters
+    case 84: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 32, 2>(a, s);  // 70 + per-section s_memtime instrumentation
+#ifdef F3R_ATTN_LAB  // the variant study of DESIGN.md section 6 (~80 more instantiations per operand type, +75 s of compile time):
+                     // F3R_EXTRA_FLAGS=-DF3R_ATTN_LAB bash fast3r_amd/csrc/build.sh
     case 0: return attn_launch<T, 8, 1, 0, 2>(a, s);  // round-1 first light: 8 waves in barrier lockstep
     case 1: return attn_launch<T, 4, 1, 0, 3>(a, s);  // 4-wave workgroups, 3 independent workgroups per CU
     case 2: return attn_launch<T, 4, 1, 3, 3>(a, s);  // + skip-rescale + setprio
@@ -672,21 +689,11 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 9: return attn_launch_v2<T, 4, 2, 2>(a, s);   // v2 body, 4 waves x 64 q
     case 10: return attn_launch_v2<T, 8, 1, 2>(a, s);  // v2 body, 8 waves x 32 q
     case 11: return attn_launch_v2<T, 4, 1, 3>(a, s);  // v2 body, 4 waves x 32 q, 3 workgroups / CU
-    case 24: return attn_launch<T, 4, 2, 1, 2>(a, s);  // like 3 without setprio
     case 25: return attn_launch<T, 8, 2, 1, 2>(a, s);  // 8 waves x 64 q (512 q / workgroup, 1 workgroup / CU)
     case 26: return attn_launch<T, 8, 2, 3, 2>(a, s);  // same + setprio
     case 51: return attn_launch<T, 4, 2, 769, 2>(a, s);  // 49 + running max through a fifth MFMA k-step
     case 52: return attn_launch<T, 8, 2, 769, 2>(a, s);  // 50 + the same
-    case 53: return attn_launch<T, 4, 2, 1793, 2>(a, s);  // 51 + lazy reference max (row-sum trigger)
     case 54: return attn_launch<T, 8, 2, 1793, 2>(a, s);  // 52 + the same
-    case 55:  // 53 + LDS-DMA staging (scalar tile base + lane-constant offsets).  OPT bit 12 changes nothing in the body: it only gives
-              // the batched (encoder, 1024 keys per sequence) launches their own kernel name, so that a rocprofv3 --stats line
-              // of attn_kernel<.., 1857, ..> averages the fusion launches alone (the roofline kernel of bench.py)
-      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857, 2>(a, s);
-    case 71:  // 55 with the next tile's DMA issued after the Q K^T MFMAs (+1 %); same kernel-name split as 55
-      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192, 2>(a, s);
-    case 72:  // product: 71 + s_setprio 1 around both MFMA clusters (= variant 70 with the kernel-name split)
-      return a.batch > 1 ? attn_launch<T, 4, 2, 1857 + 8192 + 2 + 4096, 2>(a, s) : attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);
     case 56: return attn_launch<T, 8, 2, 1857, 2>(a, s);  // 54 + the same
     case 57: return attn_launch<T, 4, 2, 3905, 2>(a, s);  // 55 + K-fragment reads pinned two steps ahead
     case 58: return attn_launch<T, 8, 2, 3905, 2>(a, s);  // 56 + the same
@@ -697,7 +704,6 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 67: return attn_launch<T, 4, 2, 1857 + 8192, 2>(a, s);   // 55 with the DMA issued after the Q K^T MFMAs
     case 68: return attn_launch<T, 4, 2, 1857 + 16384, 2>(a, s);  // ... between the two query blocks of the softmax
     case 69: return attn_launch<T, 4, 2, 1857 + 24576, 2>(a, s);  // ... after the softmax
-    case 70: return attn_launch<T, 4, 2, 1857 + 8192 + 2, 2>(a, s);  // 67 + s_setprio around the MFMA clusters
     case 73: return attn_launch<T, 4, 2, 1857 + 2, 2>(a, s);          // 55 + s_setprio (DMA at the loop top)
     case 74: return attn_launch<T, 4, 2, 1857 + 16384 + 2, 2>(a, s);  // 68 + s_setprio (DMA between the softmax query blocks)
     case 75: return attn_launch<T, 8, 2, 1857 + 8192 + 2, 2>(a, s);   // 8 waves, DMA after Q K^T, s_setprio
@@ -708,7 +714,6 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 80: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 262144, 2>(a, s);  // 70 with priority 3
     case 81: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 2048, 2>(a, s);    // 70 + K fragments pinned two steps ahead
     case 82: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 524288, 2>(a, s);  // 70 with the V^T pieces issued after the softmax
-    case 84: return attn_launch<T, 4, 2, 1857 + 8192 + 2 + 32, 2>(a, s);  // 70 + per-section s_memtime instrumentation
     case 63: return attn_launch_xp<T, 4, 0, 2>(a, s);  // xp: P V(h-1) / Q K^T(h+1) MFMAs with the softmax of half h in their shadows
     case 64: return attn_launch_xp<T, 4, 1, 2>(a, s);  // 63 + loop timing
     case 65: return attn_launch_xp<T, 4, 0, 1>(a, s);  // xp with one wave per SIMD (512 registers, no spills)
@@ -746,7 +751,8 @@ int attn_dispatch(const f3r_attn_args& a, hipStream_t s, int variant) {
     case 17: return attn_launch_v3<T, 4, 2, 8>(a, s);  // v3, 4 waves, sched_group_barrier pattern 1 MFMA : 1 DS : 8 VALU
     case 18: return attn_launch_v3<T, 8, 2, 8>(a, s);  // v3, 8 waves, same pattern
     case 19: return attn_launch_v3<T, 4, 2, 6>(a, s);  // v3, 4 waves, 1 : 1 : 6
-    default: f3r_set_error("f3r_attn_fwd: unknown variant %d", variant); return F3R_ERR_ARG;
+#endif
+    default: f3r_set_error("f3r_attn_fwd: variant %d is not in this build (lab variants need -DF3R_ATTN_LAB)", variant); return F3R_ERR_ARG;
   }
 }
 
