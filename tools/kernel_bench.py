@@ -255,7 +255,7 @@ def bench_image(H=3000, W=4000, size=512, n=16):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="attn,gemm,conv")
-    ap.add_argument("--variants", default="0,1,2,3,4,5")
+    ap.add_argument("--variants", default="24,72", help="attention variants; anything but 24 53 55 70 71 72 84 needs a -DF3R_ATTN_LAB build")
     ap.add_argument("--views", default="20,100")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]

@@ -2,7 +2,7 @@
 # PMC passes over the attention micro-benchmark (one variant, fusion shape).  Each --pmc pass is its own run.
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-V=${1:-3}; VIEWS=${2:-100}
+V=${1:-72}; VIEWS=${2:-100}
 rocprofv3 -L > gpurun_out/pmc/counters_list.txt 2>&1
 CMD="python tools/kernel_bench.py --what attnonly --variants $V --views $VIEWS"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES -d gpurun_out/pmc/p1 --output-format csv -- $CMD > gpurun_out/pmc/p1.log 2>&1
