@@ -2,7 +2,6 @@
 (fast3r/dust3r/post_process.py::estimate_focal_knowing_depth_and_confidence_mask, focal_mode="weiszfeld") on seeded inputs.
 Run in the build container (needs /root/reference):  python oracle/make_golden_focal.py
 """
-import math
 import os
 import sys
 

@@ -2,7 +2,6 @@
 dust3r/cloud_opt/init_im_poses.py:300-350).  The reference's solver is cv2.solvePnPRansac (OpenCV is not in this image and its RANSAC is
 randomised), so parity with the reference is UNPINNED for this row; it is anchored on ground truth -- known cameras are recovered from
 synthetic pointmaps with noise and gross outliers -- and on HIP == the independent torch restatement of the same algorithm."""
-import math
 
 import numpy as np
 import pytest
