@@ -490,6 +490,34 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                                         conf_mode=self.head_args["conf_mode"])
         raise NotImplementedError(f"unexpected {head_type=} and {output_mode=}")  # fast3r.py:157
 
+    def load_from_dust3r_checkpoint(self, dust3r_checkpoint_path):
+        """fast3r.py:162-234: initialise from a DUSt3R checkpoint ({'model': state_dict}): `patch_embed.* | enc_blocks.* | enc_norm.*`
+        go to `encoder.*`, `downstream_head1.*` to `downstream_head.*` (skipped with head_args['skip_load_pretrained_head'], and
+        reverted if the shapes do not fit); everything else in the file is ignored.  Returns (loaded_keys, not_loaded_keys)."""
+        checkpoint = torch.load(dust3r_checkpoint_path, weights_only=False)["model"]
+        enc_sd, head_sd, loaded = {}, {}, set()
+        for key, value in checkpoint.items():
+            if key.startswith(("patch_embed", "enc_blocks", "enc_norm")):
+                enc_sd["encoder." + key] = value
+                loaded.add(key)
+            elif key.startswith("downstream_head1"):
+                head_sd[key.replace("downstream_head1", "downstream_head")] = value
+                loaded.add(key)
+        res = self.load_state_dict(enc_sd, strict=False)
+        bad = set(res.unexpected_keys)
+        loaded -= {k[len("encoder."):] for k in bad}
+        if not self.head_args.get("skip_load_pretrained_head", False):
+            backup = {k: v.clone() for k, v in self.downstream_head.state_dict().items()}
+            try:
+                res = self.load_state_dict(head_sd, strict=False)
+                loaded -= {k.replace("downstream_head", "downstream_head1", 1) for k in res.unexpected_keys}
+            except RuntimeError:  # size mismatch: keep the head as it was (:213-222)
+                self.downstream_head.load_state_dict(backup)
+                loaded -= {k for k in checkpoint if k.startswith("downstream_head1")}
+        else:
+            loaded -= {k for k in checkpoint if k.startswith("downstream_head1")}
+        return loaded, set(checkpoint.keys()) - loaded
+
     def set_freeze(self, freeze):
         self.freeze = freeze
         todo = {"none": [], "encoder": [self.encoder], "sandwich": [self.encoder, self.downstream_head]}[freeze]

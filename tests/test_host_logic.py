@@ -177,3 +177,33 @@ def test_hub_mixin_round_trip(tmp_path):
     assert m2.encoder_args == m.encoder_args and m2.decoder_args == m.decoder_args and m2.head_args == m.head_args
     assert list(m2.state_dict()) == list(m.state_dict())
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_load_from_dust3r_checkpoint(tmp_path):
+    """fast3r.py:162-234: encoder + first head of a DUSt3R checkpoint are mapped in; decoder / second head keys are ignored."""
+    enc, dec, head = tiny_args()
+    src = Fast3R(enc, dec, head)
+    sd = src.state_dict()
+    dust3r = {}
+    for k, v in sd.items():
+        if k.startswith("encoder."):
+            dust3r[k[len("encoder."):]] = v + 1.0
+        elif k.startswith("downstream_head."):
+            dust3r[k.replace("downstream_head.", "downstream_head1.", 1)] = v - 1.0
+    dust3r["dec_blocks.0.attn.qkv.weight"] = torch.zeros(3, 3)       # DUSt3R's own decoder: not ours
+    dust3r["downstream_head2.dpt.head.4.bias"] = torch.zeros(4)
+    path = tmp_path / "dust3r.pth"
+    torch.save({"model": dust3r}, path)
+    m = Fast3R(enc, dec, head)
+    loaded, skipped = m.load_from_dust3r_checkpoint(str(path))
+    assert skipped == {"dec_blocks.0.attn.qkv.weight", "downstream_head2.dpt.head.4.bias"}
+    new = m.state_dict()
+    for k, v in sd.items():
+        if k.startswith("encoder."):
+            assert torch.equal(new[k], v + 1.0), k
+        elif k.startswith("downstream_head."):
+            assert torch.equal(new[k], v - 1.0), k
+    m2 = Fast3R(enc, dec, dict(head, skip_load_pretrained_head=True))
+    before = {k: v.clone() for k, v in m2.downstream_head.state_dict().items()}
+    m2.load_from_dust3r_checkpoint(str(path))
+    assert all(torch.equal(v, m2.downstream_head.state_dict()[k]) for k, v in before.items())
