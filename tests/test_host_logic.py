@@ -207,3 +207,16 @@ def test_load_from_dust3r_checkpoint(tmp_path):
     before = {k: v.clone() for k, v in m2.downstream_head.state_dict().items()}
     m2.load_from_dust3r_checkpoint(str(path))
     assert all(torch.equal(v, m2.downstream_head.state_dict()[k]) for k, v in before.items())
+
+
+def test_half_and_bfloat16_modules_still_pack():
+    """SURVEY.md section 8b "Modes": model.half() / .bfloat16() must keep working -- the packed operands are rebuilt from whatever
+    precision the parameters hold, biases / norm weights go back to fp32 for the epilogues."""
+    for cast in ("half", "bfloat16"):
+        m = Fast3R(*tiny_args()).eval()
+        getattr(m, cast)()
+        assert m._packed is None  # _apply invalidates the cache
+        pk = m._pack(torch.device("cpu"))
+        blk = pk["dec"][0]
+        assert blk.qkv_w.dtype == m.compute_dtype and blk.qkv_b.dtype == torch.float32 and blk.n1w.dtype == torch.float32
+        assert torch.isfinite(blk.qkv_w.float()).all() and pk["head"] is not None
