@@ -13,6 +13,7 @@ F3R_F16, F3R_BF16 = 0, 1
 F3R_A_PLAIN, F3R_A_CONV3X3 = 0, 1
 F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_EPI_CONVT = 0, 1, 2
 F3R_ACT_NONE, F3R_ACT_GELU, F3R_ACT_RELU = 0, 1, 2
+F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3 = 0, 1, 2
 F3R_MAX_SEG = 8
 
 _c_i64, _c_i32, _c_f32, _c_vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
@@ -37,6 +38,8 @@ class GemmArgs(ctypes.Structure):
         ("rope_cos", _c_vp), ("rope_sin", _c_vp), ("rope_w", _c_i32), ("q_scale", _c_f32),
         ("ct_s", _c_i32), ("ct_h", _c_i32), ("ct_w", _c_i32), ("ct_cout", _c_i32),
         ("dtype", _c_i32), ("rope_mode", _c_i32),
+        ("split", _c_i32), ("kernel_sel", _c_i32), ("A_lo", _c_vp),
+        ("out_lp_lo", _c_vp), ("res_lp_lo", _c_vp), ("res_lp2_lo", _c_vp), ("out_relu", _c_vp), ("out_relu_lo", _c_vp),
     ]
 
 
@@ -68,9 +71,9 @@ SYMBOLS = {
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
     "f3r_attn_set_variant": (ctypes.c_int, [ctypes.c_int]),
     "f3r_attn_read_prof": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]),
-    "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
-    "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_vp]),
-    "f3r_cast_f32_to_lp": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
+    "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_vp]),
+    "f3r_cast_f32_to_lp": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "f3r_align_local_to_global": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_size_t,
                                                  ctypes.c_int, _c_i64, _c_f32, _c_vp]),
@@ -143,3 +146,15 @@ def require_gpu(t: torch.Tensor, name="tensor"):
     if not t.is_cuda:
         raise F3RError(f"fast3r_amd: {name} lives on {t.device}; the HIP kernels need a ROCm device "
                        "(there is no CPU fallback -- the CPU path is oracle/, test infrastructure only)")
+
+
+def work_device(t: torch.Tensor, what="tensor"):
+    """Where the kernels run for `t`: its own ROCm device, or -- for a CPU tensor, e.g. the preds `inference()` hands back after its
+    `to_cpu` (inference_multiview.py:92) -- the current ROCm device (the caller uploads, runs the kernels, and returns results on
+    `t.device`).  Still no CPU *compute* path: without a GPU this raises."""
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise F3RError(f"fast3r_amd: {what} lives on {t.device} and no ROCm device is available; the HIP kernels need one "
+                       "(there is no CPU fallback -- the CPU path is oracle/, test infrastructure only)")
+    return torch.device("cuda", torch.cuda.current_device())

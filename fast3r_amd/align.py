@@ -8,7 +8,7 @@ roma.rigid_points_registration on each; here all pairs are one batched launch of
 import torch
 
 from . import _lib
-from ._lib import F3RError, check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, work_device
 
 _REQUIRED = ("pts3d_local", "conf_local", "pts3d_in_other_view", "conf")
 
@@ -21,10 +21,8 @@ def align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=0, return_
                 raise ValueError(msg)  # same type and text as the reference (:441-449)
     if len(preds) == 0:
         return preds
-    dev = preds[0]["pts3d_local"].device
-    if dev.type != "cuda":
-        raise F3RError(f"fast3r_amd.align_local_pts3d_to_global runs on the ROCm GPU (preds are on {dev}); keep the output of "
-                       "Fast3R.forward on the device, or move it back with .to('cuda') -- there is no CPU fallback")
+    home = preds[0]["pts3d_local"].device  # CPU preds (what `inference()` returns) are uploaded here and the result comes back there
+    dev = work_device(preds[0]["pts3d_local"], "preds")
     B = preds[0]["pts3d_local"].shape[0]
     q = float(min_conf_thr_percentile) / 100.0
     # views of one resolution are batched into one launch; mixed resolutions give one launch per distinct (H, W)
@@ -34,9 +32,9 @@ def align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=0, return_
     transforms = [None] * len(preds)
     for (H, W), idxs in groups.items():
         npix, n_prob = H * W, len(idxs) * B
-        loc = torch.stack([preds[i]["pts3d_local"].float() for i in idxs]).contiguous()          # (n, B, H, W, 3)
-        glo = torch.stack([preds[i]["pts3d_in_other_view"].float() for i in idxs]).contiguous()
-        conf = torch.stack([preds[i]["conf"].float() for i in idxs]).contiguous()                  # (n, B, H, W)
+        loc = torch.stack([preds[i]["pts3d_local"].float() for i in idxs]).to(dev).contiguous()          # (n, B, H, W, 3)
+        glo = torch.stack([preds[i]["pts3d_in_other_view"].float() for i in idxs]).to(dev).contiguous()
+        conf = torch.stack([preds[i]["conf"].float() for i in idxs]).to(dev).contiguous()                  # (n, B, H, W)
         valid = None
         if any("valid_mask" in views[i] for i in idxs):
             valid = torch.stack([views[i]["valid_mask"].to(dev) if "valid_mask" in views[i]
@@ -45,9 +43,10 @@ def align_local_pts3d_to_global(preds, views, min_conf_thr_percentile=0, return_
         rts = torch.empty((n_prob, 13), dtype=torch.float32, device=dev)
         ws_bytes = _lib.lib().f3r_align_workspace_bytes(n_prob)
         ws = torch.empty((ws_bytes // 8,), dtype=torch.float64, device=dev)
-        check(_lib.lib().f3r_align_local_to_global(ptr(conf), ptr(loc), ptr(glo), ptr(valid), ptr(out), ptr(rts), None, ptr(ws),
-                                                   ws_bytes, n_prob, npix, q, stream_ptr()), "f3r_align_local_to_global")
-        rts = rts.view(len(idxs), B, 13)
+        with torch.cuda.device(dev):
+            check(_lib.lib().f3r_align_local_to_global(ptr(conf), ptr(loc), ptr(glo), ptr(valid), ptr(out), ptr(rts), None, ptr(ws),
+                                                       ws_bytes, n_prob, npix, q, stream_ptr()), "f3r_align_local_to_global")
+        rts, out = rts.view(len(idxs), B, 13).to(home), out.to(home)
         for j, i in enumerate(idxs):
             preds[i]["pts3d_local_aligned_to_global"] = out[j]
             transforms[i] = rts[j]

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // thread = 8 channels of one output pixel.  src = dst * (in-1)/(out_full-1), out_full = 2*in (F.interpolate
 // scale_factor=2, align_corners=True); the output may be cropped to (oh, ow).
 template <class T>
-__global__ void upsample2x_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int h, int w, int C, int oh,
-                                  int ow, int64_t n_items) {
+__global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ in_lo, uint16_t* __restrict__ out,
+                                  uint16_t* __restrict__ out_lo, int B, int h, int w, int C, int oh, int ow, int64_t n_items) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const int cv = C / 8;
@@ -115,41 +115,52 @@ __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, uint16_t* __r
   const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
   const float ly = fy - (float)y0, lx = fx - (float)x0;
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const uint16_t* base = in + (int64_t)b * h * w * C + c8 * 8;
-  const u32x4 p00 = *(const u32x4*)(base + ((int64_t)y0 * w + x0) * C);
-  const u32x4 p01 = *(const u32x4*)(base + ((int64_t)y0 * w + x1) * C);
-  const u32x4 p10 = *(const u32x4*)(base + ((int64_t)y1 * w + x0) * C);
-  const u32x4 p11 = *(const u32x4*)(base + ((int64_t)y1 * w + x1) * C);
-  u32x4 o;
+  const int64_t boff = (int64_t)b * h * w * C + c8 * 8;
+  const int64_t o00 = boff + ((int64_t)y0 * w + x0) * C, o01 = boff + ((int64_t)y0 * w + x1) * C;
+  const int64_t o10 = boff + ((int64_t)y1 * w + x0) * C, o11 = boff + ((int64_t)y1 * w + x1) * C;
+  const u32x4 p00 = *(const u32x4*)(in + o00), p01 = *(const u32x4*)(in + o01), p10 = *(const u32x4*)(in + o10), p11 = *(const u32x4*)(in + o11);
+  u32x4 q00 = {0u, 0u, 0u, 0u}, q01 = q00, q10 = q00, q11 = q00;  // low planes (a zero word is +0.0 in both 16-bit formats)
+  if (in_lo) {
+    q00 = *(const u32x4*)(in_lo + o00); q01 = *(const u32x4*)(in_lo + o01); q10 = *(const u32x4*)(in_lo + o10); q11 = *(const u32x4*)(in_lo + o11);
+  }
+  u32x4 o, ol;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     // torch's upsample_bilinear2d: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
-    const float a = hy * (hx * lo_f<T>(p00[k]) + lx * lo_f<T>(p01[k])) + ly * (hx * lo_f<T>(p10[k]) + lx * lo_f<T>(p11[k]));
-    const float bq = hy * (hx * hi_f<T>(p00[k]) + lx * hi_f<T>(p01[k])) + ly * (hx * hi_f<T>(p10[k]) + lx * hi_f<T>(p11[k]));
+    const float a = hy * (hx * (lo_f<T>(p00[k]) + lo_f<T>(q00[k])) + lx * (lo_f<T>(p01[k]) + lo_f<T>(q01[k]))) +
+                    ly * (hx * (lo_f<T>(p10[k]) + lo_f<T>(q10[k])) + lx * (lo_f<T>(p11[k]) + lo_f<T>(q11[k])));
+    const float bq = hy * (hx * (hi_f<T>(p00[k]) + hi_f<T>(q00[k])) + lx * (hi_f<T>(p01[k]) + hi_f<T>(q01[k]))) +
+                     ly * (hx * (hi_f<T>(p10[k]) + hi_f<T>(q10[k])) + lx * (hi_f<T>(p11[k]) + hi_f<T>(q11[k])));
     o[k] = pack2<T>(a, bq);
+    ol[k] = pack2<T>(a - lo_f<T>(o[k]), bq - hi_f<T>(o[k]));
   }
   *(u32x4*)(out + pix * C + c8 * 8) = o;
+  if (out_lo) *(u32x4*)(out_lo + pix * C + c8 * 8) = ol;
 }
 
 // ------------------------------------------------------------------------------------------ final 1x1 conv + postprocess
 // thread = one pixel: 4 dot products over Cin (weights through LDS), then
 //   d = |xyz|, pts = xyz / max(d, 1e-8) * expm1(d), conf = vmin + min(exp(c), vmax - vmin)   (postprocess.py:32-61)
 template <class T>
-__global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ pts, float* __restrict__ conf,
-                                                        int64_t npix, int Cin, float vmin, float vmax) {
-  extern __shared__ float wsh[];  // [4][Cin]
-  for (int i = threadIdx.x; i < 4 * Cin; i += blockDim.x) wsh[i] = w[i];
+__global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_lo,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int n_out,
+                                                        float* __restrict__ pts, float* __restrict__ conf, int64_t npix, int Cin,
+                                                        float vmin, float vmax) {
+  extern __shared__ float wsh[];  // [4][Cin]; row 3 is zero when the head has no confidence channel (n_out == 3)
+  for (int i = threadIdx.x; i < 4 * Cin; i += blockDim.x) wsh[i] = i < n_out * Cin ? w[i] : 0.f;
   __syncthreads();
   const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= npix) return;
-  float a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = bias[3];
+  float a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = n_out > 3 ? bias[3] : 0.f;
   const uint16_t* xp = x + pix * Cin;
+  const uint16_t* xl = x_lo ? x_lo + pix * Cin : nullptr;
   for (int c = 0; c < Cin; c += 8) {
     const u32x4 v = *(const u32x4*)(xp + c);
+    u32x4 vl = {0u, 0u, 0u, 0u};
+    if (xl) vl = *(const u32x4*)(xl + c);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float f0 = lo_f<T>(v[k]), f1 = hi_f<T>(v[k]);
+      const float f0 = lo_f<T>(v[k]) + lo_f<T>(vl[k]), f1 = hi_f<T>(v[k]) + hi_f<T>(vl[k]);
       const int cc = c + 2 * k;
       a0 = __builtin_fmaf(f0, wsh[cc], a0);            a0 = __builtin_fmaf(f1, wsh[cc + 1], a0);
       a1 = __builtin_fmaf(f0, wsh[Cin + cc], a1);      a1 = __builtin_fmaf(f1, wsh[Cin + cc + 1], a1);
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restri
 }
 
 template <class T>
-__global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n8) {
+__global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, int64_t n8) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const float4v a = *(const float4v*)(in + i * 8);
@@ -177,6 +188,14 @@ __global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__
   o[2] = pack2<T>(b[0], b[1]);
   o[3] = pack2<T>(b[2], b[3]);
   *(u32x4*)(out + i * 8) = o;
+  if (out_lo) {  // lo = lowp(x - float(hi)): hi + lo carries ~2x the significand bits (f3r.h, f3r_split)
+    u32x4 l;
+    l[0] = pack2<T>(a[0] - lo_f<T>(o[0]), a[1] - hi_f<T>(o[0]));
+    l[1] = pack2<T>(a[2] - lo_f<T>(o[1]), a[3] - hi_f<T>(o[1]));
+    l[2] = pack2<T>(b[0] - lo_f<T>(o[2]), b[1] - hi_f<T>(o[2]));
+    l[3] = pack2<T>(b[2] - lo_f<T>(o[3]), b[3] - hi_f<T>(o[3]));
+    *(u32x4*)(out_lo + i * 8) = l;
+  }
 }
 
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -306,9 +325,9 @@ extern "C" int f3r_layernorm(const float* x, const float* gamma, const float* be
   return f3r_check_launch("f3r_layernorm");
 }
 
-extern "C" int f3r_upsample2x(const void* in, void* out, int batch, int h, int w, int C, int out_h, int out_w, int dtype,
-                              f3r_stream_t stream) {
-  F3R_REQUIRE(in && out && al16(in) && al16(out), "f3r_upsample2x: null/misaligned pointer");
+extern "C" int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int out_h,
+                              int out_w, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && al16(in) && al16(out) && al16(in_lo) && al16(out_lo), "f3r_upsample2x: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
   F3R_REQUIRE(C > 0 && C % 8 == 0, "f3r_upsample2x: C %d must be a multiple of 8", C);
   F3R_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= 2 * h && out_w <= 2 * w, "f3r_upsample2x: bad sizes");
@@ -316,37 +335,43 @@ extern "C" int f3r_upsample2x(const void* in, void* out, int batch, int h, int w
   if (n <= 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == F3R_F16)
-    hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, batch, h, w, C, out_h, out_w, n);
+    hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, n);
   else
-    hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, batch, h, w, C, out_h, out_w, n);
+    hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, n);
   return f3r_check_launch("f3r_upsample2x");
 }
 
-extern "C" int f3r_dpt_final(const void* x, const float* w, const float* b, float* pts3d, float* conf, int64_t npix, int Cin,
-                             float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream) {
-  F3R_REQUIRE(x && w && b && pts3d && al16(x), "f3r_dpt_final: null/misaligned pointer");
+extern "C" int f3r_dpt_final(const void* x, const void* x_lo, const float* w, const float* b, int n_out, float* pts3d, float* conf,
+                             int64_t npix, int Cin, float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(x && w && b && pts3d && al16(x) && al16(x_lo), "f3r_dpt_final: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
   F3R_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cin <= 2048, "f3r_dpt_final: Cin %d must be a multiple of 8, <= 2048", Cin);
+  F3R_REQUIRE(n_out == 3 || n_out == 4, "f3r_dpt_final: n_out %d (3 = xyz, 4 = xyz + confidence)", n_out);
+  F3R_REQUIRE(n_out == 4 || conf == nullptr, "f3r_dpt_final: a confidence output needs the 4-channel weight");
   if (npix <= 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   const size_t sh = (size_t)4 * Cin * sizeof(float);
   if (dtype == F3R_F16)
-    hipLaunchKernelGGL(dpt_final_kernel<F16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, w, b, pts3d, conf, npix, Cin, conf_vmin, conf_vmax);
+    hipLaunchKernelGGL(dpt_final_kernel<F16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, pts3d,
+                       conf, npix, Cin, conf_vmin, conf_vmax);
   else
-    hipLaunchKernelGGL(dpt_final_kernel<BF16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, w, b, pts3d, conf, npix, Cin, conf_vmin, conf_vmax);
+    hipLaunchKernelGGL(dpt_final_kernel<BF16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, pts3d,
+                       conf, npix, Cin, conf_vmin, conf_vmax);
   return f3r_check_launch("f3r_dpt_final");
 }
 
-extern "C" int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dtype, f3r_stream_t stream) {
-  F3R_REQUIRE(in && out && al16(in) && al16(out), "f3r_cast_f32_to_lp: null/misaligned pointer");
+extern "C" int f3r_cast_f32_to_lp(const float* in, void* out, void* out_lo, int64_t n, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && al16(in) && al16(out) && al16(out_lo), "f3r_cast_f32_to_lp: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
   F3R_REQUIRE(n >= 0 && n % 8 == 0, "f3r_cast_f32_to_lp: n %lld must be a multiple of 8", (long long)n);
   if (n == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == F3R_F16)
-    hipLaunchKernelGGL(cast_kernel<F16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, n / 8);
+    hipLaunchKernelGGL(cast_kernel<F16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, (uint16_t*)out_lo, n / 8);
   else
-    hipLaunchKernelGGL(cast_kernel<BF16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, n / 8);
+    hipLaunchKernelGGL(cast_kernel<BF16>, dim3(nblk(n / 8, 256)), dim3(256), 0, s, in, (uint16_t*)out, (uint16_t*)out_lo, n / 8);
   return f3r_check_launch("f3r_cast_f32_to_lp");
 }
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "f3r_common.h"
+#include "f3r_gemm_epi.h"
 
 namespace {
 
@@ -25,22 +26,6 @@ constexpr int TILE_ELEMS = 128 * 64;                       // one operand tile
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_ELEMS * 2;     // 2 stages x (A, W) x 16 KB = 64 KB
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
-
-// Exact (erf) GELU, nn.GELU() default (blocks.py:84).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp,
-// five FMAs, one v_exp -- libm's erff costs ~40 instructions per element and made the fc1 epilogue as long as its K loop.
-// Branch-free in the sign so there is no cancellation for x < 0:  gelu(x) = x*Phi(x),  Phi(-|x|) = erfc(|x|/sqrt2)/2.
-// Max abs deviation from fp64 GELU over [-10, 10]: 3.4e-7 (well below the 16-bit rounding of the stored activation).
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  poly = __builtin_fmaf(poly, t, 1.421413741f);
-  poly = __builtin_fmaf(poly, t, -0.284496736f);
-  poly = __builtin_fmaf(poly, t, 0.254829592f);
-  const float u = poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // erfc(z)
-  const float h = 0.5f * x * u;
-  return x >= 0.f ? x - h : h;
-}
 
 struct ConvRow {  // per staged row: output pixel decomposition
   int b, oy, ox;
@@ -120,11 +105,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
     w_row_off[i] = (int64_t)n * p.Kpad;
   }
 
-  const int nk = p.Kpad / BK;
+  // split precision (f3r.h f3r_split): the K loop runs over nseg segments of nk1 tiles; segment 1 multiplies by the low plane of W,
+  // segment 2 takes the low plane of A
+  const int nseg = p.split == F3R_SPLIT_NONE ? 1 : (p.split == F3R_SPLIT_W2 ? 2 : 3);
+  const int Kpad1 = p.split == F3R_SPLIT_NONE ? p.Kpad : p.Kpad / 2;
+  const int nk1 = Kpad1 / BK;
+  const int nk = nseg * nk1;
   const int cpad_tiles = (A_MODE == F3R_A_CONV3X3) ? ((p.conv_C + 63) / 64) : 1;
+  const uint16_t* Alo = (const uint16_t*)p.A_lo;
 
   u32x4 ra[4], rw[4];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt_all) {
+    const int seg = kt_all / nk1;
+    const int kt = kt_all - seg * nk1;
+    const uint16_t* Ag = (seg == 2) ? Alo : (const uint16_t*)p.A;
     if (A_MODE == F3R_A_PLAIN) {
       const int k = kt * BK + sc * 8;
       const bool kok = (k + 8) <= p.K;
@@ -157,7 +151,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
         ra[i] = v;
       }
     }
-    const int kw = kt * BK + sc * 8;
+    const int kw = (seg == 1 ? Kpad1 : 0) + kt * BK + sc * 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -213,70 +207,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
     }
   };
 
-  if constexpr (GLDS == 2) {
-    // ---- 4-stage ring of 32-deep k-tiles, counted vmcnt: three tiles of DMA stay in flight across the barriers, so the
-    // HBM/L2 latency of a tile is covered by the MFMAs of the two tiles in front of it (cdna_hip_programming.md T3/T4).
-    // Stage = A [128][32] | W [128][32] = 16 KB; 64-byte rows; 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3)
-    // (conflict-free for the ds_read_b128 lane groups at this row stride).  A wave-instruction of the DMA fills 16 rows.
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    constexpr int ST = 4, SE = 128 * 32;  // stages, elements per operand per stage
-    uint16_t* const A4 = smem;            // [ST][128][32]
-    uint16_t* const W4 = smem + ST * SE;  // [ST][128][32]
-    const int lrow = lane >> 2, pch = lane & 3;
-    const uint16_t* asrc[2];
-    const uint16_t* wsrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 16 + lrow;
-      const int lch = pch ^ ((-(r >> 2)) & 3);
-      int64_t m = m0 + r;
-      if (m >= p.M) m = p.M - 1;
-      int n = n0 + r;
-      if (n >= p.N) n = p.N - 1;
-      asrc[i] = Ag + m * p.lda + lch * 8;
-      wsrc[i] = Wg + (int64_t)n * p.Kpad + lch * 8;
-    }
-    auto dma = [&](int kt32) {
-      const int st = kt32 & (ST - 1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt32 * 32), (lds_ptr_t)(A4 + st * SE + (wid * 2 + i) * 16 * 32), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt32 * 32), (lds_ptr_t)(W4 + st * SE + (wid * 2 + i) * 16 * 32), 16, 0, 0);
-      }
-    };
-    const int nk32 = p.Kpad / 32;
-    const int offA4 = swap_roles ? 0 : ST * SE, offB4 = swap_roles ? ST * SE : 0;
-    int foff[4];  // fragment offsets inside a stage: row (f*16 + fr) of the wave's 64-row slice, k-chunk fg
-#pragma unroll
-    for (int f = 0; f < 4; ++f) foff[f] = (f * 16 + fr) * 32 + ((fg ^ ((-((f * 16 + fr) >> 2)) & 3)) << 3);
-    const int rbaseA = (swap_roles ? wm : wn) * 64 * 32, rbaseB = (swap_roles ? wn : wm) * 64 * 32;
-#pragma unroll
-    for (int t = 0; t < ST - 1; ++t)
-      if (t < nk32) dma(t);
-    for (int kt = 0; kt < nk32; ++kt) {
-      // tile kt must have landed: at most the DMAs of the (ST-2) younger tiles may still be in flight
-      if (kt + ST - 2 < nk32) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);   // vmcnt(8) = 2 tiles x 4 DMA instructions per wave
-      else if (kt + 1 < nk32) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // tail: one younger tile
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                          // last tile: everything
-      __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed AND every wave is done reading tile kt-1
-      if (kt + ST - 1 < nk32) dma(kt + ST - 1);  // refill the slot tile kt-1 just left
-      const int st = kt & (ST - 1);
-      const uint16_t* ta = smem + offA4 + st * SE + rbaseA;
-      const uint16_t* tb = smem + offB4 + st * SE + rbaseB;
-      typename T::vec8 fa[4], fb[4];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        fa[f] = as_vec8<T>(*(const u32x4*)(ta + foff[f]));
-        fb[f] = as_vec8<T>(*(const u32x4*)(tb + foff[f]));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(fa[i], fb[j], acc[i][j]);
-    }
-    __syncthreads();
-  } else if constexpr (GLDS == 1) {
+  if constexpr (GLDS == 1) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     // wave w issues instructions i = 0..3 for each operand: rows (w*4 + i)*8 + lane/8 of the 128-row tile
@@ -294,13 +225,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
       asrc[i] = Ag + m * p.lda + lch * 8;
       wsrc[i] = Wg + (int64_t)n * p.Kpad + lch * 8;
     }
-    auto dma_tile = [&](int kt, int buf) {
+    const int64_t alo_delta = Alo ? (Alo - Ag) : 0;
+    auto dma_tile = [&](int kt_all, int buf) {
+      const int seg = kt_all / nk1;
+      const int kt = kt_all - seg * nk1;
+      const int64_t ka = (seg == 2 ? alo_delta : 0) + (int64_t)kt * BK;
+      const int kw = (seg == 1 ? Kpad1 : 0) + kt * BK;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint16_t* la = As + buf * TILE_ELEMS + (wid * 4 + i) * 8 * 64;  // wave-uniform: 8 rows x 64 elements per instruction
         uint16_t* lw = Ws + buf * TILE_ELEMS + (wid * 4 + i) * 8 * 64;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * BK), (lds_ptr_t)la, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * BK), (lds_ptr_t)lw, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ka), (lds_ptr_t)la, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kw), (lds_ptr_t)lw, 16, 0, 0);
       }
     };
     dma_tile(0, 0);
@@ -327,151 +263,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
     }
   }
 
-  // ------------------------------------------------------------------ epilogues
-  if (EPI == F3R_EPI_GENERIC || EPI == F3R_EPI_CONVT) {
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-      const int64_t m = m0 + wm * 64 + mf * 16 + fr;
-      if (m >= p.M) continue;
-      int64_t ct_base = 0;
-      if (EPI == F3R_EPI_CONVT) {
-        const int hw = p.ct_h * p.ct_w;
-        const int b = (int)(m / hw);
-        const int rem = (int)(m % hw);
-        const int y = rem / p.ct_w, x = rem % p.ct_w;
-        ct_base = (((int64_t)b * p.ct_h * p.ct_s + (int64_t)y * p.ct_s) * ((int64_t)p.ct_w * p.ct_s) + (int64_t)x * p.ct_s);
-      }
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        const int nb = n0 + wn * 64 + nf * 16 + fg * 4;
-        if (nb >= p.N) continue;
-        float4v v = acc[nf][mf];
-        if (p.bias) {
-          const float4v bb = *(const float4v*)(p.bias + nb);
-          v += bb;
-        }
-        if (p.act == F3R_ACT_GELU) {
-          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        } else if (p.act == F3R_ACT_RELU) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        if (EPI == F3R_EPI_GENERIC) {
-          if (p.rowadd) v += *(const float4v*)(p.rowadd + (m / p.rowadd_div) * (int64_t)p.N + nb);
-          if (p.res_f32) v += *(const float4v*)(p.res_f32 + m * p.ldr_f32 + nb);
-          if (p.res_lp) {
-            const u32x2 r = *(const u32x2*)((const uint16_t*)p.res_lp + m * p.ldr_lp + nb);
-            v[0] += lo_f<T>(r[0]); v[1] += hi_f<T>(r[0]); v[2] += lo_f<T>(r[1]); v[3] += hi_f<T>(r[1]);
-          }
-          if (p.res_lp2) {
-            const u32x2 r = *(const u32x2*)((const uint16_t*)p.res_lp2 + m * p.ldr_lp2 + nb);
-            v[0] += lo_f<T>(r[0]); v[1] += hi_f<T>(r[0]); v[2] += lo_f<T>(r[1]); v[3] += hi_f<T>(r[1]);
-          }
-          if (p.out_f32) *(float4v*)(p.out_f32 + m * p.ldo_f32 + nb) = v;
-          if (p.out_lp) {
-            u32x2 o;
-            o[0] = pack2<T>(v[0], v[1]);
-            o[1] = pack2<T>(v[2], v[3]);
-            *(u32x2*)((uint16_t*)p.out_lp + m * p.ldo_lp + nb) = o;
-          }
-        } else {  // CONVT scatter (pixel shuffle): n = (dy*s + dx)*cout + co
-          const int tap = nb / p.ct_cout;
-          const int co = nb - tap * p.ct_cout;
-          const int dy = tap / p.ct_s, dx = tap - dy * p.ct_s;
-          const int64_t pix = ct_base + (int64_t)dy * ((int64_t)p.ct_w * p.ct_s) + dx;
-          u32x2 o;
-          o[0] = pack2<T>(v[0], v[1]);
-          o[1] = pack2<T>(v[2], v[3]);
-          *(u32x2*)((uint16_t*)p.out_lp + pix * p.ct_cout + co) = o;
-        }
-      }
-    }
-  } else {  // ------------------------------------------------------------ QKV
-    const int part = n0 / Dm;  // 0 q, 1 k, 2 v (block-uniform: Dm % 128 == 0)
-    if (part < 2) {
-      uint16_t* dst = (uint16_t*)(part == 0 ? p.q : p.k);
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf) {
-        const int64_t m = m0 + wm * 64 + mf * 16 + fr;
-        if (m >= p.M) continue;
-        float4v v[4];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          const int nb = n0 + wn * 64 + nf * 16 + fg * 4;
-          v[nf] = acc[nf][mf];
-          if (p.bias) v[nf] += *(const float4v*)(p.bias + nb);
-        }
-        if (p.rope_cos) {
-          // RoPE-2D (pos_embed.py:162-183): the wave's 64 columns are one head; dims [0,32) rotate by the
-          // row position y, [32,64) by the column position x; dim i pairs with i+16 inside each half.
-          const int pos = (int)(m % p.seq_len);
-          const int py = pos / p.rope_w, px = pos - py * p.rope_w;
-          const int64_t grp = m / p.rope_w;  // rope_mode 1: one angle set per row group (LlamaDecoder: per view)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int64_t toff = p.rope_mode == 1 ? grp * 32 + h * 16 : (int64_t)(h == 0 ? py : px) * 16;
-            const float4v c = *(const float4v*)(p.rope_cos + toff + fg * 4);
-            const float4v s = *(const float4v*)(p.rope_sin + toff + fg * 4);
-            const float4v a = v[2 * h], b = v[2 * h + 1];
-            v[2 * h] = a * c - b * s;
-            v[2 * h + 1] = b * c + a * s;
-          }
-        }
-        if (part == 0 && p.q_scale != 0.f) {
-#pragma unroll
-          for (int nf = 0; nf < 4; ++nf) v[nf] *= p.q_scale;
-        }
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          const int nb = n0 + wn * 64 + nf * 16 + fg * 4 - part * Dm;
-          u32x2 o;
-          o[0] = pack2<T>(v[nf][0], v[nf][1]);
-          o[1] = pack2<T>(v[nf][2], v[nf][3]);
-          *(u32x2*)(dst + m * (int64_t)Dm + nb) = o;
-        }
-      }
-    } else {
-      // V, swapped roles: acc[mf][nf], lane = (col n = fr, rows m = fg*4 + j)
-      uint16_t* vt = (uint16_t*)p.vt;
-      const bool vec_ok = ((p.seq_len | p.ldvt) & 3) == 0;
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        const int n = n0 + wn * 64 + nf * 16 + fr;  // < N (Dm % 128 == 0)
-        const int d = n - 2 * Dm;
-        const float bb = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          const int64_t mb = m0 + wm * 64 + mf * 16 + fg * 4;
-          if (mb >= p.M) continue;
-          const float4v v = acc[mf][nf] + bb;
-          if (vec_ok) {  // seq_len % 4 == 0 -> the 4 tokens share a sequence; M % 4 == 0 follows
-            const int64_t s = mb / p.seq_len, t = mb % p.seq_len;
-            u32x2 o;
-            o[0] = pack2<T>(v[0], v[1]);
-            o[1] = pack2<T>(v[2], v[3]);
-            *(u32x2*)(vt + (s * Dm + d) * p.ldvt + t) = o;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int64_t m = mb + j;
-              if (m < p.M) {
-                const int64_t s = m / p.seq_len, t = m % p.seq_len;
-                vt[(s * Dm + d) * p.ldvt + t] = to_lp<T>(v[j]);
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-int g_gemm_glds = -1;  // -1: read F3R_GEMM_GLDS once: 0 register staging, 1 DMA double buffer (BK 64), 2 DMA 4-stage ring (BK 32)
-int glds_mode() {
-  if (g_gemm_glds < 0) {
-    const char* e = getenv("F3R_GEMM_GLDS");
-    g_gemm_glds = e ? atoi(e) : 1;
-  }
-  return g_gemm_glds;
+  // ------------------------------------------------------------------ epilogues (f3r_gemm_epi.h)
+  const int64_t m_base = m0 + wm * 64;
+  const int n_base = n0 + wn * 64;
+  if (swap_roles) gemm_epilogue_vt<T, 4, 4, true>(p, &acc[0][0], m_base, n_base, lane);
+  else gemm_epilogue_default<T, EPI, 4, 4, true>(p, &acc[0][0], m_base, n_base, lane);
 }
 
 template <class T, int A_MODE, int EPI, int GLDS>
@@ -491,18 +287,13 @@ int launch(const f3r_gemm_args& a, hipStream_t stream) {
 
 template <class T>
 int dispatch(const f3r_gemm_args& a, hipStream_t stream) {
-  if (a.a_mode == F3R_A_CONV3X3) {
-    F3R_REQUIRE(a.epi == F3R_EPI_GENERIC, "f3r_gemm: conv3x3 supports only the generic epilogue");
-    return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC, 0>(a, stream);
-  }
-  const int glds = (a.K == a.Kpad && a.M > 0) ? glds_mode() : 0;
+  if (a.a_mode == F3R_A_CONV3X3) return launch<T, F3R_A_CONV3X3, F3R_EPI_GENERIC, 0>(a, stream);
+  // LDS-DMA staging cannot zero-fill a K tail: plain operands with K < Kpad go through registers
+  const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
+  const bool glds = a.K == Kpad1 && a.M > 0;
   switch (a.epi) {
-    case F3R_EPI_GENERIC:
-      return glds == 2 ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 2>(a, stream)
-           : glds == 1 ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 0>(a, stream);
-    case F3R_EPI_QKV:
-      return glds == 2 ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 2>(a, stream)
-           : glds == 1 ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 0>(a, stream);
+    case F3R_EPI_GENERIC: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_GENERIC, 0>(a, stream);
+    case F3R_EPI_QKV: return glds ? launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 1>(a, stream) : launch<T, F3R_A_PLAIN, F3R_EPI_QKV, 0>(a, stream);
     case F3R_EPI_CONVT: return launch<T, F3R_A_PLAIN, F3R_EPI_CONVT, 0>(a, stream);
   }
   f3r_set_error("f3r_gemm: bad epi %d", a.epi);
@@ -519,16 +310,22 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   const f3r_gemm_args& a = *args;
   F3R_REQUIRE(a.A && a.W, "f3r_gemm: null operand");
   F3R_REQUIRE(a.M >= 0 && a.N > 0, "f3r_gemm: bad M/N (%lld, %d)", (long long)a.M, a.N);
-  F3R_REQUIRE(a.Kpad > 0 && a.Kpad % 64 == 0, "f3r_gemm: Kpad %d must be a positive multiple of 64", a.Kpad);
+  F3R_REQUIRE(a.split >= F3R_SPLIT_NONE && a.split <= F3R_SPLIT_X3, "f3r_gemm: bad split %d", a.split);
+  const int planes = a.split ? 2 : 1;
+  F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
+  const int Kpad1 = a.Kpad / planes;
+  F3R_REQUIRE(a.split != F3R_SPLIT_X3 || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 split needs A_lo (16-byte aligned) and no a_relu");
+  F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 3, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
   F3R_REQUIRE(a.N % 4 == 0, "f3r_gemm: N %d must be a multiple of 4", a.N);
   F3R_REQUIRE(al16(a.A) && al16(a.W), "f3r_gemm: A/W must be 16-byte aligned");
   F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_gemm: bad dtype %d", a.dtype);
   if (a.a_mode == F3R_A_PLAIN) {
-    F3R_REQUIRE(a.K > 0 && a.K % 8 == 0 && a.K <= a.Kpad, "f3r_gemm: K %d must be a multiple of 8 and <= Kpad", a.K);
+    F3R_REQUIRE(a.K > 0 && a.K % 8 == 0 && a.K <= Kpad1, "f3r_gemm: K %d must be a multiple of 8 and <= Kpad", a.K);
     F3R_REQUIRE(a.lda % 8 == 0 && a.lda >= a.K, "f3r_gemm: lda %lld must be a multiple of 8 and >= K", (long long)a.lda);
   } else if (a.a_mode == F3R_A_CONV3X3) {
     F3R_REQUIRE(a.conv_C > 0 && a.conv_C % 8 == 0, "f3r_gemm: conv_C %d must be a multiple of 8", a.conv_C);
-    F3R_REQUIRE(a.Kpad == 9 * ((a.conv_C + 63) / 64) * 64, "f3r_gemm: conv Kpad %d != 9*roundup(C,64)", a.Kpad);
+    F3R_REQUIRE(Kpad1 == 9 * ((a.conv_C + 63) / 64) * 64, "f3r_gemm: conv Kpad %d != 9*roundup(C,64) per plane", a.Kpad);
+    F3R_REQUIRE(a.epi == F3R_EPI_GENERIC, "f3r_gemm: conv3x3 supports only the generic epilogue");
     F3R_REQUIRE(a.conv_stride == 1 || a.conv_stride == 2, "f3r_gemm: conv stride %d", a.conv_stride);
     F3R_REQUIRE(a.conv_OH == (a.conv_H + 2 - 3) / a.conv_stride + 1 && a.conv_OW == (a.conv_W + 2 - 3) / a.conv_stride + 1,
                 "f3r_gemm: conv output dims inconsistent");
@@ -544,6 +341,9 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(!a.res_f32 || (al16(a.res_f32) && a.ldr_f32 % 4 == 0), "f3r_gemm: res_f32 alignment/ld");
     F3R_REQUIRE(!a.res_lp || (al8(a.res_lp) && a.ldr_lp % 4 == 0), "f3r_gemm: res_lp alignment/ld");
     F3R_REQUIRE(!a.res_lp2 || (al8(a.res_lp2) && a.ldr_lp2 % 4 == 0), "f3r_gemm: res_lp2 alignment/ld");
+    F3R_REQUIRE((!a.res_lp_lo || (a.res_lp && al8(a.res_lp_lo))) && (!a.res_lp2_lo || (a.res_lp2 && al8(a.res_lp2_lo))), "f3r_gemm: low residual planes need their high planes");
+    F3R_REQUIRE((!a.out_lp_lo || (a.out_lp && al8(a.out_lp_lo))) && (!a.out_relu || (al8(a.out_relu) && a.ldo_lp % 4 == 0 && a.ldo_lp >= a.N)) &&
+                (!a.out_relu_lo || (a.out_relu && al8(a.out_relu_lo))), "f3r_gemm: out_lp_lo / out_relu alignment");
     F3R_REQUIRE(!a.rowadd || (al16(a.rowadd) && a.rowadd_div > 0), "f3r_gemm: rowadd alignment/div");
     F3R_REQUIRE(!a.bias || al16(a.bias), "f3r_gemm: bias alignment");
   } else if (a.epi == F3R_EPI_QKV) {
@@ -560,5 +360,9 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(!a.bias || al16(a.bias), "f3r_gemm: bias alignment");
   }
   hipStream_t s = (hipStream_t)stream;
+  // kernel_sel: 0 = by shape (256-tile kernel for the large, regular problems), 1 = 128-tile kernel, 2 / 3 = 256-tile kernel with /
+  // without the staggered wave rows (measurement; an ineligible shape is an error, not a silent fallback)
+  if (a.kernel_sel >= 2) F3R_REQUIRE(f3r_gemm256_eligible(a), "f3r_gemm: kernel_sel %d but the shape is not eligible for the 256-tile kernel", a.kernel_sel);
+  if (a.kernel_sel >= 2 || (a.kernel_sel == 0 && f3r_gemm256_eligible(a))) return f3r_gemm256_launch(a, s, a.kernel_sel != 3);
   return a.dtype == F3R_F16 ? dispatch<F16>(a, s) : dispatch<BF16>(a, s);
 }

@@ -15,6 +15,8 @@ residual stream, LayerNorm statistics, softmax and post-processing are fp32; GEM
 """
 import math
 import time
+import warnings
+from collections import OrderedDict
 from copy import deepcopy
 
 import numpy as np
@@ -287,18 +289,18 @@ def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 
 
-def _pack_block(blk: _Block, lp):
+def _pack_block(blk: _Block, lp, split=False):
     p = _PackedBlock()
     p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
     p.eps = blk.norm1.eps
-    p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp), _f32(blk.attn.qkv.bias)
-    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp), _f32(blk.attn.proj.bias)
-    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp), _f32(blk.mlp.fc1.bias)
-    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp), _f32(blk.mlp.fc2.bias)
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp, split), _f32(blk.attn.qkv.bias)
+    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp, split), _f32(blk.attn.proj.bias)
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, split), _f32(blk.mlp.fc1.bias)
+    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp, split), _f32(blk.mlp.fc2.bias)
     return p
 
 
-def _pack_llama_block(blk: _LlamaBlock, n_heads, lp):
+def _pack_llama_block(blk: _LlamaBlock, n_heads, lp, split=False):
     """LlamaDecoder layer -> the same packed fields as a ViT block: [wq; wk; wv] as one QKV matrix (q / k rows permuted per head, see
     _ROPE_PERM), [w1; w3] stacked for one up-projection GEMM, no biases, RMSNorm weights."""
     p = _PackedBlock()
@@ -307,12 +309,12 @@ def _pack_llama_block(blk: _LlamaBlock, n_heads, lp):
     p.eps = blk.attention_norm.eps
     perm = torch.tensor([h * 64 + d for h in range(n_heads) for d in _ROPE_PERM])
     wq, wk, wv = (m.weight.detach().float() for m in (blk.attention.wq, blk.attention.wk, blk.attention.wv))
-    p.qkv_w, p.qkv_b = ops.pack_linear_weight(torch.cat([wq[perm], wk[perm], wv], dim=0), lp), None
-    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attention.wo.weight.detach().float(), lp), None
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(torch.cat([wq[perm], wk[perm], wv], dim=0), lp, split), None
+    p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attention.wo.weight.detach().float(), lp, split), None
     w1, w3 = blk.feed_forward.w1.weight.detach().float(), blk.feed_forward.w3.weight.detach().float()
     p.swiglu_hidden = w1.shape[0]
-    p.fc1_w, p.fc1_b = ops.pack_linear_weight(torch.cat([w1, w3], dim=0), lp), None
-    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.feed_forward.w2.weight.detach().float(), lp), None
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(torch.cat([w1, w3], dim=0), lp, split), None
+    p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.feed_forward.w2.weight.detach().float(), lp, split), None
     return p
 
 
@@ -320,27 +322,29 @@ class _PackedHead:
     pass
 
 
-def _pack_head(head: PixelwiseTaskWithDPT, lp):
+def _pack_head(head: PixelwiseTaskWithDPT, lp, split=False):
     d = head.dpt
     h = _PackedHead()
     ap = d.act_postprocess
-    h.a_w = [ops.pack_linear_weight(ap[i][0].weight.detach().float(), lp) for i in range(4)]
+    lin = lambda w: ops.pack_linear_weight(w.detach().float(), lp, split)
+    c33 = lambda w: ops.pack_conv3x3_weight(w.detach().float(), lp, split)
+    h.a_w = [lin(ap[i][0].weight) for i in range(4)]
     h.a_b = [_f32(ap[i][0].bias) for i in range(4)]
-    h.t0_w, h.t0_b = ops.pack_convT_weight(ap[0][1].weight.detach().float(), ap[0][1].bias.detach(), lp)
-    h.t1_w, h.t1_b = ops.pack_convT_weight(ap[1][1].weight.detach().float(), ap[1][1].bias.detach(), lp)
-    h.c3_w, h.c3_b = ops.pack_conv3x3_weight(ap[3][1].weight.detach().float(), lp), _f32(ap[3][1].bias)
-    h.rn_w = [ops.pack_conv3x3_weight(getattr(d.scratch, f"layer{i + 1}_rn").weight.detach().float(), lp) for i in range(4)]
+    h.t0_w, h.t0_b = ops.pack_convT_weight(ap[0][1].weight.detach().float(), ap[0][1].bias.detach(), lp, split)
+    h.t1_w, h.t1_b = ops.pack_convT_weight(ap[1][1].weight.detach().float(), ap[1][1].bias.detach(), lp, split)
+    h.c3_w, h.c3_b = c33(ap[3][1].weight), _f32(ap[3][1].bias)
+    h.rn_w = [c33(getattr(d.scratch, f"layer{i + 1}_rn").weight) for i in range(4)]
     h.ref = []
     for i in range(1, 5):
         r = getattr(d.scratch, f"refinenet{i}")
         h.ref.append(dict(
-            u1c1=(ops.pack_conv3x3_weight(r.resConfUnit1.conv1.weight.detach().float(), lp), _f32(r.resConfUnit1.conv1.bias)),
-            u1c2=(ops.pack_conv3x3_weight(r.resConfUnit1.conv2.weight.detach().float(), lp), _f32(r.resConfUnit1.conv2.bias)),
-            u2c1=(ops.pack_conv3x3_weight(r.resConfUnit2.conv1.weight.detach().float(), lp), _f32(r.resConfUnit2.conv1.bias)),
-            u2c2=(ops.pack_conv3x3_weight(r.resConfUnit2.conv2.weight.detach().float(), lp), _f32(r.resConfUnit2.conv2.bias)),
-            out=(ops.pack_linear_weight(r.out_conv.weight.detach().float(), lp), _f32(r.out_conv.bias))))
-    h.h0_w, h.h0_b = ops.pack_conv3x3_weight(d.head[0].weight.detach().float(), lp), _f32(d.head[0].bias)
-    h.h2_w, h.h2_b = ops.pack_conv3x3_weight(d.head[2].weight.detach().float(), lp), _f32(d.head[2].bias)
+            u1c1=(c33(r.resConfUnit1.conv1.weight), _f32(r.resConfUnit1.conv1.bias)),
+            u1c2=(c33(r.resConfUnit1.conv2.weight), _f32(r.resConfUnit1.conv2.bias)),
+            u2c1=(c33(r.resConfUnit2.conv1.weight), _f32(r.resConfUnit2.conv1.bias)),
+            u2c2=(c33(r.resConfUnit2.conv2.weight), _f32(r.resConfUnit2.conv2.bias)),
+            out=(lin(r.out_conv.weight), _f32(r.out_conv.bias))))
+    h.h0_w, h.h0_b = c33(d.head[0].weight), _f32(d.head[0].bias)
+    h.h2_w, h.h2_b = c33(d.head[2].weight), _f32(d.head[2].bias)
     h.h4_w = d.head[4].weight.detach().float().reshape(d.num_channels, -1).contiguous()
     h.h4_b = _f32(d.head[4].bias)
     h.dims = d.layer_dims
@@ -351,11 +355,13 @@ def _pack_head(head: PixelwiseTaskWithDPT, lp):
 
 # ======================================================================================= the model
 class _GraphCache:
-    """Captured forwards by scene shape (see Fast3R.enable_graphs)."""
+    """Captured forwards by scene shape (see Fast3R.enable_graphs); least-recently-used shapes are dropped beyond `max_entries`
+    (every entry pins a private memory pool the size of a forward's activations)."""
 
     def __init__(self):
         self.max_views = 64
-        self.entries = {}
+        self.max_entries = 8
+        self.entries = OrderedDict()
         self.seen = set()
 
     def clear(self):
@@ -368,11 +374,10 @@ class _GraphCache:
         shapes = {tuple(i.shape) for i in imgs}
         if len(views) > self.max_views or len(shapes) != 1 or any(i.dtype != torch.float32 for i in imgs):
             return None
-        for v in views:  # the eager path's argument check (utils/misc.py:69), done on the host before replay
-            ts = v.get("true_shape", None)
-            if ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
-                raise AssertionError("true_shape must be all identical")
-        key = (len(views), tuple(imgs[0].shape), str(dev), model.compute_dtype, model.max_parallel_views_for_head, model.training)
+        if model._orientation_plan(views)["any_portrait"]:  # also the eager path's argument checks (utils/misc.py:69), done on the host
+            return None
+        key = (len(views), tuple(imgs[0].shape), str(dev), model.compute_dtype, model.precision, model.max_parallel_views_for_head,
+               model.training, model._params_version())
         dec = model.decoder
         B = imgs[0].shape[0]
         if key not in self.entries:
@@ -389,6 +394,9 @@ class _GraphCache:
             with torch.cuda.graph(graph):
                 outs = model._forward_eager(static_views, False, _emb_rows=static_emb)
             self.entries[key] = (graph, static_imgs, static_emb, outs)
+            while len(self.entries) > self.max_entries:
+                self.entries.popitem(last=False)
+        self.entries.move_to_end(key)
         graph, static_imgs, static_emb, outs = self.entries[key]
         for t, i in zip(static_imgs, imgs):
             t.copy_(i, non_blocking=True)
@@ -409,13 +417,23 @@ except Exception:  # pragma: no cover  (huggingface_hub is a requirement of the 
 
 class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch/fast3r", tags=["image-to-3d"]):
     """`Fast3R.from_pretrained("jedyang97/Fast3R_ViT_Large_512")` (or a local directory holding config.json + model.safetensors) works as
-    in the reference: the mixin reads the three *_args dicts from config.json, builds the model and loads the state dict (identical keys)."""
+    in the reference: the mixin reads the three *_args dicts from config.json, builds the model and loads the state dict (identical keys).
+
+    Two arguments the reference does not have (both optional):
+      compute_dtype   the 16-bit MFMA operand type (torch.float16 default, torch.bfloat16);
+      precision       "fast": every GEMM / conv operand is ONE 16-bit number.
+                      "high": split-precision operands (f3r.h f3r_split) -- transformer weights as hi + lo planes (2 MFMA passes per
+                      GEMM), both operands of the DPT heads as hi + lo planes (3 passes, activations kept as two planes in HBM);
+                      attention unchanged.  With fp16 this brings the stress fixture inside 1e-3 of the fp32 reference (DESIGN.md
+                      section 4, oracle/precision_study.py) at ~1.15x the time of "fast" at N=320."""
 
     def __init__(self, encoder_args: dict, decoder_args: dict, head_args: dict, freeze="none",
-                 compute_dtype: torch.dtype = torch.float16):
+                 compute_dtype: torch.dtype = torch.float16, precision: str = "fast"):
         super().__init__()
         if isinstance(compute_dtype, str):  # config.json round trip stores the dtype as text
             compute_dtype = getattr(torch, compute_dtype.replace("torch.", ""))
+        if precision not in ("fast", "high"):
+            raise ValueError(f"precision must be 'fast' or 'high', got {precision!r}")
         self.encoder_args = dict(encoder_args)
         self.build_encoder(encoder_args)
         self.decoder_args = dict(decoder_args)
@@ -425,6 +443,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         self.max_parallel_views_for_head = 25  # fast3r.py:68
         self.max_parallel_views_for_encoder = 128  # the reference chunks at 400 (fast3r.py:250); bounds the workspace
         self.compute_dtype = compute_dtype
+        self.precision = precision
         self.sharding = None  # set by shard_views(): view-sharded multi-GPU execution (fast3r_amd/dist.py)
         self.debug_taps = None  # set to a dict to capture the lowp DPT inputs (hooks 0, L/2, 3L/4, L) per sample
         self.use_graphs = False  # enable_graphs(): hipGraph replay of small scenes
@@ -465,6 +484,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                                        patch_size=head_args["patch_size"])
         self.downstream_head = mk()
         self.downstream_head_local = mk() if head_args.get("with_local_head", False) else None
+        # transpose_to_landscape(head, activate=landscape_only) (fast3r.py:123-130, dust3r/utils/misc.py:61-106): see _orientation_plan
         self.landscape_only = bool(head_args.get("landscape_only", False))
 
     # `.head` / `.local_head` of the reference are closures over the two heads (utils/misc.py:61-106), not modules:
@@ -535,9 +555,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return self
 
     # ---------------------------------------------------------------- packed weights
-    def load_state_dict(self, ckpt, **kw):
+    def load_state_dict(self, state_dict, strict=True, assign=False):
         self.invalidate_packed_weights()
-        return super().load_state_dict(ckpt, **kw)
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def _apply(self, fn, *a, **k):
         self.invalidate_packed_weights()
@@ -548,28 +568,36 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if getattr(self, "_graphs", None) is not None:
             self._graphs.clear()  # captured graphs hold pointers into the packed weights
 
+    def _params_version(self):
+        """Sum of the in-place version counters of all parameters: `p.data.copy_`, a submodule's own load_state_dict or an optimizer
+        step change it, so packed (device, 16-bit) weights and captured graphs built from older values are never reused."""
+        return sum(p._version for p in self.parameters())
+
     def _pack(self, device):
         lp = self.compute_dtype
-        key = (lp, str(device))
+        key = (lp, self.precision, str(device), self._params_version())
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
+        if self._packed is not None:
+            self._graphs.clear()
         enc, dec = self.encoder, self.decoder
+        hp = self.precision == "high"
         pk = dict(key=key)
-        pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp)
+        pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
         pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
-        pk["enc"] = [_pack_block(b, lp) for b in enc.enc_blocks]
+        pk["enc"] = [_pack_block(b, lp, hp) for b in enc.enc_blocks]
         pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
-        pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp)
+        pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
         if isinstance(dec, LlamaDecoder):
-            pk["dec"] = [_pack_llama_block(b, dec.num_heads, lp) for b in dec.layers]
+            pk["dec"] = [_pack_llama_block(b, dec.num_heads, lp, hp) for b in dec.layers]
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
-            pk["dec"] = [_pack_block(b, lp) for b in dec.dec_blocks]
+            pk["dec"] = [_pack_block(b, lp, hp) for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
-        pk["head"] = _pack_head(self.downstream_head, lp)
-        pk["head_local"] = _pack_head(self.downstream_head_local, lp) if self.downstream_head_local is not None else None
+        pk["head"] = _pack_head(self.downstream_head, lp, hp)
+        pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None
         self._packed = pk
         return pk
 
@@ -581,8 +609,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
 
     # ---------------------------------------------------------------- transformer block on the HIP kernels
     def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None):
-        """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239."""
+        """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
+        with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single."""
         lp = self.compute_dtype
+        sp = "w2" if self.precision == "high" else None
         D = x.shape[1]
         T = x.shape[0]
         h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, rms=pb.rms)
@@ -594,7 +624,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 torch.empty((n_seq, D, ldvt), dtype=lp, device=x.device)
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
-        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode)
+        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp)
         o = h  # LN output is dead: reuse as the attention output buffer
         if kv_exchange is None:
             ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * D, D * ldvt)], tq=seq_len, batch=n_seq,
@@ -613,19 +643,28 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             else:
                 kv_exchange.finish()
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True)
-        ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x)
+        ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
-            _, ab = ops.gemm(h2, pb.fc1_w, want_lp=True)
+            _, ab = ops.gemm(h2, pb.fc1_w, want_lp=True, split=sp)
             hid = ops.silu_mul(ab, pb.swiglu_hidden)
         else:
-            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True)
-        ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x)
+            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, split=sp)
+        ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split=sp)
         return x
 
+    def _planes(self, x_f32):
+        """fp32 -> the operand format of the DPT heads: (hi, lo) planes in "high" precision, (lowp, None) otherwise."""
+        if self.precision == "high":
+            return ops.cast_lp(x_f32, self.compute_dtype, want_lo=True)
+        return ops.cast_lp(x_f32, self.compute_dtype), None
+
     def _encode(self, imgs, pk):
-        """CroCoEncoder.forward (fast3r.py:549-559) for a batch of same-size images -> lowp enc_norm output [NV*P][D]."""
+        """CroCoEncoder.forward (fast3r.py:549-559) for a batch of same-size images -> enc_norm output [NV*P][D] as (lowp, low plane or
+        None).  The high plane alone feeds decoder_embed; both planes are hook 0 of the heads in "high" precision."""
         lp = self.compute_dtype
+        hp = self.precision == "high"
+        sp = "w2" if hp else None
         enc = self.encoder
         NV, _, H, W = imgs.shape
         ps = enc.patch_size
@@ -635,60 +674,172 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         P = h * w
         rope = self._rope(max(h, w), imgs.device) + (w,)
         out = torch.empty((NV * P, enc.embed_dim), dtype=lp, device=imgs.device)
+        out_lo = torch.empty_like(out) if hp else None
         step = max(1, self.max_parallel_views_for_encoder)
         for v0 in range(0, NV, step):
             v1 = min(NV, v0 + step)
             a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp)
-            x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True)
+            x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True, split=sp)
             for pb in pk["enc"]:
                 self._block(x, pb, enc.num_heads, (enc.embed_dim // enc.num_heads) ** -0.5, P, v1 - v0, rope)
             w_, b_, eps = pk["enc_norm"]
-            ops.layernorm(x, w_, b_, eps, lp, out_lp=out[v0 * P:v1 * P])
-        return out, P, (h, w)
+            if hp:
+                _, y = ops.layernorm(x, w_, b_, eps, lp, want_lp=False, want_f32=True)
+                hi, lo = ops.cast_lp(y, lp, want_lo=True)
+                out[v0 * P:v1 * P].copy_(hi)
+                out_lo[v0 * P:v1 * P].copy_(lo)
+            else:
+                ops.layernorm(x, w_, b_, eps, lp, out_lp=out[v0 * P:v1 * P])
+        return out, out_lo, P, (h, w)
+
+    # ---------------------------------------------------------------- fusion decoder on the HIP kernels
+    def _decode_sample(self, pk, enc_hi, enc_lo, Ps, emb_rows, v_lo, kvx):
+        """Fast3RDecoder.forward / LlamaDecoder.forward (fast3r.py:768-808 / :924-966) for ONE sample: enc_hi [T_loc][Denc] lowp (the
+        local views' encoder tokens, view after view; enc_lo = their low plane or None), Ps = tokens per local view, emb_rows
+        (N_total, D) fp32 = the image-id rows of ALL views (this rank's are [v_lo, v_lo + len(Ps))).  Returns the 4 hooked
+        outputs (fast3r.py:148) as (plane, low plane or None) pairs."""
+        dec = self.decoder
+        lp = self.compute_dtype
+        sp = "w2" if self.precision == "high" else None
+        dev = enc_hi.device
+        L = dec.depth
+        llama = isinstance(dec, LlamaDecoder)
+        hd_ = int(self.decoder_args["depth"]) if llama else L  # the heads read decoder_args["depth"] for both decoder types (fast3r.py:137-148)
+        hooks = [0, hd_ * 2 // 4, hd_ * 3 // 4, hd_]
+        scale = dec.attention_scale(self.training)
+        D = dec.embed_dim
+        T_loc, n_loc = sum(Ps), len(Ps)
+        x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
+        if llama:
+            # embed; per layer add view0_embed to the tokens of view 0, then the block with the rotary angles of each token's view;
+            # outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
+            ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], out_f32=x, split=sp)
+            rows = emb_rows[v_lo:v_lo + n_loc]                              # (n_loc, 64) = [cos (32) | sin (32)] of each view's id
+            if len(set(Ps)) == 1:
+                rope = (rows[:, :32].contiguous(), rows[:, 32:].contiguous(), Ps[0])
+            else:  # mixed resolutions: one table row per token
+                per_tok = rows.repeat_interleave(torch.tensor(Ps, device=dev), dim=0)
+                rope = (per_tok[:, :32].contiguous(), per_tok[:, 32:].contiguous(), 1)
+            view0_rows = Ps[0] if v_lo == 0 else 0                          # view 0 lives on the rank that owns the first views
+            taps = {}
+            if 0 in hooks:
+                taps[0] = self._planes(x)
+            for li, pb in enumerate(pk["dec"]):
+                ops.rows_add(x, pk["view0"], view0_rows)
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx)
+                if (li + 1) in hooks and (li + 1) != L:
+                    taps[li + 1] = self._planes(x)
+            if L in hooks:
+                w_, b_, eps = pk["dec_norm"]
+                if self.precision == "high":
+                    _, y = ops.layernorm(x, w_, None, eps, lp, want_lp=False, want_f32=True, rms=True)
+                    taps[L] = self._planes(y)
+                else:
+                    taps[L] = (ops.layernorm(x, w_, None, eps, lp, rms=True)[0], None)
+        else:
+            if len(set(Ps)) == 1:
+                ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo:v_lo + n_loc].contiguous(), rowadd_div=Ps[0], out_f32=x, split=sp)
+            else:
+                r0 = 0
+                for i in range(n_loc):
+                    ops.gemm(enc_hi[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo + i:v_lo + i + 1].contiguous(),
+                             rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]], split=sp)
+                    r0 += Ps[i]
+            taps = {0: (enc_hi, enc_lo)}
+            for li, pb in enumerate(pk["dec"]):
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
+                if (li + 1) in hooks[1:3]:
+                    taps[li + 1] = self._planes(x)
+            w_, b_, eps = pk["dec_norm"]
+            if self.precision == "high":
+                _, y = ops.layernorm(x, w_, b_, eps, lp, want_lp=False, want_f32=True)
+                taps[L] = self._planes(y)
+            else:
+                taps[L] = (ops.layernorm(x, w_, b_, eps, lp)[0], None)
+        return [taps[hk] for hk in hooks]
+
+    @torch.no_grad()
+    def decode_tokens(self, enc_tokens, tokens_per_view, image_ids):
+        """The fusion decoder alone (BASELINE configs[1]: "fusion transformer only, frozen random encoder"): enc_tokens lowp
+        [sum(tokens_per_view)][enc_embed_dim] on the GPU, image_ids (N,) or (1, N) long -> the 4 hooked outputs, lowp [T][D]."""
+        dev = enc_tokens.device
+        if dev.type != "cuda":
+            raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (tokens are on {dev}); there is no CPU fallback")
+        with torch.cuda.device(dev):
+            pk = self._pack(dev)
+            ids = torch.as_tensor(image_ids).reshape(-1).to(dev)
+            assert ids.numel() == len(tokens_per_view)
+            emb_rows = self.decoder.image_idx_emb.to(dev)[ids]
+            enc_lo = None
+            if self.precision == "high" and not isinstance(self.decoder, LlamaDecoder):
+                enc_lo = torch.zeros_like(enc_tokens)
+            out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None)
+            return [t[0] for t in out]
 
     # ---------------------------------------------------------------- DPT head on the HIP kernels
     def _dpt(self, hk, toks, nv, gh, gw):
         """DPTOutputAdapter_fix.forward + postprocess (heads/dpt_head.py:42-129) for nv same-size views.
-        toks: the 4 hooked token matrices, lowp [nv*gh*gw][C].  Everything stays NHWC lowp; accumulation fp32."""
-        P = gh * gw
+        toks: the 4 hooked token matrices as (lowp [nv*gh*gw][C], low plane or None) pairs.  Activations stay NHWC lowp (two planes
+        each in "high" precision, every conv then runs split="x3"); accumulation fp32.  A ResidualConvUnit reads relu(x) for its first
+        conv and x for its skip add (dpt_block.py:143-154): the PRODUCER of x writes both (f3r_gemm_args.out_relu), so no conv
+        pre-activates its operand while staging it and all of them can use LDS-DMA."""
+        hp = self.precision == "high"
+        sp = "x3" if hp else None
         ld = hk.dims
 
-        def c1(i):
-            _, y = ops.gemm(toks[i], hk.a_w[i], bias=hk.a_b[i], want_lp=True)
-            return y.view(nv, gh, gw, ld[i])
+        def c1(i):  # act_postprocess[i][0]: 1x1 conv on the tokens
+            r = ops.gemm(toks[i][0], hk.a_w[i], bias=hk.a_b[i], want_lp=True, want_lo=hp, split=sp, a_lo=toks[i][1])
+            return tuple(t.view(nv, gh, gw, ld[i]) for t in r[1:]) if hp else (r[1].view(nv, gh, gw, ld[i]), None)
 
-        l0 = ops.convT(c1(0), hk.t0_w, hk.t0_b, 4, ld[0])                              # dpt_block.py:416-434
-        l1 = ops.convT(c1(1), hk.t1_w, hk.t1_b, 2, ld[1])                              # :436-454
+        def convT(xp, w, b, s, cout):
+            r = ops.convT(xp[0], w, b, s, cout, split=sp, x_lo=xp[1], want_lo=hp)
+            return r if hp else (r, None)
+
+        def conv(xp, w, bias=None, stride=1, act=None, res=None, res2=None, relu_copy=False):
+            """-> {"x": (out, lo), "relu": (relu(out), lo)}"""
+            r = ops.conv3x3(xp[0], w, stride=stride, bias=bias, act=act, split=sp, x_lo=xp[1],
+                            res_lp=None if res is None else res[0], res_lp_lo=None if res is None else res[1],
+                            res_lp2=None if res2 is None else res2[0], res_lp2_lo=None if res2 is None else res2[1],
+                            want_lo=hp, want_relu=relu_copy)
+            if not isinstance(r, dict):
+                return {"x": (r, None)}
+            return {"x": (r["out"], r.get("out_lo")), "relu": (r.get("relu"), r.get("relu_lo"))}
+
+        l0 = convT(c1(0), hk.t0_w, hk.t0_b, 4, ld[0])                                  # dpt_block.py:416-434
+        l1 = convT(c1(1), hk.t1_w, hk.t1_b, 2, ld[1])                                  # :436-454
         l2 = c1(2)                                                                      # :456-464
-        l3 = ops.conv3x3(c1(3), hk.c3_w, stride=2, bias=hk.c3_b)                        # :466-481
-        ls = [ops.conv3x3(l, hk.rn_w[i]) for i, l in enumerate((l0, l1, l2, l3))]       # scratch.layer_rn, no bias
+        l3 = conv(c1(3), hk.c3_w, bias=hk.c3_b, stride=2)["x"]                          # :466-481
+        ls = [conv(l, hk.rn_w[i], relu_copy=True) for i, l in enumerate((l0, l1, l2, l3))]  # scratch.layer_rn, no bias
         del l0, l1, l2, l3
 
-        def rcu(x, c1w, c2w, extra=None):
-            # x + conv2(relu(conv1(relu(x)))) (+ extra): ReLUs fused into the operand staging, adds into the epilogue
-            t = ops.conv3x3(x, c1w[0], bias=c1w[1], a_relu=True)
-            return ops.conv3x3(t, c2w[0], bias=c2w[1], a_relu=True, res_lp=x, res_lp2=extra)
+        def rcu(x, c1w, c2w, extra=None, relu_copy=False):
+            # x + conv2(relu(conv1(relu(x)))) (+ extra); x = {"x": planes, "relu": planes of relu(x)}
+            t = conv(x["relu"], c1w[0], bias=c1w[1], act="relu")["x"]
+            return conv(t, c2w[0], bias=c2w[1], res=x["x"], res2=extra, relu_copy=relu_copy)
 
         def fusion(r, path, skip=None, crop=None):
             # out_conv(up2(RCU2(path + RCU1(skip)))); the 1x1 out_conv commutes exactly with the bilinear
             # interpolation (both linear, weights sum to 1), so it runs BEFORE the upsample on 4x fewer pixels.
             if skip is not None:
-                path = rcu(skip, r["u1c1"], r["u1c2"], extra=path)
-            y = rcu(path, r["u2c1"], r["u2c2"])
-            B, hh, ww, C = y.shape
-            _, z = ops.gemm(y.view(B * hh * ww, C), r["out"][0], bias=r["out"][1], want_lp=True)
-            return ops.upsample2x(z.view(B, hh, ww, C), crop)
+                path = rcu(skip, r["u1c1"], r["u1c2"], extra=path, relu_copy=True)
+            y = rcu(path, r["u2c1"], r["u2c2"])["x"]
+            B, hh, ww, C = y[0].shape
+            g = ops.gemm(y[0].view(B * hh * ww, C), r["out"][0], bias=r["out"][1], want_lp=True, want_lo=hp, split=sp,
+                         a_lo=None if y[1] is None else y[1].view(B * hh * ww, C))
+            z = (g[1].view(B, hh, ww, C), g[2].view(B, hh, ww, C) if hp else None)
+            u = ops.upsample2x(z[0], crop, x_lo=z[1], want_lo=hp)
+            return u if hp else (u, None)
 
-        p4 = fusion(hk.ref[3], ls[3], None, crop=(ls[2].shape[1], ls[2].shape[2]))    # dpt_head.py:69-71
+        p4 = fusion(hk.ref[3], ls[3], None, crop=(ls[2]["x"][0].shape[1], ls[2]["x"][0].shape[2]))  # dpt_head.py:69-71
         p3 = fusion(hk.ref[2], p4, ls[2])
         p2 = fusion(hk.ref[1], p3, ls[1])
         p1 = fusion(hk.ref[0], p2, ls[0])
         del ls, p4, p3, p2
-        y = ops.conv3x3(p1, hk.h0_w, bias=hk.h0_b)                                      # head[0]
+        y = conv(p1, hk.h0_w, bias=hk.h0_b)["x"]                                        # head[0]
         assert hk.patch_size == 16, "head Interpolate scale = patch_size / 8 (dpt_block.py:374): only x2 is fused"
-        y = ops.upsample2x(y)                                                           # head[1]
-        y = ops.conv3x3(y, hk.h2_w, bias=hk.h2_b, act="relu")                          # head[2], head[3]
-        return ops.dpt_final(y, hk.h4_w, hk.h4_b, hk.conf_mode)                         # head[4] + postprocess
+        u = ops.upsample2x(y[0], x_lo=y[1], want_lo=hp)                                 # head[1]
+        y = conv(u if hp else (u, None), hk.h2_w, bias=hk.h2_b, act="relu")["x"]        # head[2], head[3]
+        return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1])           # head[4] + postprocess
 
     # ---------------------------------------------------------------- forward
     def forward(self, views, profiling=False):
@@ -711,43 +862,102 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         self._graphs.max_views = max_views
         return self
 
+    def _orientation_plan(self, views):
+        """Per (view, sample): is the image stored transposed (a portrait picture kept as a landscape tensor)?
+
+        The reference handles aspect ratio in two places: `ManyAR_PatchEmbed` (dust3r/patch_embed.py:41-105) swaps the
+        axes of the samples whose `true_shape` is portrait before the patch convolution, and `transpose_to_landscape(head,
+        activate=landscape_only)` (dust3r/utils/misc.py:61-106) runs the head of those samples on the (W, H) grid and swaps the output
+        back.  With PatchEmbedDust3R / landscape_only=False (what the inference loaders set, utils/checkpoint_utils.py:37-38) neither
+        happens and `true_shape` must be identical for all samples of a view (misc.py:69).  Returns, per view, `enc_swap` (B bools),
+        `head_hw` (B (H, W) pairs: the image size the head predicts at) and `head_swap` (B bools)."""
+        many_ar = self.encoder.patch_embed_cls == "ManyAR_PatchEmbed"
+        plan, any_p = [], False
+        for v in views:
+            img = v["img"]
+            B, H, W = img.shape[0], img.shape[-2], img.shape[-1]
+            ts = v.get("true_shape", None)
+            ts = torch.tensor([[H, W]] * B) if ts is None else torch.as_tensor(ts).cpu().reshape(B, 2).long()
+            portrait = (ts[:, 1] < ts[:, 0]).tolist()
+            if many_ar:
+                assert W >= H, f"img should be in landscape mode, but got {W=} {H=}"  # patch_embed.py:62
+            enc_swap = [bool(p) and many_ar for p in portrait]
+            if self.landscape_only:  # wrapper_yes: by definition the batch is stored in landscape mode, W >= H (misc.py:77-80)
+                Ht, Wt = int(ts.min()), int(ts.max())
+                head_hw = [(Wt, Ht) if p else (Ht, Wt) for p in portrait]
+                head_swap = [bool(p) for p in portrait]
+            else:                    # wrapper_no
+                if not bool((ts[0:1] == ts).all()):
+                    raise AssertionError("true_shape must be all identical")  # utils/misc.py:69
+                head_hw = [tuple(ts[0].tolist())] * B
+                head_swap = [False] * B
+            any_p = any_p or any(enc_swap) or any(head_swap) or any(tuple(hw) != (H, W) for hw in head_hw)
+            plan.append(dict(enc_swap=enc_swap, head_hw=head_hw, head_swap=head_swap))
+        return dict(views=plan, any_portrait=any_p)
+
     def _forward_eager(self, views, profiling=False, _emb_rows=None):
         dev = views[0]["img"].device
         if dev.type != "cuda":
             raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (views are on {dev}); there is no CPU fallback")
+        if any(v["img"].device != dev for v in views) or next(self.parameters()).device != dev:
+            raise F3RError("fast3r_amd.Fast3R: the model and every view must live on the same device")
+        with torch.cuda.device(dev):  # kernels launch on the CURRENT device / stream: make that the tensors' device (ADVICE r1)
+            return self._forward_on_device(views, profiling, _emb_rows, dev)
+
+    def _forward_on_device(self, views, profiling, _emb_rows, dev):
         prof = {} if profiling else None
         lp = self.compute_dtype
         pk = self._pack(dev)
         enc, dec = self.encoder, self.decoder
+        ps = enc.patch_size
         sh = self.sharding
         N_total = len(views)
         v_lo, v_hi = (0, N_total) if sh is None else sh.my_range(N_total)
         if sh is not None and N_total < sh.world:
             raise ValueError(f"view sharding needs at least one view per rank ({N_total} views, {sh.world} ranks)")
         my_views = views[v_lo:v_hi]
+        n_loc = len(my_views)
         B = views[0]["img"].shape[0]
 
-        # ---- encode (fast3r.py:250-296): same-shape views are batched, others go one by one
+        # ---- encode (fast3r.py:250-296): every (view, sample) image, grouped by its (possibly un-transposed) size
         t0 = time.time()
-        shapes = [tuple(v["img"].shape[-2:]) for v in views]
-        for v in views:
-            ts = v.get("true_shape", None)
-            if _emb_rows is None and ts is not None and not bool((torch.as_tensor(ts).cpu()[0:1] == torch.as_tensor(ts).cpu()).all()):
-                raise AssertionError("true_shape must be all identical")  # utils/misc.py:69
-        same = all(s == shapes[0] for s in shapes)
-        feats, Ps, grids = [], [], []
-        if same and len(my_views) > 0:
+        plan = self._orientation_plan(views) if _emb_rows is None else dict(views=[None] * N_total, any_portrait=False)
+        Ps, feats = [], [[None] * B for _ in range(n_loc)]  # feats[i][b] = (hi [P][D], lo or None)
+        if not plan["any_portrait"] and all(tuple(v["img"].shape[-2:]) == tuple(my_views[0]["img"].shape[-2:]) for v in my_views) and n_loc > 0:
             imgs = torch.cat([v["img"] for v in my_views], dim=0).float()
-            f, P, grid = self._encode(imgs, pk)
-            f = f.view(len(my_views), B, P, -1)
-            feats = [f[i] for i in range(len(my_views))]
-            Ps, grids = [P] * len(my_views), [grid] * len(my_views)
+            f, flo, P, grid = self._encode(imgs, pk)
+            f = f.view(n_loc, B, P, -1)
+            flo = None if flo is None else flo.view(n_loc, B, P, -1)
+            for i in range(n_loc):
+                for b in range(B):
+                    feats[i][b] = (f[i, b], None if flo is None else flo[i, b])
+            Ps = [P] * n_loc
+            head_grid = [[grid] * B for _ in range(n_loc)]
+            head_swap = [[False] * B for _ in range(n_loc)]
         else:
-            for v in my_views:
-                f, P, grid = self._encode(v["img"].float().contiguous(), pk)
-                feats.append(f.view(B, P, -1))
-                Ps.append(P)
-                grids.append(grid)
+            groups = {}  # image size as encoded -> [(i, b, image (3, H', W'))]
+            head_grid, head_swap = [], []
+            for i, v in enumerate(my_views):
+                pl = plan["views"][v_lo + i]
+                img = v["img"].float()
+                P_view = (img.shape[-2] // ps) * (img.shape[-1] // ps)
+                Ps.append(P_view)
+                grids_i = []
+                for b in range(B):
+                    im = img[b].transpose(-1, -2) if pl["enc_swap"][b] else img[b]
+                    groups.setdefault(tuple(im.shape[-2:]), []).append((i, b, im))
+                    hh, ww = pl["head_hw"][b]
+                    assert hh % ps == 0 and ww % ps == 0 and (hh // ps) * (ww // ps) == P_view, \
+                        f"true_shape {pl['head_hw'][b]} does not describe the {tuple(img.shape[-2:])} image of view {v_lo + i}"
+                    grids_i.append((hh // ps, ww // ps))
+                head_grid.append(grids_i)
+                head_swap.append(list(pl["head_swap"]))
+            for _, items in groups.items():
+                f, flo, P, _ = self._encode(torch.stack([im for _, _, im in items]).contiguous(), pk)
+                f = f.view(len(items), P, -1)
+                flo = None if flo is None else flo.view(len(items), P, -1)
+                for j, (i, b, _) in enumerate(items):
+                    feats[i][b] = (f[j], None if flo is None else flo[j])
         if profiling:
             torch.cuda.synchronize()
             prof["encode_images_time"] = time.time() - t0
@@ -768,91 +978,55 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if profiling:
             torch.cuda.synchronize()
         t2 = time.time()
-        L = dec.depth
-        llama = isinstance(dec, LlamaDecoder)
-        hd_ = int(self.decoder_args["depth"]) if llama else L  # the heads read decoder_args["depth"] for both decoder types (fast3r.py:137-148)
-        hooks = [0, hd_ * 2 // 4, hd_ * 3 // 4, hd_]
-        scale = dec.attention_scale(self.training)
         D = dec.embed_dim
         T_loc = sum(Ps)
-        n_loc = len(my_views)
-        hook_toks = []  # per sample: [4] lowp [T_loc][C]
+        hook_toks = []  # per sample: [4] (plane [T_loc][C], low plane or None)
         for b in range(B):
-            enc_b = torch.cat([feats[i][b] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b]
-            enc_b = enc_b.contiguous()
-            x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
+            enc_hi = torch.cat([feats[i][b][0] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b][0]
+            enc_hi = enc_hi.contiguous()
+            enc_lo = None
+            if feats[0][b][1] is not None:
+                enc_lo = (torch.cat([feats[i][b][1] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b][1]).contiguous()
             kvx = None if sh is None else sh.make_kv_exchange(T_loc, D, lp, dev)
-            if llama:
-                # LlamaDecoder.forward (fast3r.py:924-966): embed; per layer add view0_embed to the tokens of view 0, then the block with
-                # the rotary angles of each token's view; outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
-                ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], out_f32=x)
-                rows = emb_rows[b, v_lo:v_hi]                                  # (n_loc, 64) = [cos (32) | sin (32)] of each view's id
-                if len(set(Ps)) == 1:
-                    rope = (rows[:, :32].contiguous(), rows[:, 32:].contiguous(), Ps[0])
-                else:  # mixed resolutions: one table row per token
-                    per_tok = rows.repeat_interleave(torch.tensor(Ps, device=dev), dim=0)
-                    rope = (per_tok[:, :32].contiguous(), per_tok[:, 32:].contiguous(), 1)
-                view0_rows = Ps[0] if v_lo == 0 else 0                          # view 0 lives on the rank that owns the first views
-                taps = {}
-                if 0 in hooks:
-                    taps[0] = ops.cast_lp(x, lp)
-                for li, pb in enumerate(pk["dec"]):
-                    ops.rows_add(x, pk["view0"], view0_rows)
-                    self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx)
-                    if (li + 1) in hooks and (li + 1) != L:
-                        taps[li + 1] = ops.cast_lp(x, lp)
-                if L in hooks:
-                    w_, b_, eps = pk["dec_norm"]
-                    taps[L], _ = ops.layernorm(x, w_, None, eps, lp, rms=True)
-            else:
-                if len(set(Ps)) == 1:
-                    ops.gemm(enc_b, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo:v_hi].contiguous(), rowadd_div=Ps[0], out_f32=x)
-                else:
-                    r0 = 0
-                    for i in range(n_loc):
-                        ops.gemm(enc_b[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[b, v_lo + i:v_lo + i + 1].contiguous(),
-                                 rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]])
-                        r0 += Ps[i]
-                taps = {0: enc_b}
-                for li, pb in enumerate(pk["dec"]):
-                    self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
-                    if (li + 1) in hooks[1:3]:
-                        taps[li + 1] = ops.cast_lp(x, lp)
-                w_, b_, eps = pk["dec_norm"]
-                taps[L], _ = ops.layernorm(x, w_, b_, eps, lp)
-            hook_toks.append([taps[hk] for hk in hooks])
+            hook_toks.append(self._decode_sample(pk, enc_hi, enc_lo, Ps, emb_rows[b], v_lo, kvx))
             if self.debug_taps is not None:
-                self.debug_taps.setdefault("hooks", []).append([t.float().cpu() for t in hook_toks[-1]])
-            del x
+                self.debug_taps.setdefault("hooks", []).append([t[0].float().cpu() for t in hook_toks[-1]])
+        del feats
         if profiling:
             torch.cuda.synchronize()
             prof["decoder_time"] = time.time() - t2
             prof["head_prepare_input_time"] = 0.0  # hooks are consumed in place: no rearrange step (fast3r.py:385-398)
 
-        # ---- heads (fast3r.py:407-485), in chunks of max_parallel_views_for_head same-size views
+        # ---- heads (fast3r.py:407-485), per sample in chunks of max_parallel_views_for_head consecutive views with one token grid
         t3 = time.time()
         results = [{} for _ in range(n_loc)]
+        per_view = [[None] * B for _ in range(n_loc)]  # per (view, sample): {name: tensor (H, W[, 3])}
         offs = np.concatenate([[0], np.cumsum(Ps)]).tolist()
         step = max(1, self.max_parallel_views_for_head)
         heads = [("pts3d_in_other_view", "conf", pk["head"])]
         if pk["head_local"] is not None:
             heads.append(("pts3d_local", "conf_local", pk["head_local"]))
-        i0 = 0
-        while i0 < n_loc:
-            i1 = i0 + 1
-            while i1 < n_loc and i1 - i0 < step and grids[i1] == grids[i0]:
-                i1 += 1
-            gh, gw = grids[i0]
-            for pname, cname, hk in heads:
-                per_b = []
-                for b in range(B):
-                    toks = [t[offs[i0]:offs[i1]] for t in hook_toks[b]]
-                    per_b.append(self._dpt(hk, toks, i1 - i0, gh, gw))
+        for b in range(B):
+            i0 = 0
+            while i0 < n_loc:
+                i1 = i0 + 1
+                while i1 < n_loc and i1 - i0 < step and head_grid[i1][b] == head_grid[i0][b]:
+                    i1 += 1
+                gh, gw = head_grid[i0][b]
+                toks = [(t[0][offs[i0]:offs[i1]], None if t[1] is None else t[1][offs[i0]:offs[i1]]) for t in hook_toks[b]]
                 for i in range(i0, i1):
-                    results[i][pname] = torch.stack([pb_[0][i - i0] for pb_ in per_b], dim=0)
-                    if per_b[0][1] is not None:
-                        results[i][cname] = torch.stack([pb_[1][i - i0] for pb_ in per_b], dim=0)
-            i0 = i1
+                    per_view[i][b] = {}
+                for pname, cname, hk in heads:
+                    pts, conf = self._dpt(hk, toks, i1 - i0, gh, gw)
+                    for i in range(i0, i1):
+                        sw = head_swap[i][b]
+                        per_view[i][b][pname] = pts[i - i0].swapaxes(0, 1) if sw else pts[i - i0]  # transposed(): misc.py:105-106
+                        if conf is not None:
+                            per_view[i][b][cname] = conf[i - i0].swapaxes(0, 1) if sw else conf[i - i0]
+                i0 = i1
+        for i in range(n_loc):
+            for name in per_view[i][0]:
+                results[i][name] = torch.stack([per_view[i][b][name] for b in range(B)], dim=0)
         if sh is not None:
             results = sh.gather_results(results, N_total, dev)
         if profiling:

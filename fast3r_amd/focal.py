@@ -12,20 +12,18 @@ import math
 import torch
 
 from . import _lib
-from ._lib import F3RError, check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, work_device
 
 N_ITER = 100  # post_process.py:131
 
 
 def estimate_focals(pts3d, conf, pp=None, min_conf_thr_percentile=10, n_iter=N_ITER, min_focal=0.0, max_focal=math.inf):
     """pts3d (n, H, W, 3), conf (n, H, W) on the GPU -> (n,) fp32 focal lengths (pixels), one per view."""
-    if pts3d.device.type != "cuda":
-        raise F3RError(f"fast3r_amd.estimate_focal runs on the ROCm GPU (pts3d is on {pts3d.device}); there is no CPU fallback")
     if pts3d.dim() != 4 or pts3d.shape[-1] != 3 or tuple(conf.shape) != tuple(pts3d.shape[:3]):
         raise ValueError(f"pts3d must be (n, H, W, 3) and conf (n, H, W); got {tuple(pts3d.shape)} and {tuple(conf.shape)}")
     n, H, W, _ = pts3d.shape
-    dev = pts3d.device
-    pts3d = pts3d.float().contiguous()
+    home, dev = pts3d.device, work_device(pts3d, "pts3d")
+    pts3d = pts3d.to(dev).float().contiguous()
     conf = conf.to(dev).float().contiguous()
     if pp is None:
         ppx, ppy = W / 2, H / 2  # multiview_dust3r_module.py:1086
@@ -35,10 +33,11 @@ def estimate_focals(pts3d, conf, pp=None, min_conf_thr_percentile=10, n_iter=N_I
     ws_bytes = _lib.lib().f3r_focal_workspace_bytes(n, H, W)
     ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=torch.float32, device=dev)
     mx = 3.0e38 if math.isinf(max_focal) else float(max_focal)
-    check(_lib.lib().f3r_estimate_focal(ptr(pts3d), ptr(conf), ptr(out), None, ptr(ws), ws_bytes, n, H, W,
-                                        float(min_conf_thr_percentile) / 100.0, float(ppx), float(ppy), int(n_iter), float(min_focal), mx,
-                                        stream_ptr()), "f3r_estimate_focal")
-    return out
+    with torch.cuda.device(dev):
+        check(_lib.lib().f3r_estimate_focal(ptr(pts3d), ptr(conf), ptr(out), None, ptr(ws), ws_bytes, n, H, W,
+                                            float(min_conf_thr_percentile) / 100.0, float(ppx), float(ppy), int(n_iter), float(min_focal), mx,
+                                            stream_ptr()), "f3r_estimate_focal")
+    return out.to(home)
 
 
 def estimate_focal(pts3d_i, conf_i, pp=None, min_conf_thr_percentile=10):

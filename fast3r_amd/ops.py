@@ -9,7 +9,8 @@ import torch
 
 from . import _lib
 from ._lib import (AttnArgs, F3R_A_CONV3X3, F3R_A_PLAIN, F3R_ACT_GELU, F3R_ACT_NONE, F3R_ACT_RELU, F3R_EPI_CONVT,
-                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, GemmArgs, check, dtype_id, ptr, require_gpu, stream_ptr)
+                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3, GemmArgs, check, dtype_id,
+                   ptr, require_gpu, stream_ptr)
 
 ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F3R_ACT_RELU}
 
@@ -23,32 +24,50 @@ def round_up(x: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------------------- weight packing (host, once)
-def pack_linear_weight(w: torch.Tensor, lp: torch.dtype) -> torch.Tensor:
-    """nn.Linear / 1x1-conv weight (N, K[,1,1]) fp32 -> lowp [N][Kpad], Kpad = roundup(K, 64), zero padded."""
+SPLIT = {None: F3R_SPLIT_NONE, 0: F3R_SPLIT_NONE, "none": F3R_SPLIT_NONE, "w2": F3R_SPLIT_W2, "x3": F3R_SPLIT_X3}
+
+
+def split_planes(w: torch.Tensor, lp: torch.dtype):
+    """fp32 -> (hi, lo) lowp with hi = lowp(w), lo = lowp(w - hi): hi + lo carries ~2x the significand bits of one lowp number."""
+    hi = w.to(lp)
+    return hi, (w - hi.float()).to(lp)
+
+
+def pack_linear_weight(w: torch.Tensor, lp: torch.dtype, split: bool = False) -> torch.Tensor:
+    """nn.Linear / 1x1-conv weight (N, K[,1,1]) fp32 -> lowp [N][Kpad], Kpad = roundup(K, 64), zero padded.
+    split: two planes per row, [N][2*Kpad] = [hi | lo] (f3r_gemm_args.split, include/f3r.h)."""
     w = w.reshape(w.shape[0], -1)
     n, k = w.shape
-    out = torch.zeros((n, round_up(k, 64)), dtype=lp, device=w.device)
-    out[:, :k] = w.to(lp)
+    kp = round_up(k, 64)
+    out = torch.zeros((n, kp * (2 if split else 1)), dtype=lp, device=w.device)
+    if split:
+        out[:, :k], out[:, kp:kp + k] = split_planes(w, lp)
+    else:
+        out[:, :k] = w.to(lp)
     return out
 
 
-def pack_conv3x3_weight(w: torch.Tensor, lp: torch.dtype) -> torch.Tensor:
-    """Conv2d weight (Cout, Cin, 3, 3) -> lowp [Cout][9 * Cpad], k = (ky*3 + kx) * Cpad + ci, Cpad = roundup(Cin, 64)."""
+def pack_conv3x3_weight(w: torch.Tensor, lp: torch.dtype, split: bool = False) -> torch.Tensor:
+    """Conv2d weight (Cout, Cin, 3, 3) -> lowp [Cout][9 * Cpad], k = (ky*3 + kx) * Cpad + ci, Cpad = roundup(Cin, 64);
+    split: [Cout][2][9 * Cpad] = hi plane then lo plane."""
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
     cpad = round_up(ci, 64)
-    out = torch.zeros((co, 9, cpad), dtype=lp, device=w.device)
-    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(lp)
-    return out.reshape(co, 9 * cpad)
+    taps = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+    planes = split_planes(taps, lp) if split else (taps.to(lp),)
+    out = torch.zeros((co, len(planes), 9, cpad), dtype=lp, device=w.device)
+    for i, pl in enumerate(planes):
+        out[:, i, :, :ci] = pl
+    return out.reshape(co, len(planes) * 9 * cpad)
 
 
-def pack_convT_weight(w: torch.Tensor, b: torch.Tensor, lp: torch.dtype):
+def pack_convT_weight(w: torch.Tensor, b: torch.Tensor, lp: torch.dtype, split: bool = False):
     """ConvTranspose2d (kernel == stride == s) weight (Cin, Cout, s, s) -> lowp [(dy*s+dx)*Cout + co][Kpad] and the bias
     tiled to [s*s*Cout] (every output pixel gets exactly one tap)."""
     ci, co, s, s2 = w.shape
     assert s == s2
     wp = w.permute(2, 3, 1, 0).reshape(s * s * co, ci)
-    return pack_linear_weight(wp, lp), b.float().repeat(s * s).contiguous()
+    return pack_linear_weight(wp, lp, split), b.float().repeat(s * s).contiguous()
 
 
 def rope_tables(n_pos: int, base: float, device, half_dim: int = 32):
@@ -86,9 +105,20 @@ def layernorm(x, gamma, beta, eps, lp, out_lp=None, out_f32=None, want_lp=True, 
     return out_lp, out_f32
 
 
+def _split_operand(g, a, split, a_lo):
+    """Common split-precision plumbing: g.split and, for "x3", the low plane of A (same shape / strides as A)."""
+    g.split = SPLIT[split]
+    if g.split == F3R_SPLIT_X3:
+        assert a_lo is not None and a_lo.dtype == a.dtype and a_lo.shape == a.shape and a_lo.stride() == a.stride(), "x3 split needs a_lo like a"
+        g.A_lo = ptr(a_lo)
+
+
 def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f32=None, res_lp=None, res_lp2=None,
-         out_f32=None, out_lp=None, want_f32=False, want_lp=False):
-    """out = act(A W^T + bias) [+ rowadd[m//div]] [+ residuals].  a: lowp [M][lda>=K]; w: packed lowp [N][Kpad]."""
+         out_f32=None, out_lp=None, want_f32=False, want_lp=False, split=None, a_lo=None, res_lp_lo=None, res_lp2_lo=None,
+         out_lp_lo=None, want_lo=False, kernel_sel=0):
+    """out = act(A W^T + bias) [+ rowadd[m//div]] [+ residuals].  a: lowp [M][lda>=K]; w: packed lowp [N][Kpad].
+    split "w2" / "x3": w packed with split=True ([hi | lo] planes), "x3" also takes a_lo (f3r.h f3r_split); *_lo: low planes of the lowp
+    residuals / output.  Returns (out_f32, out_lp) or, with want_lo / out_lp_lo, (out_f32, out_lp, out_lp_lo)."""
     require_gpu(a, "a")
     lp = a.dtype
     assert w.dtype == lp and a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1
@@ -97,12 +127,16 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
     K = a.shape[1] if K is None else K
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    if want_lp and out_lp is None:
+    if (want_lp or want_lo) and out_lp is None:
         out_lp = torch.empty((M, N), dtype=lp, device=a.device)
+    if want_lo and out_lp_lo is None:
+        out_lp_lo = torch.empty((M, N), dtype=lp, device=a.device)
     g = GemmArgs()
     g.A, g.W, g.bias = ptr(a), ptr(w), ptr(bias)
     g.M, g.N, g.K, g.Kpad, g.lda = M, N, K, Kpad, a.stride(0)
     g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_GENERIC, ACT[act]
+    g.kernel_sel = kernel_sel
+    _split_operand(g, a, split, a_lo)
     if rowadd is not None:
         g.rowadd, g.rowadd_div = ptr(rowadd), rowadd_div
     if res_f32 is not None:
@@ -115,8 +149,19 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
         g.out_f32, g.ldo_f32 = ptr(out_f32), out_f32.stride(0)
     if out_lp is not None:
         g.out_lp, g.ldo_lp = ptr(out_lp), out_lp.stride(0)
+    if out_lp_lo is not None:
+        assert out_lp is not None and out_lp_lo.stride(0) == out_lp.stride(0)
+        g.out_lp_lo = ptr(out_lp_lo)
+    if res_lp_lo is not None:
+        assert res_lp is not None and res_lp_lo.stride(0) == res_lp.stride(0)
+        g.res_lp_lo = ptr(res_lp_lo)
+    if res_lp2_lo is not None:
+        assert res_lp2 is not None and res_lp2_lo.stride(0) == res_lp2.stride(0)
+        g.res_lp2_lo = ptr(res_lp2_lo)
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
+    if out_lp_lo is not None:
+        return out_f32, out_lp, out_lp_lo
     return out_f32, out_lp
 
 
@@ -128,7 +173,7 @@ def vt_ld(seq_len: int) -> int:
 LOG2E = 1.4426950408889634
 
 
-def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0):
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0, split=None, a_lo=None, kernel_sel=0):
     """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE'd), v -> vt[M/seq][D][ldvt].
     rope = (cos, sin, tokens_per_row) or None; rope_mode 0 = RoPE-2D tables [n_pos][16], 1 = per-row-group tables [n_groups][32]
     (rope[2] = rows per group; see f3r_gemm_args.rope_mode).  vt must be zero-initialised once (its padding is never written)."""
@@ -146,6 +191,8 @@ def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0)
         g.rope_cos, g.rope_sin, g.rope_w = ptr(rope[0]), ptr(rope[1]), rope[2]
         g.rope_mode = int(rope_mode)
     g.q_scale = float(q_scale)
+    g.kernel_sel = kernel_sel
+    _split_operand(g, a, split, a_lo)
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
 
@@ -168,8 +215,11 @@ def rows_add(x, vec, rows):
     return x
 
 
-def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, res_lp2=None, out=None):
-    """3x3 conv, pad 1, NHWC lowp in/out, as an implicit GEMM.  x: (B,H,W,C); w: pack_conv3x3_weight(...)."""
+def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, res_lp2=None, out=None, split=None, x_lo=None,
+            res_lp_lo=None, res_lp2_lo=None, want_lo=False, want_relu=False, kernel_sel=0):
+    """3x3 conv, pad 1, NHWC lowp in/out, as an implicit GEMM.  x: (B,H,W,C); w: pack_conv3x3_weight(...).
+    Returns the output, or a dict {"out", "out_lo", "relu", "relu_lo"} when low planes (want_lo) or the pre-activated copy relu(out)
+    (want_relu; what the next ResidualConvUnit conv reads) are asked for."""
     require_gpu(x, "x")
     lp = x.dtype
     assert x.is_contiguous() and x.dim() == 4
@@ -179,6 +229,22 @@ def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, r
     if out is None:
         out = torch.empty((B, OH, OW, N), dtype=lp, device=x.device)
     g = GemmArgs()
+    g.kernel_sel = kernel_sel
+    _split_operand(g, x, split, x_lo)
+    extra = {}
+    if want_lo:
+        extra["out_lo"] = torch.empty_like(out)
+        g.out_lp_lo = ptr(extra["out_lo"])
+    if want_relu:
+        extra["relu"] = torch.empty_like(out)
+        g.out_relu = ptr(extra["relu"])
+        if want_lo:
+            extra["relu_lo"] = torch.empty_like(out)
+            g.out_relu_lo = ptr(extra["relu_lo"])
+    if res_lp_lo is not None:
+        g.res_lp_lo = ptr(res_lp_lo)
+    if res_lp2_lo is not None:
+        g.res_lp2_lo = ptr(res_lp2_lo)
     g.A, g.W, g.bias = ptr(x), ptr(w), ptr(bias)
     g.M, g.N, g.K, g.Kpad, g.lda = B * OH * OW, N, 0, Kpad, 0
     g.a_mode, g.a_relu = F3R_A_CONV3X3, int(a_relu)
@@ -191,16 +257,25 @@ def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, r
     g.out_lp, g.ldo_lp = ptr(out), N
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(conv3x3)")
+    if extra:
+        extra["out"] = out
+        return extra
     return out
 
 
-def convT(x, w, bias_tiled, s, cout):
-    """ConvTranspose2d with kernel == stride == s: x (B,h,w,Cin) NHWC lowp -> (B,h*s,w*s,cout)."""
+def convT(x, w, bias_tiled, s, cout, split=None, x_lo=None, want_lo=False, kernel_sel=0):
+    """ConvTranspose2d with kernel == stride == s: x (B,h,w,Cin) NHWC lowp -> (B,h*s,w*s,cout) [, its low plane with want_lo]."""
     require_gpu(x, "x")
     lp = x.dtype
     B, h, wd, cin = x.shape
     out = torch.empty((B, h * s, wd * s, cout), dtype=lp, device=x.device)
     g = GemmArgs()
+    g.kernel_sel = kernel_sel
+    _split_operand(g, x, split, x_lo)
+    out_lo = None
+    if want_lo:
+        out_lo = torch.empty_like(out)
+        g.out_lp_lo = ptr(out_lo)
     g.A, g.W, g.bias = ptr(x), ptr(w), ptr(bias_tiled)
     g.M, g.N, g.K, g.Kpad, g.lda = B * h * wd, s * s * cout, cin, w.shape[1], cin
     g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_CONVT, F3R_ACT_NONE
@@ -208,7 +283,7 @@ def convT(x, w, bias_tiled, s, cout):
     g.ct_s, g.ct_h, g.ct_w, g.ct_cout = s, h, wd, cout
     g.dtype = dtype_id(lp)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(convT)")
-    return out
+    return (out, out_lo) if want_lo else out
 
 
 def attention_state(tq_total: int, n_heads: int, device):
@@ -252,35 +327,41 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     return out
 
 
-def upsample2x(x, out_hw=None):
-    """bilinear x2, align_corners=True, NHWC lowp; optional crop to out_hw."""
+def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
+    """bilinear x2, align_corners=True, NHWC lowp; optional crop to out_hw.  x_lo: low plane of the input; want_lo: also return the
+    low plane of the output (split precision)."""
     require_gpu(x, "x")
     B, h, w, C = x.shape
     oh, ow = (2 * h, 2 * w) if out_hw is None else out_hw
     out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
-    check(_lib.lib().f3r_upsample2x(ptr(x), ptr(out), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
-    return out
+    out_lo = torch.empty_like(out) if want_lo else None
+    check(_lib.lib().f3r_upsample2x(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
+    return (out, out_lo) if want_lo else out
 
 
-def dpt_final(x, w, b, conf_mode):
-    """x (B,H,W,Cin) NHWC lowp -> pts3d (B,H,W,3) fp32, conf (B,H,W) fp32 (or None)."""
+def dpt_final(x, w, b, conf_mode, x_lo=None):
+    """x (+ x_lo) (B,H,W,Cin) NHWC lowp -> pts3d (B,H,W,3) fp32, conf (B,H,W) fp32 (or None).  w (n_out, Cin), b (n_out,), n_out = 3 + has_conf."""
     require_gpu(x, "x")
     B, H, W, Cin = x.shape
+    n_out = w.shape[0]
+    assert w.shape == (n_out, Cin) and b.shape == (n_out,) and n_out == (4 if conf_mode is not None else 3)
     pts = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
     conf = None
     vmin, vmax = 1.0, math.inf
     if conf_mode is not None:
         conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
         vmin, vmax = float(conf_mode[1]), float(conf_mode[2])
-    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(w), ptr(b), ptr(pts), ptr(conf), B * H * W, Cin, vmin, vmax,
+    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(x_lo), ptr(w), ptr(b), n_out, ptr(pts), ptr(conf), B * H * W, Cin, vmin, vmax,
                                    dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
     return pts, conf
 
 
-def cast_lp(x, lp, out=None):
+def cast_lp(x, lp, out=None, want_lo=False):
+    """fp32 -> lowp [, low plane lowp(x - float(hi)) with want_lo]."""
     require_gpu(x, "x")
     assert x.dtype == torch.float32 and x.is_contiguous()
     if out is None:
         out = torch.empty(x.shape, dtype=lp, device=x.device)
-    check(_lib.lib().f3r_cast_f32_to_lp(ptr(x), ptr(out), x.numel(), dtype_id(lp), stream_ptr()), "f3r_cast_f32_to_lp")
-    return out
+    out_lo = torch.empty(x.shape, dtype=lp, device=x.device) if want_lo else None
+    check(_lib.lib().f3r_cast_f32_to_lp(ptr(x), ptr(out), ptr(out_lo), x.numel(), dtype_id(lp), stream_ptr()), "f3r_cast_f32_to_lp")
+    return (out, out_lo) if want_lo else out

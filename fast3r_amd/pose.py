@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F3RError, check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, work_device
 from .focal import estimate_focals
 
 N_GUESSED_FOCALS = 100  # init_im_poses.py:300
@@ -21,15 +21,14 @@ CONF_THR = 1.0          # multiview_dust3r_module.py:1045
 
 
 def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals=N_GUESSED_FOCALS):
-    """pts3d (n, H, W, 3), conf (n, H, W) on the GPU, focal None / float / (n,) tensor ->
-    (cam_to_world (n, 4, 4) fp32, focal (n,) fp32 with NaN where the solve failed, inliers (n,) int32), all on the GPU."""
-    if pts3d.device.type != "cuda":
-        raise F3RError(f"fast3r_amd.estimate_poses runs on the ROCm GPU (pts3d is on {pts3d.device}); there is no CPU fallback")
+    """pts3d (n, H, W, 3), conf (n, H, W), focal None / float / (n,) tensor ->
+    (cam_to_world (n, 4, 4) fp32, focal (n,) fp32 with NaN where the solve failed, inliers (n,) int32) on pts3d's device (CPU inputs
+    are uploaded to the current ROCm device for the kernels)."""
     if pts3d.dim() != 4 or pts3d.shape[-1] != 3 or tuple(conf.shape) != tuple(pts3d.shape[:3]):
         raise ValueError(f"pts3d must be (n, H, W, 3) and conf (n, H, W); got {tuple(pts3d.shape)} and {tuple(conf.shape)}")
     n, H, W, _ = pts3d.shape
-    dev = pts3d.device
-    pts3d = pts3d.float().contiguous()
+    home, dev = pts3d.device, work_device(pts3d, "pts3d")
+    pts3d = pts3d.to(dev).float().contiguous()
     conf = conf.to(dev).float().contiguous()
     fin = None
     if focal is not None:
@@ -40,9 +39,10 @@ def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals
     poses = torch.empty((n, 4, 4), dtype=torch.float32, device=dev)
     fout = torch.empty((n,), dtype=torch.float32, device=dev)
     inl = torch.empty((n,), dtype=torch.int32, device=dev)
-    check(_lib.lib().f3r_estimate_poses(ptr(pts3d), ptr(conf), ptr(fin), ptr(fout), ptr(poses), ptr(inl), n, H, W, float(conf_thr),
-                                        float(ppx), float(ppy), int(n_focals), stream_ptr()), "f3r_estimate_poses")
-    return poses, fout, inl
+    with torch.cuda.device(dev):
+        check(_lib.lib().f3r_estimate_poses(ptr(pts3d), ptr(conf), ptr(fin), ptr(fout), ptr(poses), ptr(inl), n, H, W, float(conf_thr),
+                                            float(ppx), float(ppy), int(n_focals), stream_ptr()), "f3r_estimate_poses")
+    return poses.to(home), fout.to(home), inl.to(home)
 
 
 def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimation_method="individual"):

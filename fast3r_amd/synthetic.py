@@ -14,8 +14,9 @@ import torch
 
 
 def vit_large_args(img_size=512, attn_implementation="flash_attention", random_image_idx_embedding=True,
-                   attn_bias_for_inference_enabled=True):
-    """The (inferred) released `Fast3R_ViT_Large_512` constructor args."""
+                   attn_bias_for_inference_enabled=True, max_image_idx=1000):
+    """The (inferred) released `Fast3R_ViT_Large_512` constructor args.  max_image_idx > 1000 adds the
+    fast3r_amd-only decoder argument that extends the image-index table past the reference's 1000 rows (BASELINE configs[4], N=1500)."""
     encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls="PatchEmbedDust3R",
                         embed_dim=1024, num_heads=16, depth=24, mlp_ratio=4, pos_embed="RoPE100",
                         attn_implementation=attn_implementation)
@@ -23,6 +24,8 @@ def vit_large_args(img_size=512, attn_implementation="flash_attention", random_i
                         enc_embed_dim=1024, embed_dim=1024, num_heads=16, depth=24, mlp_ratio=4.0, qkv_bias=True,
                         drop=0.0, attn_drop=0.0, attn_implementation=attn_implementation,
                         attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)
+    if max_image_idx != 1000:
+        decoder_args["max_image_idx"] = int(max_image_idx)
     head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=False,
                      depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],
                      patch_size=16, with_local_head=True)

@@ -128,7 +128,27 @@ typedef struct f3r_gemm_args {
                         group m / rope_w (rope_w = tokens per view, or 1 with one table row per token); the first 32 dims of a head
                         rotate with table columns 0-15 (dim i pairs with i+16), the last 32 with columns 16-31 -- the host permutes
                         the q / k weight rows so that the reference's interleaved pairs (2j, 2j+1) land on these positions */
+  /* Split-precision operands (the "high" precision mode): a value x is carried as two lowp numbers
+     hi = lowp(x), lo = lowp(x - hi) (~22 significand bits with fp16 pieces) and the product is summed over K SEGMENTS on the same
+     MFMA path (fp32 accumulate):  F3R_SPLIT_W2: A.W_hi + A.W_lo (weights exact to ~2^-22, activations single);
+     F3R_SPLIT_X3: A_hi.W_hi + A_hi.W_lo + A_lo.W_hi.  With split != 0, W is [N][2][Kpad/2] (plane 0 = hi, plane 1 = lo; Kpad is still
+     the row stride, K the real depth of ONE plane) and, for X3, A_lo is the low plane of A (same layout / strides as A). */
+  int32_t split;     /* f3r_split */
+  int32_t kernel_sel; /* 0 = pick the kernel by shape; 1 = 128x128-tile kernel; 2 / 3 = 256x256-tile kernel with / without staggered wave rows
+                         (measurement only: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
+  const void* A_lo;
+  /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
+     their high planes.  Same leading dimensions as the high planes. */
+  void* out_lp_lo;
+  const void* res_lp_lo;
+  const void* res_lp2_lo;
+  /* GENERIC: second lowp output relu(v) [M][ldo_lp] (+ its low plane): the pre-activated copy the next ResidualConvUnit conv reads
+     (dpt_block.py:143,148), so that conv needs no a_relu and can stage its operand by LDS-DMA */
+  void* out_relu;
+  void* out_relu_lo;
 } f3r_gemm_args;
+
+typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_split;
 
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 
@@ -188,25 +208,28 @@ int f3r_attn_read_prof(unsigned long long* out8);
  * Replaces F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) in
  * FeatureFusionBlock_custom.forward (dpt_block.py:238-243) and the head's Interpolate (:374).
  * The output may be cropped to (out_h, out_w) <= (2h, 2w) (refinenet4 crop, dpt_head.py:69-71).
+ * in_lo / out_lo: optional low planes (split precision, see f3r_gemm_args.split): the input is in + in_lo, the output is
+ * written as hi = lowp(y), lo = lowp(y - hi).  Either may be NULL.
  */
-int f3r_upsample2x(const void* in, void* out, int batch, int h, int w, int C, int out_h, int out_w, int dtype,
-                   f3r_stream_t stream);
+int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int out_h, int out_w,
+                   int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * f3r_dpt_final: last 1x1 conv (Cin -> 4) fused with postprocess.
- * Replaces head[4] Conv2d(last_dim, 4, 1) (dpt_block.py:379-381) + postprocess/reg_dense_depth/
+ * f3r_dpt_final: last 1x1 conv (Cin -> n_out) fused with postprocess.
+ * Replaces head[4] Conv2d(last_dim, 3 + has_conf, 1) (dpt_block.py:379-381) + postprocess/reg_dense_depth/
  * reg_dense_conf (heads/postprocess.py:16-64), depth_mode ('exp', -inf, inf), conf_mode ('exp', vmin, vmax):
- *   xyz,c = W(4,Cin) x + b;  d = |xyz|;  pts = xyz / max(d, 1e-8) * expm1(d);  conf = vmin + min(exp(c), vmax - vmin)
- *   x : NHWC lowp [npix][Cin];  w: fp32 [4][Cin];  b: fp32 [4];  pts3d: fp32 [npix][3];  conf: fp32 [npix]
+ *   xyz,c = W(n_out,Cin) x + b;  d = |xyz|;  pts = xyz / max(d, 1e-8) * expm1(d);  conf = vmin + min(exp(c), vmax - vmin)
+ *   x (+ x_lo, optional low plane): NHWC lowp [npix][Cin];  w: fp32 [n_out][Cin];  b: fp32 [n_out];  n_out = 3 (no confidence:
+ *   conf must be NULL) or 4;  pts3d: fp32 [npix][3];  conf: fp32 [npix] or NULL
  */
-int f3r_dpt_final(const void* x, const float* w, const float* b, float* pts3d, float* conf, int64_t npix, int Cin,
-                  float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream);
+int f3r_dpt_final(const void* x, const void* x_lo, const float* w, const float* b, int n_out, float* pts3d, float* conf, int64_t npix,
+                  int Cin, float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_cast_f32_to_lp: fp32 -> lowp copy (hooked residual streams 12/18 as DPT inputs, dpt_head.py:54;
- * weight packing).
+ * weight packing).  out_lo (optional): the low plane lowp(x - float(out)) of the split-precision operand format.
  */
-int f3r_cast_f32_to_lp(const float* in, void* out, int64_t n, int dtype, f3r_stream_t stream);
+int f3r_cast_f32_to_lp(const float* in, void* out, void* out_lo, int64_t n, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_align_local_to_global: similarity alignment of the local pointmap of every (view, sample) to its global pointmap.

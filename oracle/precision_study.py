@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU emulation of operand-rounding designs for the HIP path (decides DESIGN.md section 4).
+
+Runs the oracle (oracle/fast3r_oracle.py) with its GEMM-like functionals wrapped so that operands (and, optionally, stored
+activations) are rounded the way a candidate kernel design would round them, and prints the end-to-end rel-L2 of every design
+against the exact fp32 oracle on the stress fixture (`hot` weights) and the default one.
+
+    python oracle/precision_study.py
+
+Zones: "tr" = encoder + fusion transformer, "hd" = DPT heads.  A design is {zone: mode}:
+    "f32"     exact
+    "bf16" / "f16"   operands of every GEMM / conv rounded once (fp32 accumulate), outputs kept fp32
+    "+store"  suffix: the op's OUTPUT is also rounded to that type (activations live in HBM as 16-bit)
+    "f16x2"   activations split hi + lo (two fp16 numbers, 22 bits), weights single fp16
+    "f16w2"   weights split hi + lo, activations single fp16
+    "f16x3"   both split: a_hi w_hi + a_lo w_hi + a_hi w_lo
+    "bf16x3"  same with bf16 pieces (3 x 8 bits; the classic bf16x3 ~ fp32-ish emulation)
+"""
+import os
+import sys
+import types
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args  # noqa: E402
+from oracle import fast3r_oracle as O  # noqa: E402
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def rnd(x, dt):
+    return x.to(dt).float()
+
+
+def split2(x, dt):
+    hi = rnd(x, dt)
+    return hi, rnd(x - hi, dt)
+
+
+class Zone:
+    mode = "f32"
+
+
+ZONE = Zone()
+
+
+def _apply(fn, a, w, *rest, **kw):
+    """fn(a, w, ...) bilinear in (a, w): emulate the operand rounding of ZONE.mode."""
+    mode = ZONE.mode
+    store = mode.endswith("+store")
+    base = mode.replace("+store", "")
+    bias = rest[0] if rest else kw.pop("bias", None)
+    rest = rest[1:]
+    if base == "f32":
+        out = fn(a, w, None, *rest, **kw)
+    elif base in DT:
+        out = fn(rnd(a, DT[base]), rnd(w, DT[base]), None, *rest, **kw)
+    elif base in ("f16x2", "bf16x2"):
+        dt = DT[base[:-2]]
+        ah, al = split2(a, dt)
+        wh = rnd(w, dt)
+        out = fn(ah, wh, None, *rest, **kw) + fn(al, wh, None, *rest, **kw)
+    elif base in ("f16w2", "bf16w2"):  # weights split, activations single
+        dt = DT[base[:-2]]
+        ah = rnd(a, dt)
+        wh, wl = split2(w, dt)
+        out = fn(ah, wh, None, *rest, **kw) + fn(ah, wl, None, *rest, **kw)
+    elif base in ("f16x3", "bf16x3"):
+        dt = DT[base[:-2]]
+        ah, al = split2(a, dt)
+        wh, wl = split2(w, dt)
+        out = fn(ah, wh, None, *rest, **kw) + fn(al, wh, None, *rest, **kw) + fn(ah, wl, None, *rest, **kw)
+    else:
+        raise ValueError(mode)
+    if bias is not None:
+        out = out + bias.view(1, -1, *([1] * (out.dim() - 2))) if fn is not F.linear else out + bias
+    if store:
+        out = rnd(out, DT[base])
+    return out
+
+
+class FProxy(types.SimpleNamespace):
+    pass
+
+
+def make_proxy():
+    p = FProxy()
+    for name in dir(F):
+        if not name.startswith("_"):
+            setattr(p, name, getattr(F, name))
+    p.linear = lambda a, w, b=None: _apply(F.linear, a, w, b)
+    p.conv2d = lambda a, w, b=None, **kw: _apply(F.conv2d, a, w, b, **kw)
+    p.conv_transpose2d = lambda a, w, b=None, **kw: _apply(F.conv_transpose2d, a, w, b, **kw)
+    return p
+
+
+def attention_emul(x, sd, pre, num_heads, scale, xpos=None, rope_base=None, q_chunk=2048):
+    """oracle.attention with q, k, v, P rounded like the attention kernel does when the transformer zone is 16-bit."""
+    mode = ZONE.mode.replace("+store", "")
+    B, S, C = x.shape
+    qkv = O.F.linear(x, sd[pre + "qkv.weight"], sd.get(pre + "qkv.bias"))
+    qkv = qkv.reshape(B, S, 3, num_heads, C // num_heads).transpose(1, 3)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    if rope_base is not None and xpos is not None:
+        q = O.rope2d(q, xpos, rope_base)
+        k = O.rope2d(k, xpos, rope_base)
+    qk_dt = ATTN.get("qk", mode)
+    pv_dt = ATTN.get("pv", mode)
+    if qk_dt in DT:
+        q, k = rnd(q * scale, DT[qk_dt]) / scale, rnd(k, DT[qk_dt])
+    a = (q @ k.transpose(-2, -1)) * scale
+    a = a - a.amax(dim=-1, keepdim=True)
+    p = a.exp()
+    if pv_dt in DT:
+        p = rnd(p, DT[pv_dt])
+        v = rnd(v, DT[pv_dt])
+    o = (p @ v) / p.sum(-1, keepdim=True)
+    o = o.transpose(1, 2).reshape(B, S, C)
+    if ZONE.mode in DT or ZONE.mode.endswith("+store"):
+        pass
+    return O.F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+ATTN = {}
+
+
+def run_design(views, sd, args, tr, hd, attn=None):
+    enc, dec, head = args
+    ATTN.clear()
+    if attn:
+        ATTN.update(attn)
+    saveF, saveA = O.F, O.attention
+    O.F = make_proxy()
+    O.attention = attention_emul
+    orig_dpt = O.dpt_forward
+
+    def dpt_zone(tokens4, *a, **k):
+        prev = ZONE.mode
+        ZONE.mode = hd
+        if hd != "f32":  # the hooks reach the head as 16-bit rows (they are GEMM operands) unless the head is exact
+            pass
+        try:
+            return orig_dpt(tokens4, *a, **k)
+        finally:
+            ZONE.mode = prev
+    O.dpt_forward = dpt_zone
+    ZONE.mode = tr
+    try:
+        torch.manual_seed(1234)
+        return O.forward(views, sd, enc, dec, head)
+    finally:
+        O.F, O.attention, O.dpt_forward = saveF, saveA, orig_dpt
+        ZONE.mode = "f32"
+
+
+def main():
+    from fast3r_amd import Fast3R
+    args = tiny_args()
+    shp = {k: tuple(v.shape) for k, v in Fast3R(*args).state_dict().items()}
+    designs = [
+        ("bf16", "bf16+store", None), ("bf16", "bf16", None), ("bf16", "f16", None), ("bf16", "f16x2", None),
+        ("bf16", "f16x3", None), ("bf16", "bf16x3", None), ("bf16", "f32", None),
+        ("f16", "f16+store", None), ("f16", "f16", None), ("f16", "f16x2", None), ("f16", "f16x3", None), ("f16", "f32", None),
+        ("f32", "f16", None), ("f32", "bf16", None),
+        ("bf16", "f16x3", {"qk": "f16"}), ("bf16", "f32", {"qk": "f16"}), ("bf16", "f32", {"qk": "f16", "pv": "f16"}),
+    ]
+    for dist in ("hot", "default"):
+        sd = synth_state_dict(shp, 0, dist)
+        views = make_views(3, 64, 64)
+        torch.manual_seed(1234)
+        ref = O.forward(views, sd, *args)
+        for tr, hd, attn in designs:
+            out = run_design(views, sd, args, tr, hd, attn)
+            worst = {}
+            for o, r in zip(out, ref):
+                for k in r:
+                    worst[k] = max(worst.get(k, 0.0), O.rel_l2(o[k], r[k]))
+            print(f"{dist:8s} tr={tr:6s} hd={hd:11s} attn={attn}: " + "  ".join(f"{k.replace('pts3d_', 'p_')}={v:.2e}" for k, v in worst.items()), flush=True)
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        main()

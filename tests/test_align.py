@@ -68,8 +68,9 @@ def test_product_raises_like_reference_and_has_no_cpu_path(built_lib):
     del bad[0]["pts3d_local"]
     with pytest.raises(ValueError, match="pts3d_local"):
         align_local_pts3d_to_global(bad, [{}])
-    with pytest.raises(F3RError):
-        align_local_pts3d_to_global(preds, [{}])  # CPU tensors: no fallback
+    if not torch.cuda.is_available():  # CPU preds are uploaded to the GPU when there is one; without one there is no fallback
+        with pytest.raises(F3RError):
+            align_local_pts3d_to_global(preds, [{}])
     assert built_lib.f3r_align_workspace_bytes(3) == 3 * 40 * 8
     assert built_lib.f3r_align_local_to_global(0x1000, 0x1000, 0x1000, None, 0x1000, 0x1000, None, 0x1000, 8, 1, 16, ctypes.c_float(1.5), None) == -1
 
@@ -150,3 +151,33 @@ def test_align_after_forward_via_lit_module(built_lib):
     for r, o in zip(ref, preds):
         a, b = o["pts3d_local_aligned_to_global"].cpu(), r["pts3d_local_aligned_to_global"]
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+def test_readme_flow_on_the_cpu_preds_inference_returns(built_lib):
+    """The reference's documented two-step use (README.md:96-125): `out = inference(...)` hands back preds on the CPU (to_cpu,
+    inference_multiview.py:92), then `lit.align_local_pts3d_to_global(out['preds'], out['views'], ...)` and
+    `lit.estimate_camera_poses(out['preds'], ...)` run on them.  Same calls here: CPU preds go up, results come back on the CPU,
+    and equal what the same functions give on the device-resident preds."""
+    from helpers import golden_model_inputs, load_golden, views_to
+    from fast3r_amd import Fast3R, MultiViewDUSt3RLitModule, inference
+    fix = load_golden("tiny_3x64")
+    enc, dec, head, sd, views = golden_model_inputs(fix)
+    m = Fast3R(enc, dec, head).eval()
+    m.load_state_dict(sd)
+    lit = MultiViewDUSt3RLitModule.load_for_inference(m.cuda())
+    torch.manual_seed(fix["rng_seed"])
+    out = inference(views, lit, torch.device("cuda"), dtype=torch.float16, verbose=False)
+    assert all(v.device.type == "cpu" for p in out["preds"] for v in p.values())
+    lit.align_local_pts3d_to_global(out["preds"], out["views"], min_conf_thr_percentile=85)
+    with torch.no_grad():
+        torch.manual_seed(fix["rng_seed"])
+        dev_preds = lit(views_to(views, "cuda"))
+    lit.align_local_pts3d_to_global(dev_preds, views, min_conf_thr_percentile=85)
+    for c, d in zip(out["preds"], dev_preds):
+        assert c["pts3d_local_aligned_to_global"].device.type == "cpu"
+        assert torch.equal(c["pts3d_local_aligned_to_global"], d["pts3d_local_aligned_to_global"].cpu())
+    poses_c, focals_c = lit.estimate_camera_poses(out["preds"], niter_PnP=10)
+    poses_d, focals_d = lit.estimate_camera_poses(dev_preds, niter_PnP=10)
+    assert len(poses_c) == 1 and len(poses_c[0]) == 3 and poses_c[0][0].shape == (4, 4)
+    assert all((a == b).all() for a, b in zip(poses_c[0], poses_d[0])) and focals_c == focals_d

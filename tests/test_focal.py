@@ -68,10 +68,14 @@ def test_hip_batched_views_and_principal_point(built_lib):
 
 
 @pytest.mark.gpu
-def test_hip_rejects_cpu_tensors_and_bad_shapes(built_lib):
+def test_hip_takes_cpu_tensors_and_rejects_bad_shapes(built_lib):
+    """CPU inputs (what `inference()` returns after its to_cpu) are uploaded, solved on the GPU, and the result comes back on the CPU."""
     from fast3r_amd import estimate_focals
-    from fast3r_amd._lib import F3RError
-    with pytest.raises(F3RError):
-        estimate_focals(torch.zeros(1, 4, 4, 3), torch.zeros(1, 4, 4))
+    g = torch.Generator().manual_seed(3)
+    pts = torch.randn(2, 16, 16, 3, generator=g) + torch.tensor([0.0, 0.0, 4.0])
+    conf = 1 + torch.rand(2, 16, 16, generator=g)
+    on_cpu = estimate_focals(pts, conf)
+    on_gpu = estimate_focals(pts.cuda(), conf.cuda())
+    assert on_cpu.device.type == "cpu" and on_gpu.is_cuda and torch.equal(on_cpu, on_gpu.cpu())
     with pytest.raises(ValueError):
         estimate_focals(torch.zeros(1, 4, 4, 3).cuda(), torch.zeros(1, 4, 5).cuda())

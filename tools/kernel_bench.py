@@ -93,25 +93,38 @@ def bench_attn_encoder(dt, views, variants, H=16):
     _lib.lib().f3r_attn_set_variant(-1)
 
 
-def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32"):
+SEL_NAME = {1: "128-tile", 2: "256-tile staggered", 3: "256-tile lock-step"}
+
+
+def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
     a = torch.randn((M, K), device=DEV).to(dt)
-    w = ops.pack_linear_weight(torch.randn((N, K), device=DEV) * K ** -0.5, dt)
+    a_lo = torch.randn((M, K), device=DEV).mul_(2.0 ** -11).to(dt) if split == "x3" else None
+    w = ops.pack_linear_weight(torch.randn((N, K), device=DEV) * K ** -0.5, dt, split=split is not None)
     bias = torch.randn(N, device=DEV)
     x = torch.randn((M, N), device=DEV) if (res or out == "f32") else None
     olp = torch.empty((M, N), dtype=dt, device=DEV) if out == "lp" else None
+    fns = {}
+    for sel in sels:
+        def f(sel=sel):
+            if out == "f32":
+                ops.gemm(a, w, bias=bias, act=act, res_f32=x if res else None, out_f32=x, kernel_sel=sel, split=split, a_lo=a_lo)
+            else:
+                ops.gemm(a, w, bias=bias, act=act, out_lp=olp, kernel_sel=sel, split=split, a_lo=a_lo)
+        f()
+        fns[sel] = f
+    res_ms = {sel: [] for sel in sels}
+    for _ in range(3):  # interleaved rounds
+        for sel in sels:
+            res_ms[sel].append(time_ms(fns[sel], rounds=3, inner=3)[0])
+    mult = {None: 1, "w2": 2, "x3": 3}[split]
+    for sel in sels:
+        ms = sorted(res_ms[sel])[1]
+        print(json.dumps({"kernel": "gemm", "name": name, "variant": SEL_NAME[sel], "split": split, "dtype": str(dt).split(".")[-1], "M": M, "N": N, "K": K,
+                          "ms": round(ms, 3), "tflops_algorithmic": round(2.0 * M * N * K / ms / 1e9, 1),
+                          "tflops_mfma": round(2.0 * M * N * K * mult / ms / 1e9, 1)}), flush=True)
 
-    def f():
-        if out == "f32":
-            ops.gemm(a, w, bias=bias, act=act, res_f32=x if res else None, out_f32=x)
-        else:
-            ops.gemm(a, w, bias=bias, act=act, out_lp=olp)
-    f()
-    med, mn = time_ms(f)
-    print(json.dumps({"kernel": "gemm", "name": name, "dtype": str(dt).split(".")[-1], "M": M, "N": N, "K": K, "ms": round(med, 3),
-                      "tflops": round(2.0 * M * N * K / med / 1e9, 1)}), flush=True)
 
-
-def bench_qkv(dt, M, D, seq):
+def bench_qkv(dt, M, D, seq, sels=(1, 2, 3)):
     a = torch.randn((M, D), device=DEV).to(dt)
     w = ops.pack_linear_weight(torch.randn((3 * D, D), device=DEV) * D ** -0.5, dt)
     bias = torch.randn(3 * D, device=DEV)
@@ -120,26 +133,49 @@ def bench_qkv(dt, M, D, seq):
     vt = torch.empty((M // seq, D, seq), dtype=dt, device=DEV)
     cos, sin = ops.rope_tables(32, 100.0, DEV)
     for rope in (None, (cos, sin, 32)):
-        def f():
-            ops.gemm_qkv(a, w, bias, q, k, vt, seq, rope)
-        f()
-        med, mn = time_ms(f)
-        print(json.dumps({"kernel": "gemm_qkv", "rope": rope is not None, "dtype": str(dt).split(".")[-1], "M": M, "seq": seq, "ms": round(med, 3),
-                          "tflops": round(2.0 * M * 3 * D * D / med / 1e9, 1)}), flush=True)
+        fns = {}
+        for sel in sels:
+            def f(sel=sel):
+                ops.gemm_qkv(a, w, bias, q, k, vt, seq, rope, kernel_sel=sel)
+            f()
+            fns[sel] = f
+        res_ms = {sel: [] for sel in sels}
+        for _ in range(3):
+            for sel in sels:
+                res_ms[sel].append(time_ms(fns[sel], rounds=3, inner=3)[0])
+        for sel in sels:
+            ms = sorted(res_ms[sel])[1]
+            print(json.dumps({"kernel": "gemm_qkv", "variant": SEL_NAME[sel], "rope": rope is not None, "dtype": str(dt).split(".")[-1], "M": M, "seq": seq,
+                              "ms": round(ms, 3), "tflops": round(2.0 * M * 3 * D * D / ms / 1e9, 1)}), flush=True)
 
 
-def bench_conv(dt, B, H, W, Ci, Co, name, stride=1):
+def bench_conv(dt, B, H, W, Ci, Co, name, stride=1, sels=(1, 2, 3), split=None):
     x = torch.randn((B, H, W, Ci), device=DEV).to(dt)
-    w = ops.pack_conv3x3_weight(torch.randn((Co, Ci, 3, 3), device=DEV) * (9 * Ci) ** -0.5, dt)
+    x_lo = torch.randn((B, H, W, Ci), device=DEV).mul_(2.0 ** -11).to(dt) if split == "x3" else None
+    w = ops.pack_conv3x3_weight(torch.randn((Co, Ci, 3, 3), device=DEV) * (9 * Ci) ** -0.5, dt, split=split is not None)
     bias = torch.randn(Co, device=DEV)
-
-    def f():
-        ops.conv3x3(x, w, stride=stride, bias=bias, a_relu=True)
-    f()
-    med, mn = time_ms(f)
     oh, ow = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    print(json.dumps({"kernel": "conv3x3", "name": name, "dtype": str(dt).split(".")[-1], "B": B, "HW": [H, W], "Ci": Ci, "Co": Co, "ms": round(med, 3),
-                      "tflops": round(2.0 * B * oh * ow * 9 * Ci * Co / med / 1e9, 1)}), flush=True)
+    r1 = torch.randn((B, oh, ow, Co), device=DEV).to(dt)
+    cases = [("a_relu (round-1 form)", dict(a_relu=True, res_lp=r1), (1,))] if split is None else []
+    cases.append(("skip + relu copy", dict(res_lp=r1, want_relu=True), tuple(s_ for s_ in sels if stride == 1 and Ci % 64 == 0 and Co >= 256 or s_ == 1)))
+    for cname, kw, csels in cases:
+        fns = {}
+        for sel in csels:
+            def f(sel=sel, kw=kw):
+                ops.conv3x3(x, w, stride=stride, bias=bias, kernel_sel=sel, split=split, x_lo=x_lo, **kw)
+            f()
+            fns[sel] = f
+        res_ms = {sel: [] for sel in csels}
+        for _ in range(3):
+            for sel in csels:
+                res_ms[sel].append(time_ms(fns[sel], rounds=3, inner=3)[0])
+        mult = {None: 1, "w2": 2, "x3": 3}[split]
+        for sel in csels:
+            ms = sorted(res_ms[sel])[1]
+            fl = 2.0 * B * oh * ow * 9 * Ci * Co
+            print(json.dumps({"kernel": "conv3x3", "name": name, "case": cname, "variant": SEL_NAME[sel], "split": split, "dtype": str(dt).split(".")[-1], "B": B,
+                              "HW": [H, W], "Ci": Ci, "Co": Co, "ms": round(ms, 3), "tflops_algorithmic": round(fl / ms / 1e9, 1),
+                              "tflops_mfma": round(fl * mult / ms / 1e9, 1)}), flush=True)
 
 
 def bench_align(n_views=320, H=512, W=512, pct=85):
@@ -275,8 +311,13 @@ if __name__ == "__main__":
         bench_gemm(dt, M, 4096, 1024, "fc1+gelu", act="gelu", out="lp")
         bench_gemm(dt, M, 1024, 4096, "fc2+res", res=True)
         bench_gemm(dt, M, 1024, 768, "patch_embed")
+        bench_gemm(dt, 8 * M, 1024, 1024, "proj+res N=320", res=True)
+        bench_gemm(dt, 8 * M, 4096, 1024, "fc1+gelu N=320", act="gelu", out="lp")
         bench_qkv(dt, M, 1024, 1024)
         bench_qkv(dt, M, 1024, M)
+        bench_gemm(torch.float16, M, 1024, 1024, "proj+res w2", res=True, split="w2")
+        bench_gemm(torch.float16, M, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2")
+        bench_gemm(torch.float16, M, 1024, 1024, "proj+res x3", res=True, split="x3")
     if "focal" in args.what:
         bench_focal()
     if "pnp" in args.what:
@@ -291,3 +332,4 @@ if __name__ == "__main__":
         bench_conv(dt, 8, 512, 512, 128, 128, "head2")
         bench_conv(dt, 8, 64, 64, 256, 256, "refinenet2 rcu")
         bench_conv(dt, 8, 32, 32, 768, 768, "act3 s2", stride=2)
+        bench_conv(torch.float16, 8, 128, 128, 256, 256, "refinenet1 rcu x3", split="x3")

@@ -44,7 +44,7 @@ def run(tag, args, n_views, hw, dist):
             P = taps["hooks"][0].shape[1] // n_views
             g = hw // 16
             toks = [t[0].to(dt).to(DEV).contiguous() for t in taps["hooks"]]
-            pts, conf = m._dpt(pk["head"], toks, n_views, g, g)
+            pts, conf = m._dpt(pk["head"], [(t, None) for t in toks], n_views, g, g)
             ref_pts = torch.cat([r["pts3d_in_other_view"] for r in ref])
             ref_conf = torch.cat([r["conf"] for r in ref])
             row["headonly_pts"] = O.rel_l2(pts.cpu(), ref_pts)
