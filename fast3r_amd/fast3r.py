@@ -564,7 +564,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return super()._apply(fn, *a, **k)
 
     def invalidate_packed_weights(self):
-        self._packed = None
+        self._packed = self._packed_alt = None
         if getattr(self, "_graphs", None) is not None:
             self._graphs.clear()  # captured graphs hold pointers into the packed weights
 
@@ -578,8 +578,14 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         key = (lp, self.precision, str(device), self._params_version())
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
-        if self._packed is not None:
+        alt = getattr(self, "_packed_alt", None)
+        if alt is not None and alt["key"] == key:  # two packs are kept, so alternating inference(dtype=...) calls do not re-pack
+            self._packed, self._packed_alt = alt, self._packed
+            return self._packed
+        if self._packed is not None and self._packed["key"][-1] != key[-1]:  # parameters changed: both packs are stale
+            self._packed = self._packed_alt = None
             self._graphs.clear()
+        self._packed_alt = self._packed
         enc, dec = self.encoder, self.decoder
         hp = self.precision == "high"
         pk = dict(key=key)
@@ -693,11 +699,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return out, out_lo, P, (h, w)
 
     # ---------------------------------------------------------------- fusion decoder on the HIP kernels
-    def _decode_sample(self, pk, enc_hi, enc_lo, Ps, emb_rows, v_lo, kvx):
+    def _decode_sample(self, pk, enc_hi, enc_lo, Ps, emb_rows, v_lo, kvx, f32_hooks=False):
         """Fast3RDecoder.forward / LlamaDecoder.forward (fast3r.py:768-808 / :924-966) for ONE sample: enc_hi [T_loc][Denc] lowp (the
         local views' encoder tokens, view after view; enc_lo = their low plane or None), Ps = tokens per local view, emb_rows
         (N_total, D) fp32 = the image-id rows of ALL views (this rank's are [v_lo, v_lo + len(Ps))).  Returns the 4 hooked
-        outputs (fast3r.py:148) as (plane, low plane or None) pairs."""
+        outputs (fast3r.py:148) as (plane, low plane or None) pairs; f32_hooks: as (fp32 tensor, None) instead, i.e. before the rounding
+        to the heads' operand format (decode_tokens: parity of the decoder alone)."""
         dec = self.decoder
         lp = self.compute_dtype
         sp = "w2" if self.precision == "high" else None
@@ -710,6 +717,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         D = dec.embed_dim
         T_loc, n_loc = sum(Ps), len(Ps)
         x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
+        planes = (lambda t: (t.clone(), None)) if f32_hooks else self._planes
+        want_f32_norm = f32_hooks or self.precision == "high"
         if llama:
             # embed; per layer add view0_embed to the tokens of view 0, then the block with the rotary angles of each token's view;
             # outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
@@ -723,17 +732,17 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             view0_rows = Ps[0] if v_lo == 0 else 0                          # view 0 lives on the rank that owns the first views
             taps = {}
             if 0 in hooks:
-                taps[0] = self._planes(x)
+                taps[0] = planes(x)
             for li, pb in enumerate(pk["dec"]):
                 ops.rows_add(x, pk["view0"], view0_rows)
                 self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx)
                 if (li + 1) in hooks and (li + 1) != L:
-                    taps[li + 1] = self._planes(x)
+                    taps[li + 1] = planes(x)
             if L in hooks:
                 w_, b_, eps = pk["dec_norm"]
-                if self.precision == "high":
+                if want_f32_norm:
                     _, y = ops.layernorm(x, w_, None, eps, lp, want_lp=False, want_f32=True, rms=True)
-                    taps[L] = self._planes(y)
+                    taps[L] = planes(y)
                 else:
                     taps[L] = (ops.layernorm(x, w_, None, eps, lp, rms=True)[0], None)
         else:
@@ -745,23 +754,24 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     ops.gemm(enc_hi[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo + i:v_lo + i + 1].contiguous(),
                              rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]], split=sp)
                     r0 += Ps[i]
-            taps = {0: (enc_hi, enc_lo)}
+            taps = {0: (enc_hi.float(), None) if f32_hooks else (enc_hi, enc_lo)}
             for li, pb in enumerate(pk["dec"]):
                 self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
                 if (li + 1) in hooks[1:3]:
-                    taps[li + 1] = self._planes(x)
+                    taps[li + 1] = planes(x)
             w_, b_, eps = pk["dec_norm"]
-            if self.precision == "high":
+            if want_f32_norm:
                 _, y = ops.layernorm(x, w_, b_, eps, lp, want_lp=False, want_f32=True)
-                taps[L] = self._planes(y)
+                taps[L] = planes(y)
             else:
                 taps[L] = (ops.layernorm(x, w_, b_, eps, lp)[0], None)
         return [taps[hk] for hk in hooks]
 
     @torch.no_grad()
-    def decode_tokens(self, enc_tokens, tokens_per_view, image_ids):
+    def decode_tokens(self, enc_tokens, tokens_per_view, image_ids, return_f32=False):
         """The fusion decoder alone (BASELINE configs[1]: "fusion transformer only, frozen random encoder"): enc_tokens lowp
-        [sum(tokens_per_view)][enc_embed_dim] on the GPU, image_ids (N,) or (1, N) long -> the 4 hooked outputs, lowp [T][D]."""
+        [sum(tokens_per_view)][enc_embed_dim] on the GPU, image_ids (N,) or (1, N) long -> the 4 hooked outputs [T][D], lowp as the
+        heads read them, or fp32 before that rounding with return_f32."""
         dev = enc_tokens.device
         if dev.type != "cuda":
             raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (tokens are on {dev}); there is no CPU fallback")
@@ -773,7 +783,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             enc_lo = None
             if self.precision == "high" and not isinstance(self.decoder, LlamaDecoder):
                 enc_lo = torch.zeros_like(enc_tokens)
-            out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None)
+            out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None, f32_hooks=return_f32)
             return [t[0] for t in out]
 
     # ---------------------------------------------------------------- DPT head on the HIP kernels

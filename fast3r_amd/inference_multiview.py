@@ -1,15 +1,22 @@
 """`inference()` with the reference's signature and return structure
 (fast3r/dust3r/inference_multiview.py:70-99 -> loss_of_one_batch :22-67), driving fast3r_amd.Fast3R.
 
-Precision argument.  The reference turns `dtype` into a torch.autocast context (:41-52): "32" disables autocast,
+Precision argument.  The reference turns `dtype` into a torch.autocast context (:41-52): "32" disables autocast (true fp32),
 "16-mixed" -> fp16, "bf16-mixed" / torch.bfloat16 -> bf16, and anything else -- notably torch.float32, which the
 demo passes -- silently falls through to the *default* autocast dtype.  Here the argument
-selects the MFMA operand type of the HIP kernels: fp16 for "16-mixed"/torch.float16, bf16 for
-"bf16-mixed"/"bf16-mixed-no-grad-scaling"/torch.bfloat16, and the model's own `compute_dtype` (fp16 by default)
-for "32"/torch.float32/anything else.  Accumulation, residual stream, LayerNorm, softmax and outputs are always
-fp32, so every mode is at least as precise as the reference's mixed-precision modes; the measured distance to the
+selects the operand format of the HIP kernels:
+    "16-mixed" / torch.float16                                     fp16 operands, the model's `precision`
+    "bf16-mixed" / "bf16-mixed-no-grad-scaling" / torch.bfloat16   bf16 operands, the model's `precision`
+    "32" / torch.float32                                           the closest thing this path has to fp32: fp16 operands with
+                                                                   precision="high" (split hi + lo planes, ~22 significand bits on the
+                                                                   weights and in the heads) -- NOT an fp32 MFMA
+                                                                   path; a one-time warning says so
+    anything else                                                  the model's own compute_dtype / precision
+Accumulation, residual stream, LayerNorm, softmax and outputs are always fp32; the measured distance of every mode to the
 reference's true-fp32 CPU path is recorded in DESIGN.md.
 """
+import warnings
+
 import numpy as np
 import torch
 
@@ -57,12 +64,24 @@ def check_if_same_size(imgs):
     return all(s == shapes[0] for s in shapes)
 
 
-def _operand_dtype(precision, model):
+_warned_fp32 = False
+
+
+def _operand_format(precision, model):
+    """-> (compute_dtype, precision mode) for this call (see the module docstring)."""
+    global _warned_fp32
     if precision in ("16-mixed", torch.float16):
-        return torch.float16
+        return torch.float16, model.precision
     if precision in ("bf16-mixed", "bf16-mixed-no-grad-scaling", torch.bfloat16):
-        return torch.bfloat16
-    return model.compute_dtype
+        return torch.bfloat16, model.precision
+    if precision in ("32", 32, torch.float32):
+        if not _warned_fp32:
+            warnings.warn("fast3r_amd.inference(dtype='32'): there is no fp32 MFMA path; running fp16 operands with split hi + lo planes "
+                          "(precision='high': ~22-bit weights and head activations, fp16 attention operands, fp32 accumulation).",
+                          stacklevel=3)
+            _warned_fp32 = True
+        return torch.float16, "high"
+    return model.compute_dtype, model.precision
 
 
 def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_batch=False, use_amp=False, ret=None,
@@ -72,12 +91,12 @@ def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_bat
             if name in view:
                 view[name] = view[name].to(device, non_blocking=True)
     net = getattr(model, "net", model)  # accept the MultiViewDUSt3RLitModule shim too
-    saved = net.compute_dtype
-    net.compute_dtype = _operand_dtype(precision, net)
+    saved = (net.compute_dtype, net.precision)
+    net.compute_dtype, net.precision = _operand_format(precision, net)
     try:
         out = model(batch, profiling=profiling) if net is model else (net(batch, profiling=profiling))
     finally:
-        net.compute_dtype = saved
+        net.compute_dtype, net.precision = saved
     preds, profiling_info = out if profiling else (out, None)
     loss = criterion(batch, preds) if criterion is not None else None
     result = dict(views=batch, preds=preds, loss=loss)
