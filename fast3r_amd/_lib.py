@@ -89,6 +89,8 @@ SYMBOLS = {
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libf3r_hip.so")
+if os.environ.get("F3R_LAB_LIB"):  # measurement builds only (tools/lab: kernels with ablation bits); never set by the product or the tests
+    LIB_PATH = os.environ["F3R_LAB_LIB"]
 _lib = None
 
 

@@ -93,6 +93,7 @@ __device__ __forceinline__ typename T::vec8 as_vec8(u32x4 v) {
 // f3r_gemm256.hip: the 256x256-tile kernel behind f3r_gemm for large regular shapes
 bool f3r_gemm256_eligible(const f3r_gemm_args& a);
 int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger);
+int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_LAB builds only (tools/lab)
 
 // host-side error plumbing (f3r_capi.cpp)
 void f3r_set_error(const char* fmt, ...);

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
   // ------------------------------------------------------------------ epilogues (f3r_gemm_epi.h)
   const int64_t m_base = m0 + wm * 64;
   const int n_base = n0 + wn * 64;
-  if (swap_roles) gemm_epilogue_vt<T, 4, 4, true>(p, &acc[0][0], m_base, n_base, lane);
-  else gemm_epilogue_default<T, EPI, 4, 4, true>(p, &acc[0][0], m_base, n_base, lane);
+  if (swap_roles) gemm_epilogue_vt<T, GemmFragLayout<4, 4, 4, 4>, true>(p, &acc[0][0], m_base, n_base, lane);
+  else gemm_epilogue_default<T, EPI, GemmFragLayout<4, 4, 4, 4>, true>(p, &acc[0][0], m_base, n_base, lane);
 }
 
 template <class T, int A_MODE, int EPI, int GLDS>
@@ -315,7 +315,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;
   F3R_REQUIRE(a.split != F3R_SPLIT_X3 || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 split needs A_lo (16-byte aligned) and no a_relu");
-  F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 3, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
+  F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 3) || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
   F3R_REQUIRE(a.N % 4 == 0, "f3r_gemm: N %d must be a multiple of 4", a.N);
   F3R_REQUIRE(al16(a.A) && al16(a.W), "f3r_gemm: A/W must be 16-byte aligned");
   F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_gemm: bad dtype %d", a.dtype);
@@ -362,6 +362,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   // kernel_sel: 0 = by shape (256-tile kernel for the large, regular problems), 1 = 128-tile kernel, 2 / 3 = 256-tile kernel with /
   // without the staggered wave rows (measurement; an ineligible shape is an error, not a silent fallback)
+  if (a.kernel_sel >= 16) return f3r_gemm256_lab(a, s);
   if (a.kernel_sel >= 2) F3R_REQUIRE(f3r_gemm256_eligible(a), "f3r_gemm: kernel_sel %d but the shape is not eligible for the 256-tile kernel", a.kernel_sel);
   if (a.kernel_sel >= 2 || (a.kernel_sel == 0 && f3r_gemm256_eligible(a))) return f3r_gemm256_launch(a, s, a.kernel_sel != 3);
   return a.dtype == F3R_F16 ? dispatch<F16>(a, s) : dispatch<BF16>(a, s);

@@ -2,27 +2,27 @@
 //
 // One 512-thread workgroup (8 waves, 2 per SIMD) per CU, 128 KiB of LDS: two K-tile buffers of four 16 KiB HALF TILES each
 // (A rows 0-127 / 128-255, W rows 0-127 / 128-255; [128 rows][64 k] 16-bit, 128-byte rows, 16-byte chunk c of row r stored at chunk
-// c ^ ((r >> 1) & 7): every ds_read_b128 lane group covers the 64 banks exactly once).  Waves are 2 (M) x 4 (N); a wave owns a
-// 128 x 64 output sub-tile = 8 x 4 fragments of v_mfma_f32_16x16x32 (128 fp32 accumulator registers) and therefore reads ONE A half
-// tile (wm) and one W half tile (wn >> 1).
+// c ^ ((r >> 1) & 7): every ds_read_b128 lane group covers the 64 banks exactly once).  Waves are 2 (M) x 4 (N); a wave owns 128 x 64
+// outputs = 8 x 4 fragments of v_mfma_f32_16x16x32 (128 fp32 accumulator registers), taken as rows wm*64..+63 of BOTH A half tiles and
+// columns wn*32..+31 of BOTH W half tiles: an output quadrant (A half mh, W half nh) then touches exactly one A and one W half tile, every
+// half tile is read in ONE phase of the K-tile by all waves, and its LDS slot is free for the next load two phases later.
 //
 // Schedule (cdna_hip_programming.md "256^2 8-phase", re-derived here because every wait below is placed by counting):
-//   * a K-tile is 4 PHASES, one 64 x 32 output quadrant x K = 64 each (16 MFMAs); fragment reads 12 / 8 / 4 / 0 ds_read_b128 per
-//     phase = 24 per 64 MFMAs (0.375 per MFMA): quadrants (A0,W0) (A1,W0) (A1,W1) (A0,W1) keep both A halves in registers;
-//   * all global -> LDS traffic is LDS-DMA (global_load_lds, 16 B per lane, no staging registers): ONE half tile (2 instructions per
-//     wave) per phase, issued at least a K-tile ahead for the streamed operand:
-//         phase 0 of tile t:  A half 1 of tile t+1        phase 1:  W half 0 of tile t+1
-//         phase 2          :  W half 1 of tile t+1        phase 3:  A half 0 of tile t+2, then s_waitcnt vmcnt(2)
-//     so the DMA queue is never drained in the loop (vmcnt(2) leaves the half tile just issued in flight across the barriers) and an
-//     A half tile has ~4 phases (~2000 cycles) to arrive -- HBM latency -- while the L2-resident W has ~2;
+//   * a K-tile is 4 PHASES, one 64 x 32 output quadrant x K = 64 each (16 MFMAs); quadrants (A0,W0) (A1,W0) (A1,W1) (A0,W1) keep
+//     both A halves in registers: 12 / 8 / 4 / 0 ds_read_b128 per phase = 24 per 64 MFMAs (0.375 per MFMA);
+//   * all global -> LDS traffic is LDS-DMA (global_load_lds, 16 B per lane, no staging registers), ONE half tile (2 instructions per
+//     wave) per phase, each issued 5-6 phases (~1.5 K-tiles, ~3000 cycles: HBM latency under load) before the phase that reads it:
+//         phase 0 of tile t:  A half 1 of tile t+1        phase 1:  W half 1 of tile t+1
+//         phase 2          :  A half 0 of tile t+2        phase 3:  W half 0 of tile t+2
+//     with s_waitcnt vmcnt(8) in phases 0, 1 and 3: the DMA queue is never drained in the loop, FOUR half tiles stay in flight across
+//     the barriers, and what each wait retires is exactly the half tile the NEXT phase reads;
 //   * the two wave rows (wm = 0 / 1, one wave of each per SIMD) run STAGGERED by one barrier: while one does its 16 MFMAs (s_setprio 1)
 //     the other issues its ds_reads and LDS-DMA, so the matrix pipe and the LDS / TA pipes alternate owners instead of colliding;
 //   * every phase is  [ds_reads, LDS-DMA, (vmcnt)] s_barrier [lgkmcnt(0), 16 MFMA] s_barrier.
 // Hazards, with the stagger (a wave of row 1 is one barrier behind a wave of row 0):
-//   RAW  LDS-DMA data may be read one phase after the phase whose FIRST barrier follows the issuers' vmcnt wait: the wait sits in
-//        phase 3 before its first barrier, the first read of the tile in phase 0 of the next tile;
-//   WAR  a half tile may be re-staged two phases after the phase that issued its last read: A halves (last read: phase 1) from
-//        phase 3, W halves (last read: phase 2) from phase 0 of the next tile -- the table above restages A at phase 3 / 0 and W at 1 / 2.
+//   RAW  LDS-DMA data may be read one phase after the phase whose FIRST barrier follows the issuers' vmcnt wait;
+//   WAR  a half tile may be re-staged two phases after the phase that issued its last read.  Reads: A0, W0 in phase 0, A1 in phase 1, W1
+//        in phase 2.  Restaged: A0 in phase 2, W0 in phase 3, A1 in phase 0 of the next tile (other buffer: 3 phases), W1 in phase 1.
 //
 // Operand roles, epilogues, the split-precision K segments and the LDS swizzle are those of f3r_gemm.hip; the implicit-GEMM 3x3
 // convolution stages its operand by LDS-DMA too: out-of-image taps read a 16-byte zero line instead of being predicated.
@@ -49,7 +49,11 @@ struct IC {
 #define F3R_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))   /* vmcnt(n), n <= 15; lgkmcnt / expcnt untouched */
 #define F3R_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0); vmcnt untouched */
 
-template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC>
+// LAB (tools/lab builds only, -DF3R_GEMM_LAB; 0 in the product): ablation / alternative bits measured by tools/kernel_bench.py --what lab
+//   1 no LDS-DMA in the loop   2 no fragment reads in the loop   4 no MFMAs   8 no vmcnt wait   16 no s_setprio
+//   32 buffer_load ... lds through a buffer descriptor instead of global_load_lds   64 no sched_barrier pinning of the load section
+// (1, 2, 4, 8 compute garbage by construction: timing only)
+template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int LAB = 0>
 __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, int64_t m0, int n0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,11 +123,20 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       if (w_kk == nk1) { w_kk = 0; ++w_seg; }
     }
   };
+  bool in_loop = false;  // LAB only
   auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
+    if ((LAB & 1) && in_loop) return;
     const char* plane = (a_seg == 2) ? Alo : Ab;
     uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
     if (A_MODE == F3R_A_PLAIN) {
       const char* base = plane + (m0 * p.lda + (int64_t)a_kk * BK) * 2;
+      if (LAB & 32) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(plane + m0 * p.lda * 2), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)a_off[h][i], a_kk * BK * 2, 0, 0);
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + a_off[h][i]), (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
@@ -139,41 +152,52 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     }
   };
   auto issue_w = [&](int h, int buf) {
+    if ((LAB & 1) && in_loop) return;
     const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
     uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
+    if (LAB & 32) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)w_off[h][i], ((w_seg == 1 ? Kpad1 : 0) + w_kk * BK) * 2, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + w_off[h][i]), (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
   };
 
-  // ------------------------------------------------------------------ fragment read addressing (elements inside a buffer)
+  // ------------------------------------------------------------------ fragment read addressing (elements inside a half tile)
   const int sw = (fr >> 1) & 7;
   int a_rd[2], w_rd[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int pc = ((ks * 4 + fg) ^ sw) << 3;
-    a_rd[ks] = wm * HT + fr * 64 + pc;
-    w_rd[ks] = (2 + (wn >> 1)) * HT + ((wn & 1) * 64 + fr) * 64 + pc;
+    a_rd[ks] = (wm * 64 + fr) * 64 + pc;
+    w_rd[ks] = (wn * 32 + fr) * 64 + pc;
   }
 
   float4v acc[32];
   typename T::vec8 fa0[2][4], fa1[2][4], fw[2][2];
 
   auto read_a = [&](typename T::vec8 (&f)[2][4], int buf, int mh) {
+    if ((LAB & 2) && in_loop) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf)
-        f[ks][mf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + a_rd[ks] + (mh * 64 + mf * 16) * 64));
+        f[ks][mf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[ks] + mf * 16 * 64));
   };
   auto read_w = [&](int buf, int nh) {
+    if ((LAB & 2) && in_loop) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
-        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + w_rd[ks] + (nh * 32 + nf * 16) * 64));
+        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * 16 * 64));
   };
   auto mma = [&](const typename T::vec8 (&f)[2][4], int mh, int nh) {
+    if (LAB & 4) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -187,77 +211,68 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   };
 
   // one K-tile out of buffer B (compile-time), 4 phases
+#define F3R_PHASE_MMA(FA, MH, NH)                        \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  __builtin_amdgcn_s_barrier();                          \
+  F3R_LGKMCNT0();                                        \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  if (!(LAB & 16)) __builtin_amdgcn_s_setprio(1);        \
+  mma(FA, MH, NH);                                       \
+  if (!(LAB & 16)) __builtin_amdgcn_s_setprio(0);        \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  __builtin_amdgcn_s_barrier();
   auto tile = [&](auto bufc) {
     constexpr int B = decltype(bufc)::value;
-    // ---- phase 0: quadrant (A0, W0)
+    // ---- phase 0: quadrant (A0, W0); A half 1 of the next tile; retire what phase 1 reads (A half 1 of this tile)
     read_w(B, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
     read_a(fa0, B, 0);
     issue_a(1, B ^ 1);
     a_advance();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    F3R_LGKMCNT0();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma(fa0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1: quadrant (A1, W0)
+    if (!(LAB & 8)) F3R_VMCNT(8);
+    F3R_PHASE_MMA(fa0, 0, 0)
+    // ---- phase 1: quadrant (A1, W0); W half 1 of the next tile; retire W half 1 of this tile (phase 2 reads it)
     read_a(fa1, B, 1);
-    issue_w(0, B ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    F3R_LGKMCNT0();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma(fa1, 1, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2: quadrant (A1, W1)
-    read_w(B, 1);
     issue_w(1, B ^ 1);
     w_advance();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    F3R_LGKMCNT0();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma(fa1, 1, 1);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3: quadrant (A0, W1); A half 0 two tiles ahead, then retire everything older (= all of the next tile)
+    if (!(LAB & 8)) F3R_VMCNT(8);
+    F3R_PHASE_MMA(fa1, 1, 0)
+    // ---- phase 2: quadrant (A1, W1); A half 0 two tiles ahead (its slot was last read in phase 0)
+    read_w(B, 1);
     issue_a(0, B);
-    F3R_VMCNT(2);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma(fa0, 0, 1);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    F3R_PHASE_MMA(fa1, 1, 1)
+    // ---- phase 3: quadrant (A0, W1); W half 0 two tiles ahead; retire A half 0 and W half 0 of the next tile (its phase 0 reads them)
+    issue_w(0, B);
+    if (!(LAB & 8)) F3R_VMCNT(8);
+    F3R_PHASE_MMA(fa0, 0, 1)
   };
+#undef F3R_PHASE_MMA
 
-  // ------------------------------------------------------------------ prologue: all of tile 0 and A half 0 of tile 1
+  // ------------------------------------------------------------------ prologue: all of tile 0 and the first halves of tile 1
   // The bias and the additive epilogue terms (fp32 / lowp residuals, image-id rows) are loaded FIRST, straight into the accumulators:
   // they land under the latency of the first tiles (f3r_gemm_epi.h); the compiler's own wait covers their first use.
-  gemm_acc_init_additive<T, 4, 8, ADDSRC, SWAP>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  typedef GemmFragLayout<4, 8, 2, 4> Frag;  // 2 x 2 fragments from each W half, 4 fragments from each A half
+  const int64_t m_base = m0 + wm * 64;
+  const int n_base = n0 + wn * 32;
+  gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
   issue_a(0, 0);
+  issue_w(0, 0);
   issue_a(1, 0);
   a_advance();
-  issue_w(0, 0);
   issue_w(1, 0);
   w_advance();
   issue_a(0, 1);
-  F3R_VMCNT(2);
+  issue_w(0, 1);
+  F3R_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed; the four younger half tiles stay in flight
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
 
-  for (int t = 0; t < nk; t += 2) {
+  if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
+    tile(IC<0>{});
+    if (nk > 1) tile(IC<1>{});
+    in_loop = true;
+  }
+  for (int t = LAB ? 2 : 0; t < nk; t += 2) {
     tile(IC<0>{});
     if (t + 1 < nk) tile(IC<1>{});
   }
@@ -267,10 +282,8 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
 
   // ------------------------------------------------------------------ epilogue
-  const int64_t m_base = m0 + wm * 128;
-  const int n_base = n0 + wn * 64;
-  if (SWAP) gemm_epilogue_vt<T, 4, 8, false>(p, acc, m_base, n_base, lane);
-  else gemm_epilogue_default<T, EPI, 4, 8, false>(p, acc, m_base, n_base, lane);
+  if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
+  else gemm_epilogue_default<T, EPI, Frag, false>(p, acc, m_base, n_base, lane);
 }
 
 template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC>
@@ -332,7 +345,39 @@ int dispatch256(const f3r_gemm_args& a, hipStream_t stream, int stagger) {
 #undef F3R_L256
 }
 
+#ifdef F3R_GEMM_LAB
+template <class T, int LAB>
+__global__ __launch_bounds__(NT, 1) void gemm256_lab_kernel(const f3r_gemm_args p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int n_tiles_n = (p.N + BN - 1) / BN;
+  const int64_t wg = blockIdx.x;
+  gemm256_body<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false, 1, F3R_ADD_NONE, LAB>(p, smem, (wg / n_tiles_n) * BM, (int)(wg % n_tiles_n) * BN);
+}
+template <class T, int LAB>
+int launch_lab(const f3r_gemm_args& a, hipStream_t stream) {
+  auto kern = gemm256_lab_kernel<T, LAB>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, a);
+  return f3r_check_launch("f3r_gemm(256 lab)");
+}
+#endif
+
 }  // namespace
+
+// Measurement builds only: kernel_sel = 16 + LAB bits (bf16, plain operand, generic epilogue, no additive terms)
+int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream) {
+#ifdef F3R_GEMM_LAB
+  switch (a.kernel_sel - 16) {
+#define F3R_LAB_CASE(n) case n: return launch_lab<BF16, n>(a, stream);
+    F3R_LAB_CASE(0) F3R_LAB_CASE(1) F3R_LAB_CASE(2) F3R_LAB_CASE(3) F3R_LAB_CASE(4) F3R_LAB_CASE(7) F3R_LAB_CASE(8) F3R_LAB_CASE(16)
+    F3R_LAB_CASE(32) F3R_LAB_CASE(33) F3R_LAB_CASE(64) F3R_LAB_CASE(96)
+#undef F3R_LAB_CASE
+  }
+#endif
+  f3r_set_error("f3r_gemm: kernel_sel %d is not available in this build", a.kernel_sel);
+  return F3R_ERR_ARG;
+}
 
 // Whether the 256-tile kernel takes this (already validated) problem: everything its LDS-DMA staging cannot express -- K tails, ragged
 // channel counts, strided or pre-activated conv operands, small or narrow outputs -- stays on the 128-tile kernel.

@@ -1,13 +1,23 @@
 // Epilogues shared by the two MFMA GEMM kernels (f3r_gemm.hip: 128x128 tile, f3r_gemm256.hip: 256x256 tile).
 //
 // Both kernels hand over a wave's accumulators as 16x16 fp32 fragments of v_mfma_f32_16x16x32 (lane l holds D[4*(l>>4) + j][l & 15],
-// j = 0..3) over a wave sub-tile of MF m-fragments x NF n-fragments whose origin is (m_base, n_base):
+// j = 0..3) over a wave sub-tile of MF m-fragments x NF n-fragments whose origin is (m_base, n_base).  Fragment mf covers rows
+// m_base + (mf / MG) * 128 + (mf % MG) * 16 .. + 15 and fragment nf columns n_base + (nf / NG) * 128 + (nf % NG) * 16 .. + 15, where
+// (MG, NG) = fragments per contiguous group: the 128-tile kernel has one group each (MG = MF, NG = NF), the 256-tile kernel takes
+// its 128 x 64 sub-tile as two row groups and two column groups, one from each HALF TILE (see f3r_gemm256.hip).  Layout struct L.
 //   default roles  (weights = MFMA A operand): fragment (nf, mf) at acc[nf * MF + mf]; a lane owns 4 consecutive n of one row m
 //                  -> every epilogue access (bias, residual, fp32 / lowp stores) is a 16 B / 8 B vector along n;
 //   swapped roles  (activations = MFMA A operand; V third of the QKV epilogue): fragment (mf, nf) at acc[mf * NF + nf]; a lane owns 4
 //                  consecutive tokens of one channel and writes V transposed with 8 B stores.
 #pragma once
 #include "f3r_common.h"
+
+template <int NF_, int MF_, int NG_, int MG_>
+struct GemmFragLayout {
+  static constexpr int NF = NF_, MF = MF_, NG = NG_, MG = MG_;
+  static __device__ __forceinline__ int row(int mf) { return (mf / MG) * 128 + (mf % MG) * 16; }
+  static __device__ __forceinline__ int col(int nf) { return (nf / NG) * 128 + (nf % NG) * 16; }
+};
 
 // Exact (erf) GELU, nn.GELU() default (blocks.py:84).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp,
 // five FMAs, one v_exp -- libm's erff costs ~40 instructions per element and made the fc1 epilogue as long as its K loop.
@@ -109,15 +119,16 @@ inline int gemm_additive_pattern(const f3r_gemm_args& a) {
   return a.rowadd ? F3R_ADD_ROWADD : (a.res_f32 ? F3R_ADD_RES_F32 : F3R_ADD_RES_LP);
 }
 
-template <class T, int NF, int MF, int SRC, bool SWAP>
+template <class T, class L, int SRC, bool SWAP>
 __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, float4v* acc, int64_t m_base, int n_base, int lane) {
+  constexpr int NF = L::NF, MF = L::MF;
   const int fr = lane & 15, fg = lane >> 4;
   // The bias goes in through the accumulators as well (act(sum + b) with the sum started at b): the epilogue then has no load that
   // a store could be waiting behind.
   if (SWAP) {  // swapped roles: a lane owns 4 tokens of ONE channel n = fr
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-      const int n = n_base + nf * 16 + fr;
+      const int n = n_base + L::col(nf) + fr;
       const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[mf * NF + nf] = float4v{b, b, b, b};
@@ -128,7 +139,7 @@ __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, f
   float4v bias4[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    const int nb = n_base + nf * 16 + fg * 4;
+    const int nb = n_base + L::col(nf) + fg * 4;
     nbc[nf] = nb < p.N ? nb : p.N - 4;
     bias4[nf] = p.bias ? *(const float4v*)(p.bias + nbc[nf]) : float4v{0.f, 0.f, 0.f, 0.f};
   }
@@ -142,7 +153,7 @@ __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, f
   int64_t mc[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
-    const int64_t m = m_base + mf * 16 + fr;
+    const int64_t m = m_base + L::row(mf) + fr;
     mc[mf] = m < p.M ? m : p.M - 1;
   }
   if (SRC == F3R_ADD_RES_F32) {
@@ -194,8 +205,9 @@ __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, f
 // loses track of a load waited for inside a conditionally executed fragment body and would wait vmcnt(0) -- i.e. for the previous
 // fragment's STORES too -- at the top of every body.
 #define F3R_EPI_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
-template <class T, int EPI, int NF, int MF, bool ADD>
+template <class T, int EPI, class L, bool ADD>
 __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
+  constexpr int NF = L::NF, MF = L::MF;
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int MB = 4;  // fragment rows per batch
   static_assert(MF % MB == 0, "MF must be a multiple of the batch");
@@ -203,7 +215,7 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
   float4v bias4[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    nb[nf] = n_base + nf * 16 + fg * 4;
+    nb[nf] = n_base + L::col(nf) + fg * 4;
     nbc[nf] = nb[nf] < p.N ? nb[nf] : p.N - 4;
     bias4[nf] = (ADD && p.bias) ? *(const float4v*)(p.bias + nbc[nf]) : float4v{0.f, 0.f, 0.f, 0.f};  // !ADD: already in acc
   }
@@ -214,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
       int64_t m[MB], mc[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
-        m[i] = m_base + (mb + i) * 16 + fr;
+        m[i] = m_base + L::row(mb + i) + fr;
         mc[i] = m[i] < p.M ? m[i] : p.M - 1;
       }
       float4v add[MB][NF];
@@ -267,31 +279,33 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
         }
       }
     }
-  } else {  // ------------------------------------------------------------ QKV, q or k third (NF == 4: the wave's 64 columns are one head)
-    static_assert(EPI != F3R_EPI_QKV || NF == 4, "a wave's columns must be exactly one 64-wide head");
+  } else {  // ------------------------------------------------------------ QKV, q or k third
+    // A column group of a wave (NG fragments = NG*16 columns, 32 or 64 wide and aligned) lies inside ONE head and inside whole 32-column
+    // halves of it: RoPE pairs dim i with i + 16 inside a half, i.e. fragments (2j, 2j+1) of a lane.
+    static_assert(EPI != F3R_EPI_QKV || (L::NG % 2 == 0 && NF % 2 == 0), "RoPE pairs need an even number of fragments per column group");
     const int Dm = p.N / 3;
-    const int part = n_base / Dm;  // 0 q, 1 k (wave-uniform)
+    const int part = n_base / Dm;  // 0 q, 1 k (wave-uniform; every column group of the tile is in the same third: Dm % tile width == 0)
     uint16_t* dst = (uint16_t*)(part == 0 ? p.q : p.k);
     const float qs = (part == 0 && p.q_scale != 0.f) ? p.q_scale : 1.f;
 #pragma unroll
     for (int mb = 0; mb < MF; mb += MB) {
       int64_t m[MB];
-      float4v c[MB][2], sn[MB][2];
+      float4v c[MB][NF / 2], sn[MB][NF / 2];
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
-        m[i] = m_base + (mb + i) * 16 + fr;
+        m[i] = m_base + L::row(mb + i) + fr;
         if (p.rope_cos) {
-          // RoPE-2D (pos_embed.py:162-183): the wave's 64 columns are one head; dims [0,32) rotate by the
-          // row position y, [32,64) by the column position x; dim i pairs with i+16 inside each half.
+          // RoPE-2D (pos_embed.py:162-183): dims [0,32) of a head rotate by the row position y, [32,64) by the column position x
           const int64_t mc = m[i] < p.M ? m[i] : p.M - 1;
           const int pos = (int)(mc % p.seq_len);
           const int py = pos / p.rope_w, px = pos - py * p.rope_w;
           const int64_t grp = mc / p.rope_w;  // rope_mode 1: one angle set per row group (LlamaDecoder: per view)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int j = 0; j < NF / 2; ++j) {
+            const int h = ((n_base + L::col(2 * j)) >> 5) & 1;  // which 32-dim half of its head this fragment pair is (wave-uniform)
             const int64_t toff = p.rope_mode == 1 ? grp * 32 + h * 16 : (int64_t)(h == 0 ? py : px) * 16;
-            c[i][h] = *(const float4v*)(p.rope_cos + toff + fg * 4);
-            sn[i][h] = *(const float4v*)(p.rope_sin + toff + fg * 4);
+            c[i][j] = *(const float4v*)(p.rope_cos + toff + fg * 4);
+            sn[i][j] = *(const float4v*)(p.rope_sin + toff + fg * 4);
           }
         }
       }
@@ -299,39 +313,40 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         if (m[i] >= p.M) continue;
-        float4v v[4];
+        float4v v[NF];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) v[nf] = acc[nf * MF + mb + i] + bias4[nf];
+        for (int nf = 0; nf < NF; ++nf) v[nf] = acc[nf * MF + mb + i] + bias4[nf];
         if (p.rope_cos) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const float4v a = v[2 * h], b = v[2 * h + 1];
-            v[2 * h] = a * c[i][h] - b * sn[i][h];
-            v[2 * h + 1] = b * c[i][h] + a * sn[i][h];
+          for (int j = 0; j < NF / 2; ++j) {
+            const float4v a = v[2 * j], b = v[2 * j + 1];
+            v[2 * j] = a * c[i][j] - b * sn[i][j];
+            v[2 * j + 1] = b * c[i][j] + a * sn[i][j];
           }
         }
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) store4_split<T>(dst + m[i] * (int64_t)Dm + (nb[nf] - part * Dm), nullptr, v[nf] * qs);
+        for (int nf = 0; nf < NF; ++nf) store4_split<T>(dst + m[i] * (int64_t)Dm + (nb[nf] - part * Dm), nullptr, v[nf] * qs);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------ swapped roles: the V third of QKV -> vt[seq][d][token]
-template <class T, int NF, int MF, bool BIAS>
+template <class T, class L, bool BIAS>
 __device__ __forceinline__ void gemm_epilogue_vt(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
+  constexpr int NF = L::NF, MF = L::MF;
   const int fr = lane & 15, fg = lane >> 4;
   const int Dm = p.N / 3;
   uint16_t* vt = (uint16_t*)p.vt;
   const bool vec_ok = ((p.seq_len | p.ldvt) & 3) == 0;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    const int n = n_base + nf * 16 + fr;  // < N
+    const int n = n_base + L::col(nf) + fr;  // < N
     const int d = n - 2 * Dm;
     const float bb = (BIAS && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const int64_t mb = m_base + mf * 16 + fg * 4;
+      const int64_t mb = m_base + L::row(mf) + fg * 4;
       if (mb >= p.M) continue;
       const float4v v = acc[mf * NF + nf] + bb;
       if (vec_ok) {  // seq_len % 4 == 0 -> the 4 tokens share a sequence; M % 4 == 0 follows

@@ -124,6 +124,36 @@ def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3)
                           "tflops_mfma": round(2.0 * M * N * K * mult / ms / 1e9, 1)}), flush=True)
 
 
+LAB_BITS = {0: "lab baseline (staggered)", 1: "no LDS-DMA in loop", 2: "no fragment reads", 3: "no DMA, no reads (MFMA + barriers)", 4: "no MFMA",
+            7: "barriers only", 8: "no vmcnt wait", 16: "no s_setprio", 32: "buffer_load lds", 33: "buffer_load, no DMA (sanity)",
+            64: "no sched_barrier pin", 96: "buffer_load + no pin"}
+
+
+def bench_lab(M, N, K):
+    """Ablations of the 256-tile kernel (tools/lab/libf3r_hip_lab.so, F3R_LAB_LIB): which section of the phase costs what."""
+    dt = torch.bfloat16
+    a = torch.randn((M, K), device=DEV).to(dt)
+    w = ops.pack_linear_weight(torch.randn((N, K), device=DEV) * K ** -0.5, dt)
+    olp = torch.empty((M, N), dtype=dt, device=DEV)
+    fns = {}
+    for bits in LAB_BITS:
+        def f(bits=bits):
+            ops.gemm(a, w, out_lp=olp, kernel_sel=16 + bits)
+        f()
+        fns[bits] = f
+    fns[-2] = lambda: ops.gemm(a, w, out_lp=olp, kernel_sel=2)
+    fns[-1] = lambda: ops.gemm(a, w, out_lp=olp, kernel_sel=1)
+    res_ms = {b: [] for b in fns}
+    for _ in range(3):
+        for b in fns:
+            res_ms[b].append(time_ms(fns[b], rounds=3, inner=3)[0])
+    for b in fns:
+        ms = sorted(res_ms[b])[1]
+        name = LAB_BITS.get(b, "product 256-tile" if b == -2 else "product 128-tile")
+        print(json.dumps({"kernel": "gemm256_lab", "bits": b, "what": name, "M": M, "N": N, "K": K, "ms": round(ms, 3),
+                          "tflops_nominal": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
+
+
 def bench_qkv(dt, M, D, seq, sels=(1, 2, 3)):
     a = torch.randn((M, D), device=DEV).to(dt)
     w = ops.pack_linear_weight(torch.randn((3 * D, D), device=DEV) * D ** -0.5, dt)
@@ -305,6 +335,10 @@ if __name__ == "__main__":
             bench_attn(dt, nv, variants)
         bench_attn(torch.float16, 20, variants[:3])
         bench_attn_encoder(dt, 64, variants)
+    if "lab" in args.what:
+        bench_lab(40 * 1024, 4096, 1024)
+        bench_lab(40 * 1024, 1024, 4096)
+        sys.exit(0)
     if "gemm" in args.what:
         M = 40 * 1024
         bench_gemm(dt, M, 1024, 1024, "proj+res", res=True)
