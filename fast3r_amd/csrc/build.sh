@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${F3R_EXTRA_FLAGS:-}"
 pids=()
 for f in f3r_gemm f3r_gemm256 f3r_attn f3r_elem f3r_post f3r_pnp f3r_capi; do
-  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/f3r_common.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_gemm_epi.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_attn_lab.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_attn_xp.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_linalg.h" -nt "$here/obj/$f.o" ] || [ "$0" -nt "$here/obj/$f.o" ] || [ "$here/../../include/f3r.h" -nt "$here/obj/$f.o" ]; then
+  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/f3r_common.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_gemm_epi.h" -nt "$here/obj/$f.o" ] || [ "$here/f3r_linalg.h" -nt "$here/obj/$f.o" ] || [ "$0" -nt "$here/obj/$f.o" ] || [ "$here/../../include/f3r.h" -nt "$here/obj/$f.o" ]; then
     extra=""
     # attention: keep MFMA results in VGPRs (the softmax reads them with VALU instructions); with one wave per SIMD the
     # AGPR half of the register file then serves as spill space instead of scratch memory

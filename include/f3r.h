@@ -12,7 +12,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch-ROCm allocator); the
- *     library allocates nothing and keeps no mutable global state except the last-error string;
+ *     library allocates nothing and keeps no mutable state except the calling thread's last-error
+ *     string (kernel choices that used to be process-wide knobs are per-call fields: f3r_gemm_args.kernel_sel);
  *   - every launch is asynchronous on the caller's `stream` (unlike the reference extension,
  *     which launches on the legacy default stream: curope/kernels.cu:102);
  *   - return value: F3R_OK (0) or a negative f3r_status; nothing throws across the boundary.
@@ -196,12 +197,6 @@ typedef struct f3r_attn_args {
 } f3r_attn_args;
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
-
-/* Tuning knob (measurement only): selects the workgroup shape / schedule variant of the attention kernel
- * (fast3r_amd/csrc/f3r_attn.hip, attn_dispatch); -1 restores the default.  All variants compute the same function. */
-int f3r_attn_set_variant(int variant);
-/* Measurement only: per-section cycle totals written by the instrumented variants (host buffer of 8 x u64). */
-int f3r_attn_read_prof(unsigned long long* out8);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_upsample2x: bilinear x2, align_corners=True, NHWC lowp -> NHWC lowp.

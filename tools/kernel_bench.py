@@ -13,6 +13,18 @@ from fast3r_amd import _lib, ops  # noqa: E402
 DEV = "cuda"
 
 
+def lab_lib():
+    """Attention variants (f3r_attn_set_variant / f3r_attn_read_prof) and GEMM ablations exist only in tools/lab/libf3r_hip_lab.so:
+    run with F3R_LAB_LIB=$PWD/tools/lab/libf3r_hip_lab.so (built by tools/lab/build_lab.sh).  The product library has neither."""
+    import ctypes
+    l = _lib.lib()
+    if not hasattr(l, "f3r_attn_set_variant"):
+        sys.exit("attention variants need the lab library: F3R_LAB_LIB=tools/lab/libf3r_hip_lab.so (tools/lab/build_lab.sh)")
+    l.f3r_attn_set_variant.restype, l.f3r_attn_set_variant.argtypes = ctypes.c_int, [ctypes.c_int]
+    l.f3r_attn_read_prof.restype, l.f3r_attn_read_prof.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]
+    return l
+
+
 def time_ms(fn, rounds=5, inner=3):
     best = []
     for _ in range(rounds):
@@ -39,7 +51,7 @@ def bench_attn(dt, views, variants, H=16):
     fns = {}
     for v in variants:
         def f(v=v):
-            _lib.lib().f3r_attn_set_variant(v)
+            lab_lib().f3r_attn_set_variant(v)
             ops.attention(q, o, H, 0.160192, [(k, vt, T, 0, 0)])
         fns[v] = f
         f()
@@ -67,12 +79,29 @@ def bench_attn(dt, views, variants, H=16):
             fns[v]()
             torch.cuda.synchronize()
             buf = (ctypes.c_uint64 * 8)()
-            _lib.lib().f3r_attn_read_prof(buf)
+            lab_lib().f3r_attn_read_prof(buf)
             n = max(1, buf[4])
             print(json.dumps({"kernel": "attn_sections", "variant": v, "tiles": int(buf[4]), "cycles_per_tile": {
                 "qk": round(buf[0] / n), "softmax": round(buf[1] / n), "pv": round(buf[2] / n), "stage+barrier": round(buf[3] / n),
                 "whole_loop": round(buf[5] / n)}}), flush=True)
-    _lib.lib().f3r_attn_set_variant(-1)
+    lab_lib().f3r_attn_set_variant(-1)
+
+
+def bench_attn_product(dt, views, H=16):
+    """The product attention kernel (no variant knob in the product library) on the fusion shape."""
+    T = views * 1024
+    D = H * 64
+    q = torch.randn((T, D), device=DEV).to(dt)
+    k = torch.randn((T, D), device=DEV).to(dt)
+    vt = torch.randn((D, T), device=DEV).to(dt)
+    o = torch.empty((T, D), dtype=dt, device=DEV)
+
+    def f():
+        ops.attention(q, o, H, 0.160192, [(k, vt, T, 0, 0)])
+    f()
+    med, mn = time_ms(f, rounds=3, inner=2)
+    print(json.dumps({"kernel": "attn (product)", "dtype": str(dt).split(".")[-1], "views": views, "T": T, "ms": round(med, 3),
+                      "tflops": round(4.0 * T * T * 64 * H / med / 1e9, 1)}), flush=True)
 
 
 def bench_attn_encoder(dt, views, variants, H=16):
@@ -84,13 +113,13 @@ def bench_attn_encoder(dt, views, variants, H=16):
     flops = 4.0 * S * S * 64 * H * views
     for v in variants:
         def f():
-            _lib.lib().f3r_attn_set_variant(v)
+            lab_lib().f3r_attn_set_variant(v)
             ops.attention(q, o, H, 0.125, [(k, vt, S, S * D, D * S)], tq=S, batch=views, q_batch_stride=S * D, o_batch_stride=S * D)
         f()
         med, mn = time_ms(f)
         print(json.dumps({"kernel": "attn_encoder", "dtype": str(dt).split(".")[-1], "views": views, "variant": v, "ms": round(med, 3),
                           "tflops": round(flops / med / 1e9, 1)}), flush=True)
-    _lib.lib().f3r_attn_set_variant(-1)
+    lab_lib().f3r_attn_set_variant(-1)
 
 
 SEL_NAME = {1: "128-tile", 2: "256-tile staggered", 3: "256-tile lock-step"}
@@ -326,6 +355,11 @@ if __name__ == "__main__":
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
+    if args.what == "attnproduct":
+        for nv in [int(v) for v in args.views.split(",")]:
+            bench_attn_product(torch.bfloat16, nv)
+            bench_attn_product(torch.float16, nv)
+        sys.exit(0)
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
             bench_attn(dt, nv, variants)
