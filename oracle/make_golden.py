@@ -31,27 +31,35 @@ CASES = {
     "tiny_hot_3x64": (dict(), [(64, 64)] * 3, 1, 0, 1234, "hot"),
     "tiny_llama_3x64": (dict(decoder_type="llama"), [(64, 64)] * 3, 1, 4, 31, "default"),
     "tiny_llama_seqids_b2": (dict(decoder_type="llama", random_image_idx_embedding=False, enc_depth=1, llama_layers=14), [(32, 48)] * 4, 2, 5, 3, "default"),
+    # the training-config pair ManyAR_PatchEmbed + landscape_only=True (configs/model/fast3r.yaml:55,77): images are STORED landscape
+    # (48 x 64) and `true_shape` says which samples are portrait pictures: view 0 all landscape, view 1 all portrait, view 2 mixed
+    "tiny_portrait_b2": (dict(enc_depth=1, patch_embed_cls="ManyAR_PatchEmbed", landscape_only=True), [(48, 64)] * 3, 2, 6, 11, "default"),
 }
+TRUE_SHAPES = {"tiny_portrait_b2": [[[48, 64], [48, 64]], [[64, 48], [64, 48]], [[64, 48], [48, 64]]]}
 
 
-def views_for(shapes, batch, seed=1000):
+def views_for(shapes, batch, seed=1000, true_shapes=None):
     vs = []
     for i, (h, w) in enumerate(shapes):
         vs.append(make_views(1, h, w, batch, seed=seed + i)[0])
         vs[-1]["idx"], vs[-1]["instance"], vs[-1]["label"] = i, str(i), f"syn/{i}"
+        if true_shapes is not None:
+            vs[-1]["true_shape"] = torch.tensor(true_shapes[i], dtype=torch.int32)
     return vs
 
 
-def main():
+def main(only=None):
     warnings.filterwarnings("ignore")
     Fast3R, inference = load_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
     for name, (kw, shapes, batch, wseed, rseed, wdist) in CASES.items():
+        if only and name not in only:
+            continue
         enc, dec, head = tiny_args(**kw)
         model = Fast3R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head)).eval()
         shp = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         model.load_state_dict(synth_state_dict(shp, wseed, wdist), strict=True)
-        views = views_for(shapes, batch)
+        views = views_for(shapes, batch, true_shapes=TRUE_SHAPES.get(name))
         # capture the ids the reference draws (fast3r.py:740-743) without touching its code path
         torch.manual_seed(rseed)
         ids = None
@@ -65,7 +73,7 @@ def main():
         out = inference(copy.deepcopy(views), model, torch.device("cpu"), dtype="32", verbose=False)
         preds = out["preds"]
         fix = dict(name=name, tiny_kwargs=kw, shapes=shapes, batch=batch, weight_seed=wseed, weight_dist=wdist, rng_seed=rseed,
-                   state_shapes=shp, image_ids=ids,
+                   state_shapes=shp, image_ids=ids, true_shapes=TRUE_SHAPES.get(name),
                    preds=[{k: v.clone() for k, v in p.items()} for p in preds],
                    torch_version=torch.__version__)
         path = os.path.join(OUT_DIR, name + ".pt")
@@ -74,4 +82,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))  # optional: only the named cases (the others stay as committed)

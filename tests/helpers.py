@@ -7,7 +7,8 @@ import torch
 from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid", "tiny_hot_3x64", "tiny_llama_3x64", "tiny_llama_seqids_b2"]
+GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid", "tiny_hot_3x64", "tiny_llama_3x64", "tiny_llama_seqids_b2",
+                "tiny_portrait_b2"]
 
 
 def load_golden(name):
@@ -19,6 +20,8 @@ def golden_views(fix, seed=1000):
     for i, (h, w) in enumerate(fix["shapes"]):
         v = make_views(1, h, w, fix["batch"], seed=seed + i)[0]
         v["idx"], v["instance"], v["label"] = i, str(i), f"syn/{i}"
+        if fix.get("true_shapes") is not None:
+            v["true_shape"] = torch.tensor(fix["true_shapes"][i], dtype=torch.int32)
         vs.append(v)
     return vs
 

@@ -1,7 +1,10 @@
 """align_local_pts3d_to_global (reference fast3r/models/multiview_dust3r_module.py:427-549).
-The reference function is not importable and its solver lives in the un-vendored, un-pinned `roma` package, so parity for this
-row is UNPINNED against the reference; it is anchored on (a) construction properties of the oracle restatement (CPU, below) and
-(b) HIP path == oracle on the same inputs (GPU): quantile thresholds bit-exact vs torch.quantile, transforms / points to fp32 noise."""
+The reference function is not importable and its solver lives in the un-vendored, un-pinned `roma` package (not installable: no
+network), so the row cannot be pinned on the reference's own outputs.  Its pin is an INDEPENDENT closed form of the same least-squares
+problem -- Horn's unit-quaternion solution in float64 (oracle/align_pin.py) -- against which both the oracle restatement (Umeyama /
+SVD) and the HIP path (raw fp64 moments + Jacobi SVD) are checked, on exact, noisy, mirrored and planar clouds; plus construction
+properties of the oracle (CPU, below) and HIP path == oracle on the same inputs (GPU): quantile thresholds bit-exact vs
+torch.quantile, transforms / points to fp32 noise."""
 import ctypes
 import math
 
@@ -45,6 +48,49 @@ def test_oracle_recovers_exact_similarity():
     # reflection-only data still yields a proper rotation (det = +1): special Procrustes
     Rr, _, _ = rigid_points_registration(x, x * torch.tensor([1.0, 1.0, -1.0]))
     assert abs(float(torch.det(Rr)) - 1.0) < 1e-5
+
+
+def _clouds():
+    """(name, x, y): generic noisy, exact, mirrored (the unconstrained optimum is a reflection), planar (rank 2), strongly noisy."""
+    g = torch.Generator().manual_seed(42)
+    out = []
+    x = torch.randn(400, 3, generator=g, dtype=torch.float64) * torch.tensor([2.0, 1.0, 0.5], dtype=torch.float64)
+    R, _ = torch.linalg.qr(random_rotation(g).double())  # orthonormal to float64 accuracy
+    if torch.det(R) < 0:
+        R[:, 0] *= -1
+    y = 1.3 * x @ R.t() + torch.tensor([0.4, -1.0, 3.0], dtype=torch.float64)
+    out.append(("exact", x, y))
+    out.append(("noisy", x, y + 0.05 * torch.randn(400, 3, generator=g, dtype=torch.float64)))
+    out.append(("very noisy", x, y + 1.0 * torch.randn(400, 3, generator=g, dtype=torch.float64)))
+    out.append(("mirrored", x, (x * torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64)) @ R.t() * 0.7 + 0.01 * torch.randn(400, 3, generator=g, dtype=torch.float64)))
+    xp = x.clone()
+    xp[:, 2] = 0.0
+    out.append(("planar", xp, 2.0 * xp @ R.t() + 0.02 * torch.randn(400, 3, generator=g, dtype=torch.float64)))
+    return out
+
+
+def test_oracle_is_pinned_on_an_independent_closed_form():
+    """The pin of this row (the reference's solver, `roma`, is not installable): Umeyama / SVD (oracle/align_oracle.py) vs Horn's
+    unit-quaternion solution (oracle/align_pin.py) -- different derivations of the same least-squares problem, no shared code -- agree to
+    1e-9 in float64 on generic, mirrored and planar clouds, and both recover an exact similarity."""
+    from oracle.align_pin import horn_similarity
+    for name, x, y in _clouds():
+        Ru, tu, su = rigid_points_registration(x, y)
+        Rh, th, sh = horn_similarity(x, y)
+        assert abs(float(torch.det(Ru)) - 1) < 1e-9 and abs(float(torch.det(Rh)) - 1) < 1e-9, name
+        assert float((Ru - Rh).abs().max()) < 1e-9 and float((tu - th).abs().max()) < 1e-8 and abs(float(su - sh)) < 1e-9, name
+        res_u = float(((su * x @ Ru.t() + tu) - y).pow(2).sum())
+        # neither beats the other, and perturbing the solution only makes the residual worse (it is the optimum, not just a fixed point)
+        for k in range(3):
+            ax = torch.zeros(3, dtype=torch.float64)
+            ax[k] = 1e-3
+            K = torch.tensor([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]], dtype=torch.float64)
+            Rp = torch.linalg.matrix_exp(K) @ Ru
+            assert float(((su * x @ Rp.t() + tu) - y).pow(2).sum()) >= res_u - 1e-12, name
+        assert float((((su * 1.001) * x @ Ru.t() + tu) - y).pow(2).sum()) >= res_u - 1e-12, name
+    name, x, y = _clouds()[0]
+    R, t, s = rigid_points_registration(x, y)
+    assert float(((s * x @ R.t() + t) - y).abs().max()) < 1e-9
 
 
 def test_oracle_control_flow_and_errors():
@@ -181,3 +227,24 @@ def test_readme_flow_on_the_cpu_preds_inference_returns(built_lib):
     poses_d, focals_d = lit.estimate_camera_poses(dev_preds, niter_PnP=10)
     assert len(poses_c) == 1 and len(poses_c[0]) == 3 and poses_c[0][0].shape == (4, 4)
     assert all((a == b).all() for a, b in zip(poses_c[0], poses_d[0])) and focals_c == focals_d
+
+
+@pytest.mark.gpu
+def test_hip_alignment_matches_the_independent_pin(built_lib):
+    """f3r_align_local_to_global (raw fp64 moments + Jacobi SVD on the GPU) against Horn's quaternion solution in float64 on the same
+    clouds -- exact, noisy, mirrored (reflection case of the det correction), planar (rank 2): rotation / scale / translation to
+    fp32-input accuracy, and the aligned points themselves."""
+    from fast3r_amd import align_local_pts3d_to_global
+    from oracle.align_pin import horn_similarity
+    for name, x, y in _clouds():
+        n = x.shape[0]  # 400 = 20 x 20 pixels
+        xf, yf = x.float(), y.float()
+        preds = [{"pts3d_local": xf.view(1, 20, 20, 3).cuda(), "conf_local": torch.ones(1, 20, 20).cuda(),
+                  "pts3d_in_other_view": yf.view(1, 20, 20, 3).cuda(), "conf": torch.ones(1, 20, 20).cuda()}]
+        got, tr = align_local_pts3d_to_global(preds, [{}], min_conf_thr_percentile=0, return_transforms=True)
+        R, t, s = horn_similarity(xf, yf)  # the pin sees exactly the fp32 inputs the kernel sees
+        Rg, tg, sg = tr[0][0, :9].view(3, 3).double().cpu(), tr[0][0, 9:12].double().cpu(), float(tr[0][0, 12])
+        assert float((Rg - R).abs().max()) < 2e-6, (name, float((Rg - R).abs().max()))
+        assert abs(sg - float(s)) < 2e-6 * float(s) and float((tg - t).abs().max()) < 1e-5, name
+        ref = (s * xf.double() @ R.t() + t).view(1, 20, 20, 3)
+        assert float((got[0]["pts3d_local_aligned_to_global"].double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()), name
