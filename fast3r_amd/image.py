@@ -123,64 +123,102 @@ def _resized_size(size_wh, long_edge_size):
     return tuple(int(round(x * long_edge_size / S)) for x in size_wh), interp
 
 
-def load_images(folder_or_list, size, square_ok=False, verbose=True, rotate_clockwise_90=False, crop_to_landscape=False, device="cuda"):
-    """open and convert all images in a list or folder to the input format of Fast3R (reference :76-159); `img` tensors live on `device`."""
+# ------------------------------------------------------------------------------------------------------ input pipeline (host side)
+class Geometry:
+    """Everything `load_images` does to ONE picture, as numbers (no pixels touched): the lossless pre-crop on the decoded picture, the
+    antialiased resize, the final centre crop.  The arithmetic is the reference's input contract (dust3r/utils/image.py:109-150):
+    a different rounding anywhere changes the network's input size."""
+    __slots__ = ("pre_crop", "resized", "filter", "box", "decoded")
+
+    def __init__(self, decoded_wh, size, square_ok, crop_to_landscape):
+        w, h = decoded_wh
+        self.decoded = (w, h)
+        self.pre_crop = None
+        if crop_to_landscape:  # 4:3 window, centred (:109-130)
+            if w / h > 4 / 3:
+                keep = int(h * (4 / 3))
+                left = (w - keep) // 2
+                self.pre_crop = (left, 0, left + keep, h)
+            else:
+                keep = int(w / (4 / 3))
+                top = (h - keep) // 2
+                self.pre_crop = (0, top, w, top + keep)
+            w, h = self.pre_crop[2] - self.pre_crop[0], self.pre_crop[3] - self.pre_crop[1]
+        # 224: the SHORT side becomes 224, then a centred square; otherwise the LONG side becomes `size` (:132-138)
+        long_edge = round(size * max(w / h, h / w)) if size == 224 else size
+        self.resized, self.filter = _resized_size((w, h), long_edge)
+        rw, rh = self.resized
+        cx, cy = rw // 2, rh // 2
+        if size == 224:
+            half = min(cx, cy)
+            self.box = (cx - half, cy - half, cx + half, cy + half)
+        else:  # both sides down to multiples of 16 around the centre; a square picture becomes 4:3 unless square_ok (:144-148)
+            hw, hh = ((2 * cx) // 16) * 8, ((2 * cy) // 16) * 8
+            if not square_ok and rw == rh:
+                hh = 3 * hw / 4
+            self.box = (cx - hw, cy - hh, cx + hw, cy + hh)
+
+    @property
+    def out_hw(self):
+        l, t, r, b = (int(v) for v in self.box)
+        return b - t, r - l
+
+
+def _image_extensions():
+    """.jpg / .jpeg / .png, plus .heic / .heif when pillow_heif can be imported (the reference's optional dependency, image.py:24-30)."""
+    exts = [".jpg", ".jpeg", ".png"]
+    try:
+        from pillow_heif import register_heif_opener
+        register_heif_opener()
+        exts += [".heic", ".heif"]
+    except ImportError:
+        pass
+    return tuple(exts)
+
+
+def _decode(path, rotate_clockwise_90):
+    """File -> upright RGB PIL image (EXIF orientation applied, optional lossless quarter turn): host work, microseconds of byte shuffling."""
     import PIL.Image
     from PIL.ImageOps import exif_transpose
+    pic = exif_transpose(PIL.Image.open(path)).convert("RGB")
+    return pic.rotate(-90, expand=True) if rotate_clockwise_90 else pic
+
+
+def load_images(folder_or_list, size, square_ok=False, verbose=True, rotate_clockwise_90=False, crop_to_landscape=False, device="cuda"):
+    """Open and convert all images of a folder or list to the input format of Fast3R -- same arguments, ordering, filtering by extension,
+    errors and per-image dict (`img` (1,3,H,W) in [-1,1], `true_shape` int32 [[H,W]], `idx`, `instance`) as the reference
+    (fast3r/dust3r/utils/image.py:76-159); the `img` tensors are produced on `device` (a ROCm GPU) by the resampling kernels."""
     if isinstance(folder_or_list, str):
+        root, names = folder_or_list, sorted(os.listdir(folder_or_list))
         if verbose:
-            print(f">> Loading images from {folder_or_list}")
-        root, folder_content = folder_or_list, sorted(os.listdir(folder_or_list))
+            print(f">> Loading images from {root}")
     elif isinstance(folder_or_list, list):
+        root, names = "", folder_or_list
         if verbose:
-            print(f">> Loading a list of {len(folder_or_list)} images")
-        root, folder_content = "", folder_or_list
+            print(f">> Loading a list of {len(names)} images")
     else:
-        raise ValueError(f"bad {folder_or_list=} ({type(folder_or_list)})")
+        raise ValueError(f"bad {folder_or_list=} ({type(folder_or_list)})")  # :91
     dev = torch.device(device)
     if dev.type != "cuda":
         raise F3RError(f"fast3r_amd.load_images resamples on the ROCm GPU (device={device}); there is no CPU fallback")
-    supported = (".jpg", ".jpeg", ".png")
-    imgs, cache = [], {}
-    for path in folder_content:
-        if not path.lower().endswith(supported):
-            continue
-        img = exif_transpose(PIL.Image.open(os.path.join(root, path))).convert("RGB")
-        if rotate_clockwise_90:
-            img = img.rotate(-90, expand=True)
-        if crop_to_landscape:  # :109-130
-            desired = 4 / 3
-            width, height = img.size
-            if width / height > desired:
-                new_width = int(height * desired)
-                left = (width - new_width) // 2
-                img = img.crop((left, 0, left + new_width, height))
-            else:
-                new_height = int(width / desired)
-                top = (height - new_height) // 2
-                img = img.crop((0, top, width, top + new_height))
-        W1, H1 = img.size
-        if size == 224:  # resize short side to 224 (then crop)
-            (W, H), interp = _resized_size(img.size, round(size * max(W1 / H1, H1 / W1)))
-        else:            # resize long side to `size`
-            (W, H), interp = _resized_size(img.size, size)
-        u8 = torch.from_numpy(np.array(img)).to(dev)  # (H1, W1, 3) uint8: the only upload
-        u8 = resize_u8(u8, W, H, interp, cache)
-        cx, cy = W // 2, H // 2
-        if size == 224:
-            half = min(cx, cy)
-            box = (cx - half, cy - half, cx + half, cy + half)
-        else:
-            halfw, halfh = ((2 * cx) // 16) * 8, ((2 * cy) // 16) * 8
-            if not square_ok and W == H:
-                halfh = 3 * halfw / 4
-            box = (cx - halfw, cy - halfh, cx + halfw, cy + halfh)
-        tensor = img_norm_crop(u8, box)
-        H2, W2 = tensor.shape[-2:]
-        if verbose:
-            print(f" - adding {path} with resolution {W1}x{H1} --> {W2}x{H2}")
-        imgs.append(dict(img=tensor, true_shape=np.int32([[H2, W2]]), idx=len(imgs), instance=str(len(imgs))))
-    assert imgs, "no images foud at " + root
+    exts = _image_extensions()
+    table_cache, out = {}, []
+    with torch.cuda.device(dev):
+        for name in names:
+            if not name.lower().endswith(exts):
+                continue
+            pic = _decode(os.path.join(root, name), rotate_clockwise_90)
+            geo = Geometry(pic.size, size, square_ok, crop_to_landscape)
+            if geo.pre_crop is not None:
+                pic = pic.crop(geo.pre_crop)
+            pixels = torch.from_numpy(np.asarray(pic)).to(dev)  # (h, w, 3) uint8: the only upload of this picture
+            pixels = resize_u8(pixels, geo.resized[0], geo.resized[1], geo.filter, table_cache)
+            tensor = img_norm_crop(pixels, geo.box)
+            h_out, w_out = tensor.shape[-2:]
+            if verbose:
+                print(f" - adding {name} with resolution {geo.decoded[0]}x{geo.decoded[1]} --> {w_out}x{h_out}")
+            out.append(dict(img=tensor, true_shape=np.int32([[h_out, w_out]]), idx=len(out), instance=str(len(out))))
+    assert out, "no images found at " + root  # the reference asserts here too (:156)
     if verbose:
-        print(f" (Found {len(imgs)} images)")
-    return imgs
+        print(f" (Found {len(out)} images)")
+    return out
