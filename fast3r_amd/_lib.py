@@ -69,8 +69,10 @@ SYMBOLS = {
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
+    "f3r_block_workspace_bytes": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)]),
     "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
-    "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, _c_f32, ctypes.c_int, _c_vp]),
+    "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     _c_f32, _c_f32, ctypes.c_int, _c_vp]),
     "f3r_cast_f32_to_lp": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "f3r_align_local_to_global": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_size_t,

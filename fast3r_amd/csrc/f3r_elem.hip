@@ -145,7 +145,7 @@ template <class T>
 __global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_lo,
                                                         const float* __restrict__ w, const float* __restrict__ bias, int n_out,
                                                         float* __restrict__ pts, float* __restrict__ conf, int64_t npix, int Cin,
-                                                        float vmin, float vmax) {
+                                                        float vmin, float vmax, int depth_mode, int conf_mode) {
   extern __shared__ float wsh[];  // [4][Cin]; row 3 is zero when the head has no confidence channel (n_out == 3)
   for (int i = threadIdx.x; i < 4 * Cin; i += blockDim.x) wsh[i] = i < n_out * Cin ? w[i] : 0.f;
   __syncthreads();
@@ -168,12 +168,17 @@ __global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restri
       a3 = __builtin_fmaf(f0, wsh[3 * Cin + cc], a3);  a3 = __builtin_fmaf(f1, wsh[3 * Cin + cc + 1], a3);
     }
   }
-  const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
-  const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+  // reg_dense_depth (postprocess.py:27-51): 'linear' xyz; else direction xyz / max(d, 1e-8) times expm1(d) ('exp') or d^2 ('square')
+  float sc = 1.f;
+  if (depth_mode != F3R_DEPTH_LINEAR) {
+    const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    sc = (depth_mode == F3R_DEPTH_EXP ? expm1f(d) : d * d) / fmaxf(d, 1e-8f);
+  }
   pts[pix * 3 + 0] = a0 * sc;
   pts[pix * 3 + 1] = a1 * sc;
   pts[pix * 3 + 2] = a2 * sc;
-  if (conf) conf[pix] = vmin + fminf(expf(a3), vmax - vmin);
+  // reg_dense_conf (:54-64): 'exp' vmin + min(exp(x), vmax - vmin); 'sigmoid' (vmax - vmin) sigmoid(x) + vmin
+  if (conf) conf[pix] = conf_mode == F3R_CONF_EXP ? vmin + fminf(expf(a3), vmax - vmin) : (vmax - vmin) * (1.f / (1.f + expf(-a3))) + vmin;
 }
 
 template <class T>
@@ -344,21 +349,24 @@ extern "C" int f3r_upsample2x(const void* in, const void* in_lo, void* out, void
 }
 
 extern "C" int f3r_dpt_final(const void* x, const void* x_lo, const float* w, const float* b, int n_out, float* pts3d, float* conf,
-                             int64_t npix, int Cin, float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream) {
+                             int64_t npix, int Cin, int depth_mode, int conf_mode, float conf_vmin, float conf_vmax, int dtype,
+                             f3r_stream_t stream) {
   F3R_REQUIRE(x && w && b && pts3d && al16(x) && al16(x_lo), "f3r_dpt_final: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
   F3R_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cin <= 2048, "f3r_dpt_final: Cin %d must be a multiple of 8, <= 2048", Cin);
   F3R_REQUIRE(n_out == 3 || n_out == 4, "f3r_dpt_final: n_out %d (3 = xyz, 4 = xyz + confidence)", n_out);
   F3R_REQUIRE(n_out == 4 || conf == nullptr, "f3r_dpt_final: a confidence output needs the 4-channel weight");
+  F3R_REQUIRE(depth_mode >= F3R_DEPTH_EXP && depth_mode <= F3R_DEPTH_SQUARE, "f3r_dpt_final: bad depth_mode %d", depth_mode);
+  F3R_REQUIRE(conf_mode == F3R_CONF_EXP || conf_mode == F3R_CONF_SIGMOID, "f3r_dpt_final: bad conf_mode %d", conf_mode);
   if (npix <= 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   const size_t sh = (size_t)4 * Cin * sizeof(float);
   if (dtype == F3R_F16)
     hipLaunchKernelGGL(dpt_final_kernel<F16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, pts3d,
-                       conf, npix, Cin, conf_vmin, conf_vmax);
+                       conf, npix, Cin, conf_vmin, conf_vmax, depth_mode, conf_mode);
   else
     hipLaunchKernelGGL(dpt_final_kernel<BF16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, pts3d,
-                       conf, npix, Cin, conf_vmin, conf_vmax);
+                       conf, npix, Cin, conf_vmin, conf_vmax, depth_mode, conf_mode);
   return f3r_check_launch("f3r_dpt_final");
 }
 

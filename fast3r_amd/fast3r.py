@@ -502,8 +502,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             assert self.decoder_args["depth"] > 9  # fast3r.py:137
             l2 = self.decoder_args["depth"]
             ed, dd = self.encoder_args["embed_dim"], self.decoder_args["embed_dim"]
-            if tuple(self.head_args["depth_mode"])[0] != "exp" or (self.head_args["conf_mode"] and tuple(self.head_args["conf_mode"])[0] != "exp"):
-                raise NotImplementedError("fast3r_amd: only depth_mode/conf_mode 'exp' (the released configuration) are fused")
+            if tuple(self.head_args["depth_mode"])[0] not in ops.DEPTH_MODES:
+                raise ValueError(f"bad mode={tuple(self.head_args['depth_mode'])[0]!r}")  # postprocess.py:51 (raised at the first forward there)
+            if self.head_args["conf_mode"] and tuple(self.head_args["conf_mode"])[0] not in ops.CONF_MODES:
+                raise ValueError(f"bad mode={tuple(self.head_args['conf_mode'])[0]!r}")   # :64
             return PixelwiseTaskWithDPT(num_channels=3 + has_conf, feature_dim=256, last_dim=128,
                                         hooks_idx=[0, l2 * 2 // 4, l2 * 3 // 4, l2], dim_tokens=[ed, dd, dd, dd],
                                         patch_size=patch_size, depth_mode=self.head_args["depth_mode"],
@@ -614,20 +616,26 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return self._rope_cache[key]
 
     # ---------------------------------------------------------------- transformer block on the HIP kernels
-    def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None):
+    def _block_ws(self, pb, T, D, n_seq, seq_len, dev):
+        """Workspace of the blocks of one encoder pass / decoder sample: ONE allocation shared by all of its layers."""
+        hidden = pb.fc1_w.shape[0]  # rows of the (possibly stacked [w1; w3]) up-projection
+        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev)
+
+    def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None):
         """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
-        with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single."""
+        with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single.
+        ws: the pass's BlockWorkspace (made here when absent): no per-layer allocation."""
         lp = self.compute_dtype
         sp = "w2" if self.precision == "high" else None
         D = x.shape[1]
         T = x.shape[0]
-        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, rms=pb.rms)
-        q = torch.empty((T, D), dtype=lp, device=x.device)
+        if ws is None:
+            ws = self._block_ws(pb, T, D, n_seq, seq_len, x.device)
+        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, out_lp=ws.h, rms=pb.rms)
+        q = ws.q
         if kv_exchange is None:
-            k = torch.empty((T, D), dtype=lp, device=x.device)
-            ldvt = ops.vt_ld(seq_len)
-            vt = torch.zeros((n_seq, D, ldvt), dtype=lp, device=x.device) if ldvt != seq_len else \
-                torch.empty((n_seq, D, ldvt), dtype=lp, device=x.device)
+            k, vt = ws.k, ws.vt
+            ldvt = vt.shape[-1]
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
         ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp)
@@ -652,10 +660,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
-            _, ab = ops.gemm(h2, pb.fc1_w, want_lp=True, split=sp)
+            _, ab = ops.gemm(h2, pb.fc1_w, out_lp=ws.hid, split=sp)
             hid = ops.silu_mul(ab, pb.swiglu_hidden)
         else:
-            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, split=sp)
+            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", out_lp=ws.hid, split=sp)
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split=sp)
         return x
 
@@ -686,8 +694,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             v1 = min(NV, v0 + step)
             a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp)
             x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True, split=sp)
+            ws = self._block_ws(pk["enc"][0], x.shape[0], enc.embed_dim, v1 - v0, P, imgs.device)
             for pb in pk["enc"]:
-                self._block(x, pb, enc.num_heads, (enc.embed_dim // enc.num_heads) ** -0.5, P, v1 - v0, rope)
+                self._block(x, pb, enc.num_heads, (enc.embed_dim // enc.num_heads) ** -0.5, P, v1 - v0, rope, ws=ws)
             w_, b_, eps = pk["enc_norm"]
             if hp:
                 _, y = ops.layernorm(x, w_, b_, eps, lp, want_lp=False, want_f32=True)
@@ -717,6 +726,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         D = dec.embed_dim
         T_loc, n_loc = sum(Ps), len(Ps)
         x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
+        ws = self._block_ws(pk["dec"][0], T_loc, D, 1, T_loc, dev)  # one allocation for the intermediates of all L blocks
         planes = (lambda t: (t.clone(), None)) if f32_hooks else self._planes
         want_f32_norm = f32_hooks or self.precision == "high"
         if llama:
@@ -735,7 +745,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 taps[0] = planes(x)
             for li, pb in enumerate(pk["dec"]):
                 ops.rows_add(x, pk["view0"], view0_rows)
-                self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx)
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx, ws=ws)
                 if (li + 1) in hooks and (li + 1) != L:
                     taps[li + 1] = planes(x)
             if L in hooks:
@@ -756,7 +766,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     r0 += Ps[i]
             taps = {0: (enc_hi.float(), None) if f32_hooks else (enc_hi, enc_lo)}
             for li, pb in enumerate(pk["dec"]):
-                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx)
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx, ws=ws)
                 if (li + 1) in hooks[1:3]:
                     taps[li + 1] = planes(x)
             w_, b_, eps = pk["dec_norm"]
@@ -849,7 +859,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         assert hk.patch_size == 16, "head Interpolate scale = patch_size / 8 (dpt_block.py:374): only x2 is fused"
         u = ops.upsample2x(y[0], x_lo=y[1], want_lo=hp)                                 # head[1]
         y = conv(u if hp else (u, None), hk.h2_w, bias=hk.h2_b, act="relu")["x"]        # head[2], head[3]
-        return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1])           # head[4] + postprocess
+        return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1], depth_mode=tuple(hk.depth_mode))  # head[4] + postprocess
 
     # ---------------------------------------------------------------- forward
     def forward(self, views, profiling=False):

@@ -165,6 +165,30 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
     return out_f32, out_lp
 
 
+class BlockWorkspace:
+    """The intermediates of a transformer block -- LN / attention output, q, k, V^T, MLP hidden -- as views of ONE allocation laid out by
+    f3r_block_workspace_bytes (include/f3r.h): made once per encoder pass / decoder sample, reused by every block of it."""
+
+    def __init__(self, tokens, D, hidden, n_seq, seq_len, lp, device):
+        offs = (ctypes.c_size_t * 5)()
+        total = _lib.lib().f3r_block_workspace_bytes(tokens, D, hidden, n_seq, seq_len, offs)
+        if total == 0:
+            raise ValueError(f"f3r_block_workspace_bytes: bad sizes ({tokens=}, {D=}, {hidden=}, {n_seq=}, {seq_len=})")
+        self.buf = torch.empty((total,), dtype=torch.uint8, device=device)
+        ld = vt_ld(seq_len)
+
+        def view(i, shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return self.buf[offs[i]:offs[i] + 2 * n].view(lp).view(shape)
+        self.h, self.q, self.k = view(0, (tokens, D)), view(1, (tokens, D)), view(2, (tokens, D))
+        self.vt, self.hid = view(3, (n_seq, D, ld)), view(4, (tokens, hidden))
+        if ld != seq_len:
+            self.vt.zero_()  # the pad columns are read by the last key tile and never written by the QKV epilogue
+        self.key = (tokens, D, hidden, n_seq, seq_len, lp, str(device))
+
+
 def vt_ld(seq_len: int) -> int:
     """Row stride of a V^T buffer: the attention kernel reads whole 64-key tiles, so rows are padded to 64 (zeroed)."""
     return round_up(seq_len, 64)
@@ -339,20 +363,31 @@ def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
     return (out, out_lo) if want_lo else out
 
 
-def dpt_final(x, w, b, conf_mode, x_lo=None):
-    """x (+ x_lo) (B,H,W,Cin) NHWC lowp -> pts3d (B,H,W,3) fp32, conf (B,H,W) fp32 (or None).  w (n_out, Cin), b (n_out,), n_out = 3 + has_conf."""
+DEPTH_MODES = {"exp": 0, "linear": 1, "square": 2}
+CONF_MODES = {"exp": 0, "sigmoid": 1}
+
+
+def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.inf)):
+    """x (+ x_lo) (B,H,W,Cin) NHWC lowp -> pts3d (B,H,W,3) fp32, conf (B,H,W) fp32 (or None).  w (n_out, Cin), b (n_out,), n_out = 3 + has_conf.
+    depth_mode / conf_mode: the reference's (mode, vmin, vmax) triples (heads/postprocess.py:27-64)."""
     require_gpu(x, "x")
     B, H, W, Cin = x.shape
     n_out = w.shape[0]
     assert w.shape == (n_out, Cin) and b.shape == (n_out,) and n_out == (4 if conf_mode is not None else 3)
+    dmode, dmin, dmax = depth_mode
+    if dmode not in DEPTH_MODES:
+        raise ValueError(f"bad mode={dmode!r}")  # postprocess.py:51
+    assert dmin == -math.inf and dmax == math.inf  # :33-34
     pts = torch.empty((B, H, W, 3), dtype=torch.float32, device=x.device)
     conf = None
-    vmin, vmax = 1.0, math.inf
+    cmode, vmin, vmax = 0, 1.0, math.inf
     if conf_mode is not None:
+        if conf_mode[0] not in CONF_MODES:
+            raise ValueError(f"bad mode={conf_mode[0]!r}")  # :64
         conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
-        vmin, vmax = float(conf_mode[1]), float(conf_mode[2])
-    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(x_lo), ptr(w), ptr(b), n_out, ptr(pts), ptr(conf), B * H * W, Cin, vmin, vmax,
-                                   dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
+        cmode, vmin, vmax = CONF_MODES[conf_mode[0]], float(conf_mode[1]), float(conf_mode[2])
+    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(x_lo), ptr(w), ptr(b), n_out, ptr(pts), ptr(conf), B * H * W, Cin, DEPTH_MODES[dmode], cmode,
+                                   vmin, vmax, dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
     return pts, conf
 
 

@@ -154,6 +154,17 @@ typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_spli
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * f3r_block_workspace_bytes: size and layout of the intermediates of ONE transformer block (Block.forward, blocks.py:236-239) over
+ * `tokens` rows = n_seq sequences of seq_len tokens, model width D, MLP hidden width `hidden` (2 x the SwiGLU width for the
+ * LlamaDecoder's stacked [w1; w3] projection).  The library allocates nothing: the caller makes ONE allocation of the returned size
+ * per encoder pass / decoder sample and every block of that pass reuses it (the intermediates of a block are dead when it ends).
+ * offsets[0..4] (bytes, 256-byte aligned) = { LN output / attention output (lowp [tokens][D]),  q (lowp [tokens][D]),
+ * k (lowp [tokens][D]),  V^T (lowp [n_seq][D][ldvt], ldvt = seq_len rounded up to 64: pad columns are never written, zero them once),
+ * MLP hidden (lowp [tokens][hidden]) }.  Returns 0 on bad arguments.
+ */
+size_t f3r_block_workspace_bytes(int64_t tokens, int D, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
+
+/* ---------------------------------------------------------------------------------------------
  * f3r_attn_fwd: O = softmax(scale * Q K^T) V, non-causal, head_dim 64, flash-style (never forms
  * the T x T matrix), fp32 online softmax.  Replaces the q@k^T -> softmax -> @v core of
  * Attention.forward (blocks.py:158-190; all three `attn_implementation`s compute this).
@@ -211,14 +222,22 @@ int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, i
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_dpt_final: last 1x1 conv (Cin -> n_out) fused with postprocess.
- * Replaces head[4] Conv2d(last_dim, 3 + has_conf, 1) (dpt_block.py:379-381) + postprocess/reg_dense_depth/
- * reg_dense_conf (heads/postprocess.py:16-64), depth_mode ('exp', -inf, inf), conf_mode ('exp', vmin, vmax):
- *   xyz,c = W(n_out,Cin) x + b;  d = |xyz|;  pts = xyz / max(d, 1e-8) * expm1(d);  conf = vmin + min(exp(c), vmax - vmin)
+ * Replaces head[4] Conv2d(last_dim, 3 + has_conf, 1) (dpt_block.py:379-381) + postprocess / reg_dense_depth /
+ * reg_dense_conf (heads/postprocess.py:16-64):
+ *   xyz,c = W(n_out,Cin) x + b;  d = |xyz|
+ *   depth_mode  F3R_DEPTH_EXP    pts = xyz / max(d, 1e-8) * expm1(d)      ('exp', -inf, inf): the released configuration
+ *               F3R_DEPTH_LINEAR pts = xyz                                 ('linear', -inf, inf)
+ *               F3R_DEPTH_SQUARE pts = xyz / max(d, 1e-8) * d^2            ('square', -inf, inf)
+ *               (the reference asserts the depth bounds are infinite, postprocess.py:33-34)
+ *   conf_mode   F3R_CONF_EXP     conf = vmin + min(exp(c), vmax - vmin)    ('exp', vmin, vmax)
+ *               F3R_CONF_SIGMOID conf = (vmax - vmin) sigmoid(c) + vmin    ('sigmoid', vmin, vmax)
  *   x (+ x_lo, optional low plane): NHWC lowp [npix][Cin];  w: fp32 [n_out][Cin];  b: fp32 [n_out];  n_out = 3 (no confidence:
  *   conf must be NULL) or 4;  pts3d: fp32 [npix][3];  conf: fp32 [npix] or NULL
  */
+typedef enum { F3R_DEPTH_EXP = 0, F3R_DEPTH_LINEAR = 1, F3R_DEPTH_SQUARE = 2 } f3r_depth_mode;
+typedef enum { F3R_CONF_EXP = 0, F3R_CONF_SIGMOID = 1 } f3r_conf_mode;
 int f3r_dpt_final(const void* x, const void* x_lo, const float* w, const float* b, int n_out, float* pts3d, float* conf, int64_t npix,
-                  int Cin, float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream);
+                  int Cin, int depth_mode, int conf_mode, float conf_vmin, float conf_vmax, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_cast_f32_to_lp: fp32 -> lowp copy (hooked residual streams 12/18 as DPT inputs, dpt_head.py:54;

@@ -81,6 +81,33 @@ def test_dpt_final(built_lib, dt):
     assert (conf >= 1).all()
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("depth_mode,conf_mode", [("linear", ("sigmoid", 0.5, 3.0)), ("square", ("exp", 1, 20.0)), ("exp", None), ("square", ("sigmoid", 0.0, 1.0))])
+def test_dpt_final_other_modes(built_lib, dt, depth_mode, conf_mode):
+    """heads/postprocess.py:27-64: depth 'linear' / 'square' / 'exp', conf 'exp' with a finite vmax (clip) / 'sigmoid' / no confidence channel
+    at all (3-channel head[4]: the kernel must not read a 4th weight row)."""
+    inf = float("inf")
+    x = rnd((2, 9, 13, 128), dt, 2)
+    n_out = 4 if conf_mode is not None else 3
+    w, b = torch.randn(n_out, 128) * 0.1, torch.randn(n_out) * 0.1
+    if conf_mode is not None and conf_mode[0] == "exp":
+        w[3] *= 5.0  # make exp(c) cross vmax - vmin for some pixels
+    pts, conf = ops.dpt_final(x.to(DEV), w.to(DEV), b.to(DEV), conf_mode, depth_mode=(depth_mode, -inf, inf))
+    y = x.double() @ w.double().t() + b.double()
+    xyz = y[..., :3]
+    d = xyz.norm(dim=-1, keepdim=True)
+    ref_p = xyz if depth_mode == "linear" else xyz / d.clip(min=1e-8) * (d.square() if depth_mode == "square" else torch.expm1(d))
+    assert_close(pts, ref_p, 1e-5, "pts3d " + depth_mode)
+    if conf_mode is None:
+        assert conf is None
+    else:
+        cm, vmin, vmax = conf_mode
+        ref_c = vmin + y[..., 3].exp().clip(max=vmax - vmin) if cm == "exp" else (vmax - vmin) * torch.sigmoid(y[..., 3]) + vmin
+        assert_close(conf, ref_c, 1e-5, "conf " + cm)
+        if cm == "exp":
+            assert float(conf.max()) <= vmax + 1e-5 and float((conf >= vmax - 1e-4).float().mean()) > 0.0  # the clip is exercised
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 96, 1024), (77, 260, 200), (1024, 512, 768), (2048, 1024, 4096)])
