@@ -91,7 +91,8 @@ __device__ __forceinline__ typename T::vec8 as_vec8(u32x4 v) {
 }
 
 // f3r_gemm256.hip: the 256x256-tile kernel behind f3r_gemm for large regular shapes
-bool f3r_gemm256_eligible(const f3r_gemm_args& a);
+bool f3r_gemm256_eligible(const f3r_gemm_args& a);   // can take the problem at all
+bool f3r_gemm256_preferred(const f3r_gemm_args& a);  // ... and is expected to be faster than the 128-tile kernel
 int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger);
 int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_LAB builds only (tools/lab)
 

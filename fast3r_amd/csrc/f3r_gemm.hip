@@ -364,6 +364,6 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   // without the staggered wave rows (measurement; an ineligible shape is an error, not a silent fallback)
   if (a.kernel_sel >= 16) return f3r_gemm256_lab(a, s);
   if (a.kernel_sel >= 2) F3R_REQUIRE(f3r_gemm256_eligible(a), "f3r_gemm: kernel_sel %d but the shape is not eligible for the 256-tile kernel", a.kernel_sel);
-  if (a.kernel_sel >= 2 || (a.kernel_sel == 0 && f3r_gemm256_eligible(a))) return f3r_gemm256_launch(a, s, a.kernel_sel != 3);
+  if (a.kernel_sel >= 2 || (a.kernel_sel == 0 && f3r_gemm256_eligible(a) && f3r_gemm256_preferred(a))) return f3r_gemm256_launch(a, s, a.kernel_sel != 3);
   return a.dtype == F3R_F16 ? dispatch<F16>(a, s) : dispatch<BF16>(a, s);
 }

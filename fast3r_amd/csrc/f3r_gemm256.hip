@@ -33,10 +33,16 @@ __device__ __attribute__((aligned(128))) uint32_t f3r_zero_line[32];  // 128 B o
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+constexpr int BM = 256, BK = 64, NT = 512;
 constexpr int HT = 128 * 64;          // elements of a half tile
-constexpr int BUF = 4 * HT;           // A_h0 A_h1 W_h0 W_h1
-constexpr int LDS_BYTES = 2 * BUF * 2;  // 131072
+// NH = W half tiles per K-tile: 2 -> 256 x 256 outputs, two K-tile buffers (128 KiB); 1 -> 256 x 128 outputs (the 128-channel
+// convolutions of the DPT head and every N that is an odd multiple of 128), three K-tile buffers of 3 half tiles (144 KiB)
+template <int NH> struct TileCfg {
+  static constexpr int BN = 128 * NH;
+  static constexpr int BUF = (2 + NH) * HT;          // A_h0 A_h1 W_h0 [W_h1]
+  static constexpr int NBUF = NH == 2 ? 2 : 3;
+  static constexpr int LDS_BYTES = NBUF * BUF * 2;   // 131072 / 147456
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -53,8 +59,9 @@ struct IC {
 //   1 no LDS-DMA in the loop   2 no fragment reads in the loop   4 no MFMAs   8 no vmcnt wait   16 no s_setprio
 //   32 buffer_load ... lds through a buffer descriptor instead of global_load_lds   64 no sched_barrier pinning of the load section
 // (1, 2, 4, 8 compute garbage by construction: timing only)
-template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int LAB = 0>
+template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0>
 __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, int64_t m0, int n0) {
+  constexpr int BUF = TileCfg<NH>::BUF;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +88,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     for (int i = 0; i < 2; ++i) {
       const int r = (wid * 2 + i) * 8 + (lane >> 3);
       const int lc = (lane & 7) ^ ((r >> 1) & 7);
-      int n = n0 + h * 128 + r;
+      int n = n0 + (h < NH ? h : 0) * 128 + r;
       if (n >= p.N) n = p.N - 1;
       w_off[h][i] = (uint32_t)(((int64_t)(n - n0) * p.Kpad + lc * 8) * 2);
       int64_t m = m0 + h * 128 + r;
@@ -177,7 +184,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     w_rd[ks] = (wn * 32 + fr) * 64 + pc;
   }
 
-  float4v acc[32];
+  float4v acc[16 * NH];
   typename T::vec8 fa0[2][4], fa1[2][4], fw[2][2];
 
   auto read_a = [&](typename T::vec8 (&f)[2][4], int buf, int mh) {
@@ -205,7 +212,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
           const int NF = nh * 2 + nf, MF = mh * 4 + mf;
-          if (SWAP) acc[MF * 4 + NF] = T::mfma16(f[ks][mf], fw[ks][nf], acc[MF * 4 + NF]);
+          if (SWAP) acc[MF * (2 * NH) + NF] = T::mfma16(f[ks][mf], fw[ks][nf], acc[MF * (2 * NH) + NF]);
           else      acc[NF * 8 + MF] = T::mfma16(fw[ks][nf], f[ks][mf], acc[NF * 8 + MF]);
         }
   };
@@ -246,35 +253,79 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     if (!(LAB & 8)) F3R_VMCNT(8);
     F3R_PHASE_MMA(fa0, 0, 1)
   };
+  // NH == 1 (256 x 128 outputs): a K-tile is 2 phases -- quadrants (A0, W) and (A1, W), 16 MFMAs each -- and 3 half tiles; three
+  // buffers, tile t in buffer t % 3.  Reads: A0 and W in phase 0, A1 in phase 1; a slot is restaged two phases after its read:
+  //     phase 0 of tile t:  A half 0 + W of tile t+2, then vmcnt(10) (retires A half 1 of tile t, read in phase 1)
+  //     phase 1          :  A half 1 of tile t+2,     then vmcnt(8)  (retires A half 0 + W of tile t+1, read in its phase 0)
+  // i.e. every half tile is issued 3 phases before the wait that retires it.
+  auto tile1 = [&](auto bufc) {
+    constexpr int B = decltype(bufc)::value;
+    constexpr int B2 = (B + 2) % 3;
+    read_w(B, 0);
+    if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
+    read_a(fa0, B, 0);
+    issue_a(0, B2);
+    issue_w(0, B2);
+    w_advance();
+    if (!(LAB & 8)) F3R_VMCNT(10);
+    F3R_PHASE_MMA(fa0, 0, 0)
+    read_a(fa1, B, 1);
+    issue_a(1, B2);
+    a_advance();
+    if (!(LAB & 8)) F3R_VMCNT(8);
+    F3R_PHASE_MMA(fa1, 1, 0)
+  };
 #undef F3R_PHASE_MMA
 
-  // ------------------------------------------------------------------ prologue: all of tile 0 and the first halves of tile 1
+  // ------------------------------------------------------------------ prologue
   // The bias and the additive epilogue terms (fp32 / lowp residuals, image-id rows) are loaded FIRST, straight into the accumulators:
   // they land under the latency of the first tiles (f3r_gemm_epi.h); the compiler's own wait covers their first use.
-  typedef GemmFragLayout<4, 8, 2, 4> Frag;  // 2 x 2 fragments from each W half, 4 fragments from each A half
+  typedef GemmFragLayout<2 * NH, 8, 2, 4> Frag;  // 2 fragments from each W half, 4 fragments from each A half
   const int64_t m_base = m0 + wm * 64;
   const int n_base = n0 + wn * 32;
   gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
-  issue_a(0, 0);
-  issue_w(0, 0);
-  issue_a(1, 0);
-  a_advance();
-  issue_w(1, 0);
-  w_advance();
-  issue_a(0, 1);
-  issue_w(0, 1);
-  F3R_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed; the four younger half tiles stay in flight
+  if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
+    issue_a(0, 0);
+    issue_w(0, 0);
+    issue_a(1, 0);
+    a_advance();
+    issue_w(1, 0);
+    w_advance();
+    issue_a(0, 1);
+    issue_w(0, 1);
+    F3R_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed; the four younger half tiles stay in flight
+  } else {                  // tiles 0 and 1
+    issue_a(0, 0);
+    issue_w(0, 0);
+    w_advance();
+    issue_a(1, 0);
+    a_advance();
+    issue_a(0, 1);
+    issue_w(0, 1);
+    w_advance();
+    issue_a(1, 1);
+    a_advance();
+    F3R_VMCNT(8);  // A half 0 and W of tile 0 have landed
+  }
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
 
-  if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
-    tile(IC<0>{});
-    if (nk > 1) tile(IC<1>{});
-    in_loop = true;
-  }
-  for (int t = LAB ? 2 : 0; t < nk; t += 2) {
-    tile(IC<0>{});
-    if (t + 1 < nk) tile(IC<1>{});
+  if constexpr (NH == 2) {
+    if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
+      tile(IC<0>{});
+      if (nk > 1) tile(IC<1>{});
+      in_loop = true;
+    }
+    for (int t = LAB ? 2 : 0; t < nk; t += 2) {
+      tile(IC<0>{});
+      if (t + 1 < nk) tile(IC<1>{});
+    }
+  } else {
+    for (int t = 0; t < nk; t += 3) {
+      tile1(IC<0>{});
+      if (t + 1 < nk) tile1(IC<1>{});
+      if (t + 2 < nk) tile1(IC<2>{});
+    }
   }
   // Past the last tile the cursors stay clamped, so the tail re-loads the last tile into half tiles nobody reads any more; drain them
   // before the workgroup's LDS can be handed to the next one.
@@ -286,9 +337,10 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   else gemm_epilogue_default<T, EPI, Frag, false>(p, acc, m_base, n_base, lane);
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
 __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  constexpr int BN = TileCfg<NH>::BN;
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles, and
   // inside the run walk GM m-tiles x all n-tiles with m fastest, so the ~32 tiles an XCD runs at once share 8 A panels and all of W
   // through its private 4 MiB L2.
@@ -312,15 +364,16 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   const int64_t m0 = tm * BM;
   const int n0 = tn * BN;
   if (EPI == F3R_EPI_QKV && n0 >= 2 * (p.N / 3))
-    gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE>(p, smem, m0, n0);
+    gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
   else
-    gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC>(p, smem, m0, n0);
+    gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
 int launch256(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC>;
+  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH>;
+  constexpr int LDS_BYTES = TileCfg<NH>::LDS_BYTES, BN = TileCfg<NH>::BN;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
@@ -330,32 +383,40 @@ int launch256(const f3r_gemm_args& a, hipStream_t stream) {
   return f3r_check_launch("f3r_gemm(256)");
 }
 
+// 256-wide tiles when N fills them; 128-wide tiles when N is an odd multiple of 128 (no half-empty tile) -- QKV needs the wide tile
+inline int tile_halves(const f3r_gemm_args& a) { return (a.N % 256 == 0 || a.epi == F3R_EPI_QKV) ? 2 : 1; }
+
 template <class T>
 int dispatch256(const f3r_gemm_args& a, hipStream_t stream, int stagger) {
-#define F3R_L256(AM, EP, AD) (stagger ? launch256<T, AM, EP, 1, AD>(a, stream) : launch256<T, AM, EP, 0, AD>(a, stream))
+#define F3R_L256H(AM, EP, AD, NHV) (stagger ? launch256<T, AM, EP, 1, AD, NHV>(a, stream) : launch256<T, AM, EP, 0, AD, NHV>(a, stream))
+#define F3R_L256(AM, EP, AD) (nh == 2 ? F3R_L256H(AM, EP, AD, 2) : F3R_L256H(AM, EP, AD, 1))
   const int add = gemm_additive_pattern(a);
+  const int nh = tile_halves(a);
   if (a.a_mode == F3R_A_CONV3X3) return add == F3R_ADD_RES_LP ? F3R_L256(F3R_A_CONV3X3, F3R_EPI_GENERIC, F3R_ADD_RES_LP) : F3R_L256(F3R_A_CONV3X3, F3R_EPI_GENERIC, F3R_ADD_NONE);
   switch (a.epi) {
     case F3R_EPI_GENERIC:
       return add == F3R_ADD_RES_F32 ? F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_RES_F32)
            : add == F3R_ADD_ROWADD ? F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_ROWADD) : F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_NONE);
-    case F3R_EPI_QKV: return F3R_L256(F3R_A_PLAIN, F3R_EPI_QKV, F3R_ADD_NONE);
+    case F3R_EPI_QKV: return F3R_L256H(F3R_A_PLAIN, F3R_EPI_QKV, F3R_ADD_NONE, 2);
     default: return F3R_L256(F3R_A_PLAIN, F3R_EPI_CONVT, F3R_ADD_NONE);
   }
 #undef F3R_L256
+#undef F3R_L256H
 }
 
 #ifdef F3R_GEMM_LAB
 template <class T, int LAB>
 __global__ __launch_bounds__(NT, 1) void gemm256_lab_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  constexpr int BN = 256;
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int64_t wg = blockIdx.x;
-  gemm256_body<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false, 1, F3R_ADD_NONE, LAB>(p, smem, (wg / n_tiles_n) * BM, (int)(wg % n_tiles_n) * BN);
+  gemm256_body<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false, 1, F3R_ADD_NONE, 2, LAB>(p, smem, (wg / n_tiles_n) * BM, (int)(wg % n_tiles_n) * BN);
 }
 template <class T, int LAB>
 int launch_lab(const f3r_gemm_args& a, hipStream_t stream) {
   auto kern = gemm256_lab_kernel<T, LAB>;
+  constexpr int BN = 256, LDS_BYTES = TileCfg<2>::LDS_BYTES;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, a);
@@ -382,13 +443,8 @@ int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream) {
 // Whether the 256-tile kernel takes this (already validated) problem: everything its LDS-DMA staging cannot express -- K tails, ragged
 // channel counts, strided or pre-activated conv operands, small or narrow outputs -- stays on the 128-tile kernel.
 bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
-  if (a.M < 2048 || a.N % 128 != 0 || a.N < 256) return false;
-  // additive epilogue terms enter through the accumulators: one kind at a time, no activation in between, and only the kinds the
-  // model uses on each operand mode (fp32 residual / image-id rows on plain GEMMs, lowp skip connections on convolutions)
-  const int add = gemm_additive_pattern(a);
-  if (add == F3R_ADD_UNSUPPORTED || (add != F3R_ADD_NONE && a.act != F3R_ACT_NONE)) return false;
-  if (add != F3R_ADD_NONE && a.epi != F3R_EPI_GENERIC) return false;
-  if (a.a_mode == F3R_A_CONV3X3 ? (add == F3R_ADD_RES_F32 || add == F3R_ADD_ROWADD) : add == F3R_ADD_RES_LP) return false;
+  if (a.N % 128 != 0) return false;
+  if (a.epi == F3R_EPI_QKV && (a.N / 3) % 256 != 0) return false;
   const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
   if (Kpad1 % 64 != 0) return false;
   if (a.a_mode == F3R_A_PLAIN) {
@@ -399,12 +455,24 @@ bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
     if (a.M * (int64_t)a.conv_C * 2 >= (1ll << 32)) return false;  // 32-bit byte offsets into the NHWC operand
   }
   if ((int64_t)256 * a.Kpad * 2 >= (1ll << 32)) return false;
-  if (a.epi == F3R_EPI_QKV && (a.N / 3) % 256 != 0) return false;
+  // additive epilogue terms enter through the accumulators: one kind at a time, no activation in between, and only the kinds the
+  // model uses on each operand mode (fp32 residual / image-id rows on plain GEMMs, lowp skip connections on convolutions)
+  const int add = gemm_additive_pattern(a);
+  if (add == F3R_ADD_UNSUPPORTED || (add != F3R_ADD_NONE && a.act != F3R_ACT_NONE)) return false;
+  if (add != F3R_ADD_NONE && a.epi != F3R_EPI_GENERIC) return false;
+  if (a.a_mode == F3R_A_CONV3X3 ? (add == F3R_ADD_RES_F32 || add == F3R_ADD_ROWADD) : add == F3R_ADD_RES_LP) return false;
   return true;
 }
 
+// Whether the 256-tile kernel is also the FASTER choice: one workgroup per CU, so below ~3/4 of a round of tiles (256 CUs) the 128-tile
+// kernel (2 workgroups per CU, 4x the tiles) fills the chip better (measured: 462 vs 545 TF at 128 tiles).
+bool f3r_gemm256_preferred(const f3r_gemm_args& a) {
+  const int bn = tile_halves(a) == 2 ? 256 : 128;
+  return ((a.M + BM - 1) / BM) * ((a.N + bn - 1) / bn) >= 192;
+}
+
 int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger) {
-  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + 127) / 128);
   if (tiles <= 0) return F3R_OK;
   F3R_REQUIRE(tiles < (1ll << 31), "f3r_gemm: grid too large");
   return a.dtype == F3R_F16 ? dispatch256<F16>(a, stream, stagger) : dispatch256<BF16>(a, stream, stagger);

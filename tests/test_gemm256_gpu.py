@@ -20,7 +20,8 @@ SELS = [1, 2, 3]
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (2048 + 37, 512, 768), (2048, 256, 4096), (3000, 384, 64), (2304, 1280, 192)])
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (2048 + 37, 512, 768), (2048, 256, 4096), (3000, 384, 64), (2304, 1280, 192),
+                                   (1500, 128, 256), (777, 640, 448)])  # the last three N: odd multiples of 128 -> the 256 x 128 tile form
 def test_gemm256_outputs_and_residuals(built_lib, dt, M, N, K):
     a, w, bias = rnd((M, K), dt, 3), rnd((N, K), dt, 4, K ** -0.5), torch.randn(N)
     wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
@@ -44,8 +45,8 @@ def test_gemm256_outputs_and_residuals(built_lib, dt, M, N, K):
 
 
 def test_gemm256_rejects_ineligible_shapes(built_lib):
-    a = rnd((64, 128), torch.float16, 1).to(DEV)
-    wp = ops.pack_linear_weight(rnd((128, 128), torch.float16, 2).float(), torch.float16).to(DEV)
+    a = rnd((64, 96), torch.float16, 1).to(DEV)  # K = 96 < Kpad = 128: the LDS-DMA staging cannot zero-fill a K tail
+    wp = ops.pack_linear_weight(rnd((128, 96), torch.float16, 2).float(), torch.float16).to(DEV)
     with pytest.raises(ValueError):
         ops.gemm(a, wp, want_f32=True, kernel_sel=2)  # a forced kernel is an error on a shape it cannot take, never a silent fallback
 
@@ -82,7 +83,7 @@ def test_gemm256_qkv_epilogue(built_lib, dt, n_seq, gh, gw, D, K, use_rope):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 32, 40, 64, 256), (1, 48, 48, 256, 256), (3, 30, 31, 128, 384)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 32, 40, 64, 256), (1, 48, 48, 256, 256), (3, 30, 31, 128, 384), (2, 33, 29, 128, 128), (1, 20, 50, 256, 128)])
 def test_conv256_with_skip_connections(built_lib, dt, B, H, W, Ci, Co):
     """3x3 conv with its operand staged by LDS-DMA (out-of-image taps from the zero line) + bias + the two lowp skip adds + the
     pre-activated second output -- ResidualConvUnit_custom inside a fusion block (dpt_block.py:133-154,208-216)."""
@@ -126,7 +127,7 @@ def split_tol(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K,sels", [(200, 192, 128, [1]), (77, 260, 200, [1]), (4096, 512, 1024, SELS), (2048 + 5, 256, 64, SELS)])
+@pytest.mark.parametrize("M,N,K,sels", [(200, 192, 128, [1]), (77, 260, 200, [1]), (4096, 512, 1024, SELS), (2048 + 5, 256, 64, SELS), (1000, 128, 320, SELS)])
 def test_gemm_split_precision(built_lib, dt, M, N, K, sels):
     g = torch.Generator().manual_seed(77)
     a32 = torch.randn((M, K), generator=g)
@@ -151,7 +152,7 @@ def test_gemm_split_precision(built_lib, dt, M, N, K, sels):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,H,W,Ci,Co,sels", [(1, 9, 7, 96, 64, [1]), (2, 32, 40, 64, 256, SELS)])
+@pytest.mark.parametrize("B,H,W,Ci,Co,sels", [(1, 9, 7, 96, 64, [1]), (2, 32, 40, 64, 256, SELS), (1, 40, 40, 128, 128, SELS)])
 def test_conv_split_precision(built_lib, dt, B, H, W, Ci, Co, sels):
     g = torch.Generator().manual_seed(78)
     x32 = torch.randn((B, H, W, Ci), generator=g)

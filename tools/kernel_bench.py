@@ -216,7 +216,7 @@ def bench_conv(dt, B, H, W, Ci, Co, name, stride=1, sels=(1, 2, 3), split=None):
     oh, ow = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     r1 = torch.randn((B, oh, ow, Co), device=DEV).to(dt)
     cases = [("a_relu (round-1 form)", dict(a_relu=True, res_lp=r1), (1,))] if split is None else []
-    cases.append(("skip + relu copy", dict(res_lp=r1, want_relu=True), tuple(s_ for s_ in sels if stride == 1 and Ci % 64 == 0 and Co >= 256 or s_ == 1)))
+    cases.append(("skip + relu copy", dict(res_lp=r1, want_relu=True), tuple(s_ for s_ in sels if stride == 1 and Ci % 64 == 0 and Co % 128 == 0 or s_ == 1)))
     for cname, kw, csels in cases:
         fns = {}
         for sel in csels:
@@ -362,7 +362,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
-            bench_attn(dt, nv, variants)
+            bench_attn(torch.bfloat16, nv, variants)
+            bench_attn(torch.float16, nv, variants)
         sys.exit(0)
     if "attn" in args.what:
         for nv in [int(v) for v in args.views.split(",")]:
