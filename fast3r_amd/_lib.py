@@ -40,6 +40,7 @@ class GemmArgs(ctypes.Structure):
         ("dtype", _c_i32), ("rope_mode", _c_i32),
         ("split", _c_i32), ("kernel_sel", _c_i32), ("A_lo", _c_vp),
         ("out_lp_lo", _c_vp), ("res_lp_lo", _c_vp), ("res_lp2_lo", _c_vp), ("out_relu", _c_vp), ("out_relu_lo", _c_vp),
+        ("qkv_dq", _c_i32), ("reserved1", _c_i32),
     ]
 
 
@@ -57,6 +58,7 @@ class AttnArgs(ctypes.Structure):
         ("k_batch_stride", _c_i64 * F3R_MAX_SEG), ("vt_batch_stride", _c_i64 * F3R_MAX_SEG),
         ("scale", _c_f32), ("q_prescaled", _c_i32),
         ("st_o", _c_vp), ("st_ml", _c_vp), ("state_in", _c_i32), ("state_out", _c_i32),
+        ("kv_group", _c_i32), ("causal", _c_i32), ("q_pos0", _c_i64), ("seg_pos0", _c_i64 * F3R_MAX_SEG),
     ]
 
 
@@ -69,7 +71,7 @@ SYMBOLS = {
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
-    "f3r_block_workspace_bytes": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "f3r_block_workspace_bytes": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)]),
     "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      _c_f32, _c_f32, ctypes.c_int, _c_vp]),

@@ -52,7 +52,9 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((ch
 
 // BATCHED only tags the kernel name: the encoder launches (many 1024-key sequences) and the fusion launches (one sequence of all
 // keys) then show up as two lines in rocprofv3 --stats, and the fusion line is the roofline kernel of bench.py.  Same body.
-template <class T, bool BATCHED>
+// CAUSAL (F.scaled_dot_product_attention(..., is_causal=True) of the LlamaDecoder variant) is a separate instantiation: the position
+// bookkeeping and the diagonal masks stay out of the non-causal kernel's loop.
+template <class T, bool BATCHED, bool CAUSAL>
 __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args p) {
   constexpr int QPW = AT_QPW, DPW = AT_DPW;
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * AT_TILE];  // [buf][K | Vt][64][64] = 32 KB
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
   const int g = lane >> 5;
 
   const int head = blockIdx.y;
+  const int kv_head = p.kv_group > 1 ? head / p.kv_group : head;  // grouped-query attention: kv_group query heads share one K / V head
   const int b = blockIdx.z;
   const int64_t q0 = (int64_t)blockIdx.x * AT_QB + wid * (QPW * 32);
 
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
   const char* dKb = nullptr;  // wave-uniform: first K row of the next tile, this head
   const char* dVb = nullptr;  // wave-uniform: V^T row head * 64, first key of the next tile
   int valid_ld = 0;           // valid keys of the tile most recently issued
+  int64_t pos_ld = 0;         // causal: global sequence position of its first key
   auto next_segment = [&]() {
     key_ld = 0;
     seg_keys = 0;
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
       if (p.seg_len[seg_ld] > 0) {
         seg_keys = p.seg_len[seg_ld];
         seg_ldvt = p.ldvt[seg_ld];
-        dKb = (const char*)((const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + head * 64);
-        dVb = (const char*)((const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)head * 64 * seg_ldvt);
+        dKb = (const char*)((const uint16_t*)p.k_seg[seg_ld] + (int64_t)b * p.k_batch_stride[seg_ld] + kv_head * 64);
+        dVb = (const char*)((const uint16_t*)p.vt_seg[seg_ld] + (int64_t)b * p.vt_batch_stride[seg_ld] + (int64_t)kv_head * 64 * seg_ldvt);
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {  // wave-instruction i of a tile fills rows (wid*DPW + i)*8 + lane/8; chunk lane%8 <- swizzled source chunk
           const int row = (wid * DPW + i) * 8 + d_lrow;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
     if (seg_keys == 0) return false;
     const int64_t rem = seg_keys - key_ld;
     valid_ld = rem < AT_KB ? (int)rem : AT_KB;
+    if (CAUSAL) pos_ld = p.seg_pos0[seg_ld] + key_ld;
     uint16_t* kt = lds + buf * 2 * AT_TILE;
     uint16_t* vt = kt + AT_TILE;
 #pragma unroll
@@ -185,6 +190,8 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
 
   dma_next(0);  // tile 0 always exists
   int valid_cur = valid_ld;
+  int64_t pos_cur = pos_ld;
+  const int64_t wave_q0 = p.q_pos0 + q0;  // causal: position of this wave's first query
   __syncthreads();
   // Everything loaded so far (Q fragments, tile 0) has landed.  Say so with a waitcnt the compiler models: without it
   // the loop body waits for the loop-invariant Q registers with vmcnt(N) counts that, in steady state, land on the
@@ -196,7 +203,6 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
     const int valid = valid_cur;
     const uint16_t* kt = lds + cur * 2 * AT_TILE;
     const uint16_t* vt = kt + AT_TILE;
-
     // ---- S^T = K Q^T - m
     float16v s[QPW][2];
     __builtin_amdgcn_s_setprio(1);
@@ -230,6 +236,21 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
             const int kc = kb * 32 + 16 * (r >> 3) + (r & 7);
             if (kc >= vg) s[qb][kb][r] = -1e30f;
           }
+    }
+    // causal: keys beyond a row's own position are masked; a tile that lies entirely beyond the wave's rows is masked whole (its P are
+    // exactly 0: it costs its MFMAs but changes nothing -- the first tile of a launch always holds a visible key for every row)
+    if (CAUSAL && pos_cur + (AT_KB - 1) > wave_q0) {  // the tile reaches past the first row of this wave (wave-uniform)
+#pragma unroll
+      for (int qb = 0; qb < QPW; ++qb) {
+        const int lim = (int)(wave_q0 + qb * 32 + lq - pos_cur) - 8 * g;  // key kc of the tile is visible iff kc + 8 g <= query position - pos_cur
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kc = kb * 32 + 16 * (r >> 3) + (r & 7);
+            if (kc > lim) s[qb][kb][r] = -1e30f;
+          }
+      }
     }
     // the next tile's DMA goes out here: buffer cur^1 was released by the barrier that ended the previous iteration
     const bool more = dma_next(cur ^ 1);
@@ -299,6 +320,7 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_kernel(const f3r_attn_args
     __builtin_amdgcn_s_setprio(0);
 
     valid_cur = valid_ld;
+    pos_cur = pos_ld;
     __syncthreads();  // (the compiler drains vmcnt before the barrier, i.e. the next tile has landed for every wave)
     cur ^= 1;
     have = more;
@@ -349,10 +371,12 @@ int attn_launch(const f3r_attn_args& a, hipStream_t s) {
   const int64_t qblocks = (a.tq + AT_QB - 1) / AT_QB;
   F3R_REQUIRE(qblocks < (1ll << 31) && a.n_heads < 65536 && a.batch < 65536, "f3r_attn_fwd: grid too large");
   dim3 grid((unsigned)qblocks, (unsigned)a.n_heads, (unsigned)a.batch);
-  if (a.batch > 1)
-    hipLaunchKernelGGL((attn_kernel<T, true>), grid, dim3(AT_NW * 64), 0, s, a);
+  if (a.causal)
+    hipLaunchKernelGGL((attn_kernel<T, false, true>), grid, dim3(AT_NW * 64), 0, s, a);
+  else if (a.batch > 1)
+    hipLaunchKernelGGL((attn_kernel<T, true, false>), grid, dim3(AT_NW * 64), 0, s, a);
   else
-    hipLaunchKernelGGL((attn_kernel<T, false>), grid, dim3(AT_NW * 64), 0, s, a);
+    hipLaunchKernelGGL((attn_kernel<T, false, false>), grid, dim3(AT_NW * 64), 0, s, a);
   return f3r_check_launch("f3r_attn_fwd");
 }
 
@@ -366,7 +390,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.n_heads > 0 && a.batch > 0 && a.tq >= 0, "f3r_attn_fwd: bad sizes");
   F3R_REQUIRE(a.n_seg >= 1 && a.n_seg <= F3R_MAX_SEG, "f3r_attn_fwd: n_seg %d out of range", a.n_seg);
   F3R_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "f3r_attn_fwd: ldq/ldk must be multiples of 8, ldo of 4");
-  F3R_REQUIRE(a.ldq >= a.n_heads * 64 && a.ldk >= a.n_heads * 64 && a.ldo >= a.n_heads * 64, "f3r_attn_fwd: row strides < heads*64");
+  F3R_REQUIRE(a.ldq >= a.n_heads * 64 && a.ldo >= a.n_heads * 64, "f3r_attn_fwd: row strides < heads*64");
   F3R_REQUIRE((((uintptr_t)a.q) & 15) == 0 && (((uintptr_t)a.o) & 7) == 0, "f3r_attn_fwd: q/o alignment");
   F3R_REQUIRE(a.q_batch_stride % 8 == 0 && a.o_batch_stride % 4 == 0, "f3r_attn_fwd: batch strides alignment");
   int64_t total = 0;
@@ -383,6 +407,9 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
     total += a.seg_len[s];
   }
   F3R_REQUIRE(total > 0, "f3r_attn_fwd: no keys");
+  F3R_REQUIRE(a.kv_group >= 0 && (a.kv_group <= 1 || a.n_heads % a.kv_group == 0), "f3r_attn_fwd: kv_group %d does not divide n_heads %d", a.kv_group, a.n_heads);
+  const int kv_heads = a.kv_group > 1 ? a.n_heads / a.kv_group : a.n_heads;
+  F3R_REQUIRE(a.ldk >= kv_heads * 64, "f3r_attn_fwd: ldk < kv heads * 64");
   if (a.state_in || a.state_out) {
     F3R_REQUIRE(a.st_o && a.st_ml && (((uintptr_t)a.st_o) & 15) == 0 && (((uintptr_t)a.st_ml) & 15) == 0, "f3r_attn_fwd: state buffers null/misaligned");
   }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wid = tid >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the per-wave operand roles below stay wave-uniform branches
   const int wm = wid >> 1, wn = wid & 1;
 
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const f3r_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-  // swapped operand roles only for the V third of the QKV epilogue (block-uniform)
-  const int Dm = p.N / 3;
-  const bool swap_roles = (EPI == F3R_EPI_QKV) && (n0 >= 2 * Dm);
+  // swapped operand roles only for the V part of the QKV epilogue (wave-uniform: a wave's 64 columns are one head)
+  const int Dq_ = p.qkv_dq ? p.qkv_dq : p.N / 3;
+  const bool swap_roles = (EPI == F3R_EPI_QKV) && (n0 + wn * 64 >= Dq_ + (p.N - Dq_) / 2);
 
   const int fr = lane & 15;  // fragment row inside a 16-row block
   const int fg = lane >> 4;  // k-group: 8 elements at k = ks*32 + fg*8
@@ -347,7 +347,9 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(!a.rowadd || (al16(a.rowadd) && a.rowadd_div > 0), "f3r_gemm: rowadd alignment/div");
     F3R_REQUIRE(!a.bias || al16(a.bias), "f3r_gemm: bias alignment");
   } else if (a.epi == F3R_EPI_QKV) {
-    F3R_REQUIRE(a.N % 3 == 0 && (a.N / 3) % 128 == 0, "f3r_gemm: QKV needs N = 3*D with D %% 128 == 0 (got %d)", a.N);
+    const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
+    F3R_REQUIRE(a.qkv_dq != 0 || a.N % 3 == 0, "f3r_gemm: QKV with three equal parts needs N %% 3 == 0 (got %d)", a.N);
+    F3R_REQUIRE(Dq > 0 && Dq % 64 == 0 && a.N > Dq && (a.N - Dq) % 128 == 0, "f3r_gemm: QKV parts must be whole 64-wide heads (N %d, q %d)", a.N, Dq);
     F3R_REQUIRE(a.q && a.k && a.vt && al8(a.q) && al8(a.k) && al8(a.vt), "f3r_gemm: QKV outputs null/misaligned");
     F3R_REQUIRE(a.seq_len > 0 && a.M % a.seq_len == 0 && a.ldvt >= a.seq_len, "f3r_gemm: QKV seq_len/ldvt");
     F3R_REQUIRE(a.act == F3R_ACT_NONE, "f3r_gemm: QKV has no activation");

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   const int64_t tm = first_m + rem_ % gm;
   const int64_t m0 = tm * BM;
   const int n0 = tn * BN;
-  if (EPI == F3R_EPI_QKV && n0 >= 2 * (p.N / 3))
+  if (EPI == F3R_EPI_QKV && n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3)))
     gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
   else
     gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
@@ -444,7 +444,10 @@ int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream) {
 // channel counts, strided or pre-activated conv operands, small or narrow outputs -- stays on the 128-tile kernel.
 bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
   if (a.N % 128 != 0) return false;
-  if (a.epi == F3R_EPI_QKV && (a.N / 3) % 256 != 0) return false;
+  if (a.epi == F3R_EPI_QKV) {  // a 256-wide tile must lie in ONE of the q / k / v parts
+    const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
+    if (Dq % 256 != 0 || ((a.N - Dq) / 2) % 256 != 0) return false;
+  }
   const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
   if (Kpad1 % 64 != 0) return false;
   if (a.a_mode == F3R_A_PLAIN) {

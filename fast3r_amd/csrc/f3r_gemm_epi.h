@@ -283,8 +283,12 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
     // A column group of a wave (NG fragments = NG*16 columns, 32 or 64 wide and aligned) lies inside ONE head and inside whole 32-column
     // halves of it: RoPE pairs dim i with i + 16 inside a half, i.e. fragments (2j, 2j+1) of a lane.
     static_assert(EPI != F3R_EPI_QKV || (L::NG % 2 == 0 && NF % 2 == 0), "RoPE pairs need an even number of fragments per column group");
-    const int Dm = p.N / 3;
-    const int part = n_base / Dm;  // 0 q, 1 k (wave-uniform; every column group of the tile is in the same third: Dm % tile width == 0)
+    // columns [0, Dq) are q, [Dq, Dq + Dkv) k (f3r_gemm_args.qkv_dq); wave-uniform: every column group of a wave lies in one part
+    const int Dq = p.qkv_dq ? p.qkv_dq : p.N / 3;
+    const int Dkv = (p.N - Dq) / 2;
+    const int part = n_base < Dq ? 0 : 1;
+    const int Dm = part == 0 ? Dq : Dkv;   // row stride of the destination
+    const int col0 = part == 0 ? 0 : Dq;   // first GEMM column of the part
     uint16_t* dst = (uint16_t*)(part == 0 ? p.q : p.k);
     const float qs = (part == 0 && p.q_scale != 0.f) ? p.q_scale : 1.f;
 #pragma unroll
@@ -325,7 +329,7 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
           }
         }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) store4_split<T>(dst + m[i] * (int64_t)Dm + (nb[nf] - part * Dm), nullptr, v[nf] * qs);
+        for (int nf = 0; nf < NF; ++nf) store4_split<T>(dst + m[i] * (int64_t)Dm + (nb[nf] - col0), nullptr, v[nf] * qs);
       }
     }
   }
@@ -336,13 +340,14 @@ template <class T, class L, bool BIAS>
 __device__ __forceinline__ void gemm_epilogue_vt(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
   constexpr int NF = L::NF, MF = L::MF;
   const int fr = lane & 15, fg = lane >> 4;
-  const int Dm = p.N / 3;
+  const int Dq = p.qkv_dq ? p.qkv_dq : p.N / 3;
+  const int Dm = (p.N - Dq) / 2;  // width of the k and of the v part
   uint16_t* vt = (uint16_t*)p.vt;
   const bool vec_ok = ((p.seq_len | p.ldvt) & 3) == 0;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int n = n_base + L::col(nf) + fr;  // < N
-    const int d = n - 2 * Dm;
+    const int d = n - Dq - Dm;
     const float bb = (BIAS && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {

@@ -35,9 +35,13 @@ def _round_up(x, m):
 class KVExchange:
     """Per-forward send/receive buffers for the per-layer K / V^T all-gather (allocated once, reused by all layers)."""
 
-    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device):
+    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device, n_heads=None, q_dim=None):
+        """D = width of the K rows / number of V^T planes x 64 (= the model width, or n_kv_heads * 64 with grouped-query attention);
+        q_dim = width of the parked O state (the model width)."""
         self.group, self.world, self.rank = group, world, rank
         self.t_loc, self.t_all, self.D = t_loc, list(t_all), D
+        q_dim = D if q_dim is None else q_dim
+        n_heads = q_dim // 64 if n_heads is None else n_heads
         t_max = max(self.t_all)
         self.t_max = t_max
         self.ldvt = _round_up(t_max, 64)
@@ -50,8 +54,8 @@ class KVExchange:
         # parked online-softmax state of the local-shard launch (fp32 O accumulators + {m, l0, l1, -} per query and head)
         self.state = None
         if self.has_remote and t_loc > 0:
-            self.state = (torch.empty((t_loc, D), dtype=torch.float32, device=device),
-                          torch.empty((t_loc, D // 64, 4), dtype=torch.float32, device=device))
+            self.state = (torch.empty((t_loc, q_dim), dtype=torch.float32, device=device),
+                          torch.empty((t_loc, n_heads, 4), dtype=torch.float32, device=device))
 
     def _all_gather(self, out2d, in2d):
         """RCCL moves device buffers directly.  Any other backend (gloo: CPU tests, and the 2-process single-GPU
@@ -69,6 +73,18 @@ class KVExchange:
         self.start()
         self.finish()
         return [(self.k_all[r], self.vt_all[r], self.t_all[r], 0, 0) for r in range(self.world) if self.t_all[r] > 0]
+
+    def positions(self):
+        """Global token index of the first row of every rank's shard (ranks own consecutive view ranges)."""
+        out, run = [], 0
+        for t in self.t_all:
+            out.append(run)
+            run += t
+        return out
+
+    def remote_positions(self):
+        pos = self.positions()
+        return [pos[r] for r in range(self.world) if r != self.rank and self.t_all[r] > 0]
 
     # ---- split form: the gather runs while the attention kernel works on the local shard
     def local_segment(self):
@@ -126,8 +142,8 @@ class ViewSharding:
         dist.all_gather_into_tensor(out, mine, group=self.group)
         return [int(v) for v in out.cpu().tolist()]
 
-    def make_kv_exchange(self, t_loc, D, dtype, dev):
-        return KVExchange(self.group, self.world, self.rank, t_loc, self.all_token_counts(t_loc, dev), D, dtype, dev)
+    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None):
+        return KVExchange(self.group, self.world, self.rank, t_loc, self.all_token_counts(t_loc, dev), D, dtype, dev, n_heads, q_dim)
 
     def gather_results(self, results, n_total, dev):
         """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with

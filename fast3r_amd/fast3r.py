@@ -185,8 +185,8 @@ class _LlamaBlock(_Params):
 class LlamaDecoder(_Params):
     """fast3r.py:810-968 (the `llama_dec` experiment, configs/experiment/llama_dec/llama_dec.yaml): pre-norm RMSNorm blocks with SwiGLU,
     bias-free projections, rotary embedding of q / k by the IMAGE id of a token's view (all patches of a view share one angle set), a
-    learnable embedding added to the tokens of view 0 before every layer, final RMSNorm.  Bidirectional attention only; n_kv_heads must
-    equal n_heads (the released config) and head_dim must be 64."""
+    learnable embedding added to the tokens of view 0 before every layer, final RMSNorm.  Bidirectional (the released config) or
+    causal attention; grouped-query attention with an even n_kv_heads; head_dim must be 64."""
 
     def __init__(self, random_image_idx_embedding, enc_embed_dim, embed_dim=4096, n_layers=32, n_heads=32, n_kv_heads=None,
                  multiple_of=256, ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=False,
@@ -194,17 +194,20 @@ class LlamaDecoder(_Params):
         super().__init__()
         if embed_dim % n_heads != 0 or embed_dim // n_heads != 64:
             raise ValueError("fast3r_amd kernels are built for head_dim 64")
-        if n_kv_heads not in (None, n_heads):
-            raise NotImplementedError("fast3r_amd LlamaDecoder: grouped-query attention (n_kv_heads != n_heads) is not built")
-        if is_causal:
-            raise NotImplementedError("fast3r_amd LlamaDecoder: causal attention is not built (the reference config is bidirectional)")
+        n_kv_heads = n_heads if n_kv_heads is None else int(n_kv_heads)
+        if n_heads % n_kv_heads != 0:
+            raise ValueError(f"n_heads ({n_heads}) must be a multiple of n_kv_heads ({n_kv_heads})")  # repeat_kv, llama.py:125-134,196
+        if n_kv_heads % 2 != 0 and n_kv_heads != n_heads:
+            # the k and the v part of the fused QKV projection must each be whole 128-column blocks (f3r_gemm QKV epilogue)
+            raise NotImplementedError("fast3r_amd LlamaDecoder: grouped-query attention needs an even n_kv_heads")
         self.embed_dim, self.num_heads, self.depth = embed_dim, n_heads, n_layers
+        self.n_kv_heads, self.is_causal = n_kv_heads, bool(is_causal)
         self.random_image_idx_embedding = random_image_idx_embedding
         self.rope_theta, self.norm_eps = rope_theta, norm_eps
         self.view0_embed = nn.Parameter(torch.zeros(embed_dim))                          # fast3r.py:841-842
         nn.init.normal_(self.view0_embed, mean=0.0, std=0.02)
         self.decoder_embed = nn.Linear(enc_embed_dim, embed_dim, bias=True)              # :845
-        self.layers = nn.ModuleList([_LlamaBlock(embed_dim, n_heads, n_heads, multiple_of, ffn_dim_multiplier, norm_eps)
+        self.layers = nn.ModuleList([_LlamaBlock(embed_dim, n_heads, n_kv_heads, multiple_of, ffn_dim_multiplier, norm_eps)
                                      for _ in range(n_layers)])                          # :848-852
         self.norm = _RMSNorm(embed_dim, norm_eps)                                        # :854
         # precompute_freqs_cis (llama.py:41-60) as [cos (32) | sin (32)] per position instead of complex64; a plain attribute, not a
@@ -279,10 +282,11 @@ class PixelwiseTaskWithDPT(_Params):
 # ======================================================================================= packed (device) weights
 class _PackedBlock:
     __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                 "rms", "rope_mode", "swiglu_hidden")
+                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal")
 
     def __init__(self):
         self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
+        self.q_dim, self.kv_dim, self.kv_group, self.causal = 0, None, 1, False  # grouped-query / causal attention (LlamaDecoder only)
 
 
 def _f32(t):
@@ -300,16 +304,21 @@ def _pack_block(blk: _Block, lp, split=False):
     return p
 
 
-def _pack_llama_block(blk: _LlamaBlock, n_heads, lp, split=False):
+def _pack_llama_block(blk: _LlamaBlock, n_heads, lp, split=False, n_kv_heads=None, causal=False):
     """LlamaDecoder layer -> the same packed fields as a ViT block: [wq; wk; wv] as one QKV matrix (q / k rows permuted per head, see
     _ROPE_PERM), [w1; w3] stacked for one up-projection GEMM, no biases, RMSNorm weights."""
     p = _PackedBlock()
     p.rms, p.rope_mode = True, 1
     p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.attention_norm.weight), None, _f32(blk.ffn_norm.weight), None
     p.eps = blk.attention_norm.eps
+    n_kv_heads = n_heads if n_kv_heads is None else n_kv_heads
     perm = torch.tensor([h * 64 + d for h in range(n_heads) for d in _ROPE_PERM])
+    perm_kv = torch.tensor([h * 64 + d for h in range(n_kv_heads) for d in _ROPE_PERM])
     wq, wk, wv = (m.weight.detach().float() for m in (blk.attention.wq, blk.attention.wk, blk.attention.wv))
-    p.qkv_w, p.qkv_b = ops.pack_linear_weight(torch.cat([wq[perm], wk[perm], wv], dim=0), lp, split), None
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(torch.cat([wq[perm], wk[perm_kv], wv], dim=0), lp, split), None
+    if n_kv_heads != n_heads:
+        p.q_dim, p.kv_dim, p.kv_group = n_heads * 64, n_kv_heads * 64, n_heads // n_kv_heads
+    p.causal = bool(causal)
     p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attention.wo.weight.detach().float(), lp, split), None
     w1, w3 = blk.feed_forward.w1.weight.detach().float(), blk.feed_forward.w3.weight.detach().float()
     p.swiglu_hidden = w1.shape[0]
@@ -598,7 +607,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
         if isinstance(dec, LlamaDecoder):
-            pk["dec"] = [_pack_llama_block(b, dec.num_heads, lp, hp) for b in dec.layers]
+            pk["dec"] = [_pack_llama_block(b, dec.num_heads, lp, hp, dec.n_kv_heads, dec.is_causal) for b in dec.layers]
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
@@ -619,7 +628,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def _block_ws(self, pb, T, D, n_seq, seq_len, dev):
         """Workspace of the blocks of one encoder pass / decoder sample: ONE allocation shared by all of its layers."""
         hidden = pb.fc1_w.shape[0]  # rows of the (possibly stacked [w1; w3]) up-projection
-        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev)
+        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=pb.kv_dim)
 
     def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None):
         """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
@@ -638,11 +647,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             ldvt = vt.shape[-1]
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
-        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp)
+        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp, q_dim=pb.q_dim)
         o = h  # LN output is dead: reuse as the attention output buffer
+        gqa = dict(kv_group=pb.kv_group, causal=pb.causal)
         if kv_exchange is None:
-            ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * D, D * ldvt)], tq=seq_len, batch=n_seq,
-                          q_batch_stride=seq_len * D, o_batch_stride=seq_len * D, q_prescaled=True)
+            Dkv = k.shape[1]
+            ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * Dkv, Dkv * ldvt)], tq=seq_len, batch=n_seq,
+                          q_batch_stride=seq_len * D, o_batch_stride=seq_len * D, q_prescaled=True, **gqa)
         else:
             # view-sharded: the all-gather of the remote K / V^T runs while the kernel attends over the local shard; the
             # online-softmax state (m, l, O) is parked in fp32 and resumed over the remote segments once they have landed
@@ -650,13 +661,15 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             if seq_len == 0:
                 kv_exchange.finish()  # a rank without tokens still takes part in the collective
             elif kv_exchange.has_remote:
+                pos = kv_exchange.positions()  # global token index of the first row of every rank's shard (causal attention only)
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True,
-                              state=kv_exchange.state, state_out=True)
-                ops.attention(q, o, n_heads, scale, kv_exchange.finish(), tq=seq_len, q_prescaled=True,
-                              state=kv_exchange.state, state_in=True)
+                              state=kv_exchange.state, state_out=True, q_pos0=pos[kv_exchange.rank], seg_pos0=[pos[kv_exchange.rank]], **gqa)
+                remote = kv_exchange.finish()
+                ops.attention(q, o, n_heads, scale, remote, tq=seq_len, q_prescaled=True, state=kv_exchange.state, state_in=True,
+                              q_pos0=pos[kv_exchange.rank], seg_pos0=kv_exchange.remote_positions(), **gqa)
             else:
                 kv_exchange.finish()
-                ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True)
+                ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True, **gqa)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
@@ -1007,7 +1020,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             enc_lo = None
             if feats[0][b][1] is not None:
                 enc_lo = (torch.cat([feats[i][b][1] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b][1]).contiguous()
-            kvx = None if sh is None else sh.make_kv_exchange(T_loc, D, lp, dev)
+            kv_dim = getattr(pk["dec"][0], "kv_dim", None) or D
+            kvx = None if sh is None else sh.make_kv_exchange(T_loc, kv_dim, lp, dev, n_heads=dec.num_heads, q_dim=D)
             hook_toks.append(self._decode_sample(pk, enc_hi, enc_lo, Ps, emb_rows[b], v_lo, kvx))
             if self.debug_taps is not None:
                 self.debug_taps.setdefault("hooks", []).append([t[0].float().cpu() for t in hook_toks[-1]])

@@ -169,9 +169,10 @@ class BlockWorkspace:
     """The intermediates of a transformer block -- LN / attention output, q, k, V^T, MLP hidden -- as views of ONE allocation laid out by
     f3r_block_workspace_bytes (include/f3r.h): made once per encoder pass / decoder sample, reused by every block of it."""
 
-    def __init__(self, tokens, D, hidden, n_seq, seq_len, lp, device):
+    def __init__(self, tokens, D, hidden, n_seq, seq_len, lp, device, kv_dim=None):
+        kv_dim = D if kv_dim is None else kv_dim
         offs = (ctypes.c_size_t * 5)()
-        total = _lib.lib().f3r_block_workspace_bytes(tokens, D, hidden, n_seq, seq_len, offs)
+        total = _lib.lib().f3r_block_workspace_bytes(tokens, D, kv_dim, hidden, n_seq, seq_len, offs)
         if total == 0:
             raise ValueError(f"f3r_block_workspace_bytes: bad sizes ({tokens=}, {D=}, {hidden=}, {n_seq=}, {seq_len=})")
         self.buf = torch.empty((total,), dtype=torch.uint8, device=device)
@@ -182,8 +183,8 @@ class BlockWorkspace:
             for d in shape:
                 n *= d
             return self.buf[offs[i]:offs[i] + 2 * n].view(lp).view(shape)
-        self.h, self.q, self.k = view(0, (tokens, D)), view(1, (tokens, D)), view(2, (tokens, D))
-        self.vt, self.hid = view(3, (n_seq, D, ld)), view(4, (tokens, hidden))
+        self.h, self.q, self.k = view(0, (tokens, D)), view(1, (tokens, D)), view(2, (tokens, kv_dim))
+        self.vt, self.hid = view(3, (n_seq, kv_dim, ld)), view(4, (tokens, hidden))
         if ld != seq_len:
             self.vt.zero_()  # the pad columns are read by the last key tile and never written by the QKV epilogue
         self.key = (tokens, D, hidden, n_seq, seq_len, lp, str(device))
@@ -197,8 +198,9 @@ def vt_ld(seq_len: int) -> int:
 LOG2E = 1.4426950408889634
 
 
-def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0, split=None, a_lo=None, kernel_sel=0):
-    """QKV projection with the attention-layout epilogue: q,k -> [M][D] (optionally RoPE'd), v -> vt[M/seq][D][ldvt].
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0, split=None, a_lo=None, kernel_sel=0, q_dim=0):
+    """QKV projection with the attention-layout epilogue: q -> [M][Dq], k -> [M][Dkv] (optionally RoPE'd), v -> vt[M/seq][Dkv][ldvt]
+    (Dq = Dkv = N/3 unless q_dim is given: grouped-query attention).
     rope = (cos, sin, tokens_per_row) or None; rope_mode 0 = RoPE-2D tables [n_pos][16], 1 = per-row-group tables [n_groups][32]
     (rope[2] = rows per group; see f3r_gemm_args.rope_mode).  vt must be zero-initialised once (its padding is never written)."""
     require_gpu(a, "a")
@@ -215,6 +217,7 @@ def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0,
         g.rope_cos, g.rope_sin, g.rope_w = ptr(rope[0]), ptr(rope[1]), rope[2]
         g.rope_mode = int(rope_mode)
     g.q_scale = float(q_scale)
+    g.qkv_dq = int(q_dim)  # 0: three equal thirds; else the q part is q_dim columns and k, v share the rest (grouped-query attention)
     g.kernel_sel = kernel_sel
     _split_operand(g, a, split, a_lo)
     g.dtype = dtype_id(lp)
@@ -317,9 +320,10 @@ def attention_state(tq_total: int, n_heads: int, device):
 
 
 def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
-              state=None, state_in=False, state_out=False):
+              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
-    with k [..][seg_len][ldk] and vt [..][heads*64][ldvt]."""
+    with k [..][seg_len][ldk] and vt [..][kv_heads*64][ldvt].  kv_group: query heads per K / V head (grouped-query attention).
+    causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices)."""
     require_gpu(q, "q")
     lp = q.dtype
     assert 1 <= len(segments) <= F3R_MAX_SEG
@@ -337,6 +341,18 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
         a.ldk = k.stride(-2)
     a.scale = float(scale)
     a.q_prescaled = int(q_prescaled)
+    a.kv_group, a.causal, a.q_pos0 = int(kv_group), int(bool(causal)), int(q_pos0)
+    if causal:
+        pos = [0] * len(segments)
+        if seg_pos0 is None:  # consecutive segments of one sequence starting at position 0
+            run = 0
+            for i, sgm in enumerate(segments):
+                pos[i] = run
+                run += int(sgm[2])
+        else:
+            pos = [int(v) for v in seg_pos0]
+        for i, v in enumerate(pos):
+            a.seg_pos0[i] = v
     if state is not None:
         a.st_o, a.st_ml = ptr(state[0]), ptr(state[1])
         a.state_in, a.state_out = int(state_in), int(state_out)

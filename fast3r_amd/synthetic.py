@@ -35,7 +35,7 @@ def vit_large_args(img_size=512, attn_implementation="flash_attention", random_i
 def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64, with_local_head=True,
               random_image_idx_embedding=True, attn_implementation="pytorch_naive",
               attn_bias_for_inference_enabled=True, decoder_type="fast3r", llama_layers=12,
-              patch_embed_cls="PatchEmbedDust3R", landscape_only=False):
+              patch_embed_cls="PatchEmbedDust3R", landscape_only=False, llama_kv_heads=None, llama_causal=False):
     """Small model of the same family (head_dim stays 64; decoder depth must be > 9, fast3r.py:137)."""
     encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls=patch_embed_cls,
                         embed_dim=embed_dim, num_heads=num_heads, depth=enc_depth, mlp_ratio=4, pos_embed="RoPE100",
@@ -49,8 +49,8 @@ def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64
         # configs/experiment/llama_dec/llama_dec.yaml:52-66 merged over configs/model/fast3r.yaml: the base keys stay in the dict (they
         # disappear into LlamaDecoder's **kwargs) and `depth` -- not n_layers -- is what the heads read (fast3r.py:137-148)
         decoder_args = dict(decoder_type="llama", random_image_idx_embedding=random_image_idx_embedding, enc_embed_dim=embed_dim,
-                            embed_dim=embed_dim, n_layers=llama_layers, n_heads=num_heads, n_kv_heads=None, multiple_of=64,
-                            ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=False,
+                            embed_dim=embed_dim, n_layers=llama_layers, n_heads=num_heads, n_kv_heads=llama_kv_heads, multiple_of=64,
+                            ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=llama_causal,
                             depth_init=True, depth=dec_depth, num_heads=num_heads, mlp_ratio=4.0, qkv_bias=True)
     head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=landscape_only,
                      depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],

@@ -147,6 +147,11 @@ typedef struct f3r_gemm_args {
      (dpt_block.py:143,148), so that conv needs no a_relu and can stage its operand by LDS-DMA */
   void* out_relu;
   void* out_relu_lo;
+  /* QKV epilogue with grouped-query attention (LlamaDecoder n_kv_heads < n_heads, components/llama.py:195-198,220-232): the N columns are
+     [ q: qkv_dq | k: (N - qkv_dq) / 2 | v: (N - qkv_dq) / 2 ], q -> [M][qkv_dq], k -> [M][Dkv], v -> vt[m / seq_len][Dkv][ldvt].
+     0 = three equal thirds (N / 3 each).  Both widths must be multiples of 64 (whole heads). */
+  int32_t qkv_dq;
+  int32_t reserved1;
 } f3r_gemm_args;
 
 typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_split;
@@ -159,10 +164,11 @@ int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
  * LlamaDecoder's stacked [w1; w3] projection).  The library allocates nothing: the caller makes ONE allocation of the returned size
  * per encoder pass / decoder sample and every block of that pass reuses it (the intermediates of a block are dead when it ends).
  * offsets[0..4] (bytes, 256-byte aligned) = { LN output / attention output (lowp [tokens][D]),  q (lowp [tokens][D]),
- * k (lowp [tokens][D]),  V^T (lowp [n_seq][D][ldvt], ldvt = seq_len rounded up to 64: pad columns are never written, zero them once),
+ * k (lowp [tokens][kv_dim]),  V^T (lowp [n_seq][kv_dim][ldvt], ldvt = seq_len rounded up to 64: pad columns are never written, zero
+ * them once; kv_dim = D, or n_kv_heads * 64 with grouped-query attention),
  * MLP hidden (lowp [tokens][hidden]) }.  Returns 0 on bad arguments.
  */
-size_t f3r_block_workspace_bytes(int64_t tokens, int D, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
+size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_attn_fwd: O = softmax(scale * Q K^T) V, non-causal, head_dim 64, flash-style (never forms
@@ -205,6 +211,15 @@ typedef struct f3r_attn_args {
   float* st_ml;
   int32_t state_in;
   int32_t state_out;
+  /* Grouped-query attention (repeat_kv, components/llama.py:125-134,229-232): query head h reads K / V head h / kv_group; the K rows
+     and V^T planes then hold n_heads / kv_group heads.  0 or 1 = one K / V head per query head. */
+  int32_t kv_group;
+  /* Causal attention (F.scaled_dot_product_attention(..., is_causal=True), components/llama.py:239): key at sequence position j is
+     visible to the query at position i iff j <= i.  Positions are GLOBAL token indices: query row r of this launch sits at
+     q_pos0 + r, key row r of segment s at seg_pos0[s] + r (the view-sharded path attends over shards that start anywhere). */
+  int32_t causal;
+  int64_t q_pos0;
+  int64_t seg_pos0[F3R_MAX_SEG];
 } f3r_attn_args;
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);

@@ -31,6 +31,9 @@ CASES = {
     "tiny_hot_3x64": (dict(), [(64, 64)] * 3, 1, 0, 1234, "hot"),
     "tiny_llama_3x64": (dict(decoder_type="llama"), [(64, 64)] * 3, 1, 4, 31, "default"),
     "tiny_llama_seqids_b2": (dict(decoder_type="llama", random_image_idx_embedding=False, enc_depth=1, llama_layers=14), [(32, 48)] * 4, 2, 5, 3, "default"),
+    # grouped-query (4 query heads on 2 K/V heads) + causal LlamaDecoder (components/llama.py:195-198,229-239): not the released config
+    "tiny_llama_gqa_causal": (dict(decoder_type="llama", embed_dim=256, num_heads=4, llama_kv_heads=2, llama_causal=True, enc_depth=1,
+                                   llama_layers=12), [(48, 64)] * 3, 1, 7, 17, "default"),
     # the training-config pair ManyAR_PatchEmbed + landscape_only=True (configs/model/fast3r.yaml:55,77): images are STORED landscape
     # (48 x 64) and `true_shape` says which samples are portrait pictures: view 0 all landscape, view 1 all portrait, view 2 mixed
     "tiny_portrait_b2": (dict(enc_depth=1, patch_embed_cls="ManyAR_PatchEmbed", landscape_only=True), [(48, 64)] * 3, 2, 6, 11, "default"),

@@ -405,3 +405,76 @@ def test_attention_state_carried_across_launches(built_lib, dt):
     ops.attention(q.to(DEV), two, H, 0.125, segs[1:], state=state, state_in=True)
     assert torch.equal(one, two)
     assert_close(two.float(), _attn_ref(q, torch.cat(ks), torch.cat(vs), H, 0.125), 2 * lp_tol(dt), "state carry")
+
+
+# ------------------------------------------------------------------------------------------------ grouped-query / causal attention
+def _attn_ref_general(q, k, v, H, Hkv, scale, causal=False, q_pos0=0, k_pos=None):
+    """q (Tq, H*64), k / v (Tk, Hkv*64) -> fp64 softmax(q k^T scale [+ causal mask]) v with repeat_kv (llama.py:125-134)."""
+    Tq, Tk = q.shape[0], k.shape[0]
+    rep = H // Hkv
+    qh = q.double().reshape(Tq, H, 64).transpose(0, 1)
+    kh = k.double().reshape(Tk, Hkv, 64).transpose(0, 1).repeat_interleave(rep, dim=0)
+    vh = v.double().reshape(Tk, Hkv, 64).transpose(0, 1).repeat_interleave(rep, dim=0)
+    sc = (qh @ kh.transpose(1, 2)) * scale
+    if causal:
+        kp = torch.arange(Tk) if k_pos is None else k_pos
+        qp = q_pos0 + torch.arange(Tq)
+        sc = sc.masked_fill(kp[None, :] > qp[:, None], float("-inf"))
+    return (sc.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,H,Hkv", [(200, 4, 2), (640, 4, 1), (130, 6, 2)])
+def test_attention_grouped_query(built_lib, dt, T, H, Hkv):
+    q, k, v = rnd((T, H * 64), dt, 120), rnd((T, Hkv * 64), dt, 121), rnd((T, Hkv * 64), dt, 122)
+    o = torch.empty((T, H * 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, [(k.to(DEV), _vt_of(v, Hkv).to(DEV), T, 0, 0)], kv_group=H // Hkv)
+    assert_close(o.float(), _attn_ref_general(q, k, v, H, Hkv, 0.125), 2 * lp_tol(dt), "gqa")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,H,Hkv", [(64, 2, 2), (200, 2, 2), (700, 4, 2), (1000, 2, 1)])
+def test_attention_causal(built_lib, dt, T, H, Hkv):
+    """is_causal=True (llama.py:239): every tile left of the diagonal is fully visible, the diagonal tiles are masked per row, the tiles
+    to the right are masked whole; ragged last tile included."""
+    q, k, v = rnd((T, H * 64), dt, 130), rnd((T, Hkv * 64), dt, 131), rnd((T, Hkv * 64), dt, 132)
+    o = torch.empty((T, H * 64), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, [(k.to(DEV), _vt_of(v, Hkv).to(DEV), T, 0, 0)], kv_group=H // Hkv, causal=True)
+    assert_close(o.float(), _attn_ref_general(q, k, v, H, Hkv, 0.125, causal=True), 2 * lp_tol(dt), "causal")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_causal_over_shards(built_lib, dt):
+    """The view-sharded layout of causal attention: this rank's queries sit at global positions [300, 500); launch 1 attends over the
+    local shard (same positions) and parks the state, launch 2 over the two remote shards [0, 300) (all visible) and [500, 730) (all
+    hidden).  Must equal causal attention of those 200 query rows over the whole 730-token sequence."""
+    H, lens, pos = 2, [300, 200, 230], [0, 300, 500]
+    ks = [rnd((n, H * 64), dt, 140 + i) for i, n in enumerate(lens)]
+    vs = [rnd((n, H * 64), dt, 150 + i) for i, n in enumerate(lens)]
+    q = rnd((200, H * 64), dt, 160)
+    segs = [(kk.to(DEV), _vt_of(vv, H).to(DEV), n, 0, 0) for kk, vv, n in zip(ks, vs, lens)]
+    o = torch.empty((200, H * 64), dtype=dt, device=DEV)
+    state = ops.attention_state(200, H, DEV)
+    ops.attention(q.to(DEV), o, H, 0.125, [segs[1]], state=state, state_out=True, causal=True, q_pos0=300, seg_pos0=[300])
+    ops.attention(q.to(DEV), o, H, 0.125, [segs[0], segs[2]], state=state, state_in=True, causal=True, q_pos0=300, seg_pos0=[0, 500])
+    ref = _attn_ref_general(q, torch.cat(ks), torch.cat(vs), H, H, 0.125, causal=True, q_pos0=300)
+    assert_close(o.float(), ref, 2 * lp_tol(dt), "causal over shards")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,Hq,Hkv,K,sels", [(300, 4, 2, 128, [1]), (2304, 8, 4, 256, [1, 2, 3]), (77, 6, 2, 192, [1])])
+def test_gemm_qkv_grouped_query_split(built_lib, dt, M, Hq, Hkv, K, sels):
+    """QKV epilogue with unequal parts (f3r_gemm_args.qkv_dq): q -> [M][Hq*64], k -> [M][Hkv*64], v -> V^T [Hkv*64][ld]."""
+    Dq, Dkv = Hq * 64, Hkv * 64
+    a = rnd((M, K), dt, 170)
+    w = rnd((Dq + 2 * Dkv, K), dt, 171, K ** -0.5)
+    wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
+    ref = a.double() @ w.double().t()
+    for sel in sels:
+        q = torch.empty((M, Dq), dtype=dt, device=DEV)
+        k = torch.empty((M, Dkv), dtype=dt, device=DEV)
+        vt = torch.zeros((1, Dkv, ops.vt_ld(M)), dtype=dt, device=DEV)
+        ops.gemm_qkv(a.to(DEV), wp, None, q, k, vt, M, None, q_dim=Dq, kernel_sel=sel)
+        assert_close(q.float(), ref[:, :Dq], lp_tol(dt), f"q sel={sel}")
+        assert_close(k.float(), ref[:, Dq:Dq + Dkv], lp_tol(dt), f"k sel={sel}")
+        assert_close(vt[0, :, :M].float().cpu().t(), ref[:, Dq + Dkv:], lp_tol(dt), f"v^T sel={sel}")
