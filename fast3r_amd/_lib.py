@@ -67,7 +67,8 @@ SYMBOLS = {
     "f3r_version": (ctypes.c_int, []),
     "f3r_last_error_string": (ctypes.c_char_p, []),
     "f3r_sizeof": (ctypes.c_size_t, [ctypes.c_int]),
-    "f3r_patchify": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_patchify": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_interp_bilinear": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp] + [ctypes.c_int] * 9 + [_c_vp]),
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),

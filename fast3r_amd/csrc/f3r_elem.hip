@@ -35,6 +35,33 @@ __global__ void patchify_kernel(const float* __restrict__ img, uint16_t* __restr
   *(u32x4*)(out + patch * K + (int64_t)ck * 8) = o;
 }
 
+// Any patch size (DINOv2: 14): one thread = one PAIR of consecutive k of one patch row, scalar fp32 loads; k >= 3*ps*ps (the zero padding
+// up to the row stride ld, a multiple of 8 so the GEMM can take the rows) is written as zeros.
+template <class T>
+__global__ void patchify_any_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int B, int H, int W, int ps, int ld, int64_t n_pairs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int ppr = ld / 2;  // pairs per output row
+  const int64_t patch = i / ppr;
+  const int k0 = (int)(i % ppr) * 2;
+  const int w = W / ps, h = H / ps;
+  const int b = (int)(patch / ((int64_t)h * w));
+  const int pr = (int)(patch % ((int64_t)h * w));
+  const int py = pr / w, px = pr % w;
+  float v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = k0 + j;
+    v[j] = 0.f;
+    if (k < 3 * ps * ps) {
+      const int c = k / (ps * ps), r = k % (ps * ps);
+      const int dy = r / ps, dx = r % ps;
+      v[j] = img[(((int64_t)b * 3 + c) * H + (py * ps + dy)) * W + px * ps + dx];
+    }
+  }
+  *(uint32_t*)(out + patch * ld + k0) = pack2<T>(v[0], v[1]);
+}
+
 // ------------------------------------------------------------------------------------------ layernorm
 // one wave per row; D % 4 == 0; float4 loads; two-pass (mean, then centred variance) from registers when
 // D <= 2048 (8 float4 per lane), otherwise re-reads the row.
@@ -93,11 +120,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ upsample x2 (align_corners)
-// thread = 8 channels of one output pixel.  src = dst * (in-1)/(out_full-1), out_full = 2*in (F.interpolate
-// scale_factor=2, align_corners=True); the output may be cropped to (oh, ow).
+// thread = 8 channels of one output pixel.  src = dst * (in-1)/(out_full-1), out_full = 2*in for F.interpolate(scale_factor=2,
+// align_corners=True) -- or any other nominal size (f3r_interp_bilinear); the output may be cropped to (oh, ow).
 template <class T>
 __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ in_lo, uint16_t* __restrict__ out,
-                                  uint16_t* __restrict__ out_lo, int B, int h, int w, int C, int oh, int ow, int64_t n_items) {
+                                  uint16_t* __restrict__ out_lo, int B, int h, int w, int C, int oh, int ow, int full_h, int full_w,
+                                  int64_t n_items) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const int cv = C / 8;
@@ -106,8 +134,10 @@ __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_
   const int ox = (int)(pix % ow);
   const int oy = (int)((pix / ow) % oh);
   const int b = (int)(pix / ((int64_t)ow * oh));
-  const float sy = (h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
-  const float sx = (w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  // align_corners=True: src = dst * (in - 1) / (full_out - 1) (torch's area_pixel_compute_scale), full_out = the interpolation's own
+  // output size (2 * in for the x2 upsamples, in * patch_size / 8 for the head's Interpolate); (oh, ow) <= it is the cropped extent
+  const float sy = (full_h > 1) ? (float)(h - 1) / (float)(full_h - 1) : 0.f;
+  const float sx = (full_w > 1) ? (float)(w - 1) / (float)(full_w - 1) : 0.f;
   const float fy = sy * (float)oy, fx = sx * (float)ox;
   int y0 = (int)fy, x0 = (int)fx;
   if (y0 > h - 1) y0 = h - 1;
@@ -293,18 +323,29 @@ __global__ void rows_add_kernel(float* __restrict__ x, const float* __restrict__
 
 #define F3R_DTYPE_OK(dt) F3R_REQUIRE((dt) == F3R_F16 || (dt) == F3R_BF16, "bad dtype %d", (dt))
 
-extern "C" int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int dtype, f3r_stream_t stream) {
+extern "C" int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int ld_out, int dtype, f3r_stream_t stream) {
   F3R_REQUIRE(img && out && al16(img) && al16(out), "f3r_patchify: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
-  F3R_REQUIRE(ps > 0 && ps % 8 == 0, "f3r_patchify: patch size %d must be a multiple of 8", ps);
-  F3R_REQUIRE(H % ps == 0 && W % ps == 0 && batch >= 0, "f3r_patchify: H/W (%d,%d) not multiples of the patch size %d", H, W, ps);
-  const int64_t n = (int64_t)batch * (H / ps) * (W / ps) * (3 * ps * ps / 8);
-  if (n == 0) return F3R_OK;
+  F3R_REQUIRE(ps > 0 && H % ps == 0 && W % ps == 0 && batch >= 0, "f3r_patchify: H/W (%d,%d) not multiples of the patch size %d", H, W, ps);
+  const int K = 3 * ps * ps;
+  if (ld_out == 0) ld_out = K;
+  F3R_REQUIRE(ld_out >= K && ld_out % 8 == 0, "f3r_patchify: row stride %d must be a multiple of 8 >= 3*ps*ps = %d", ld_out, K);
+  const int64_t patches = (int64_t)batch * (H / ps) * (W / ps);
+  if (patches == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == F3R_F16)
-    hipLaunchKernelGGL(patchify_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
-  else
-    hipLaunchKernelGGL(patchify_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
+  if (ps % 8 == 0 && ld_out == K) {  // 16 bytes per lane
+    const int64_t n = patches * (K / 8);
+    if (dtype == F3R_F16)
+      hipLaunchKernelGGL(patchify_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
+    else
+      hipLaunchKernelGGL(patchify_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, n);
+  } else {
+    const int64_t n = patches * (ld_out / 2);
+    if (dtype == F3R_F16)
+      hipLaunchKernelGGL(patchify_any_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, ld_out, n);
+    else
+      hipLaunchKernelGGL(patchify_any_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, img, (uint16_t*)out, batch, H, W, ps, ld_out, n);
+  }
   return f3r_check_launch("f3r_patchify");
 }
 
@@ -330,22 +371,27 @@ extern "C" int f3r_layernorm(const float* x, const float* gamma, const float* be
   return f3r_check_launch("f3r_layernorm");
 }
 
-extern "C" int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int out_h,
-                              int out_w, int dtype, f3r_stream_t stream) {
-  F3R_REQUIRE(in && out && al16(in) && al16(out) && al16(in_lo) && al16(out_lo), "f3r_upsample2x: null/misaligned pointer");
+extern "C" int f3r_interp_bilinear(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int full_h,
+                                   int full_w, int out_h, int out_w, int dtype, f3r_stream_t stream) {
+  F3R_REQUIRE(in && out && al16(in) && al16(out) && al16(in_lo) && al16(out_lo), "f3r_interp_bilinear: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
-  F3R_REQUIRE(C > 0 && C % 8 == 0, "f3r_upsample2x: C %d must be a multiple of 8", C);
-  F3R_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= 2 * h && out_w <= 2 * w, "f3r_upsample2x: bad sizes");
+  F3R_REQUIRE(C > 0 && C % 8 == 0, "f3r_interp_bilinear: C %d must be a multiple of 8", C);
+  F3R_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= full_h && out_w <= full_w, "f3r_interp_bilinear: bad sizes");
   const int64_t n = (int64_t)batch * out_h * out_w * (C / 8);
   if (n <= 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == F3R_F16)
     hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
-                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, n);
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n);
   else
     hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
-                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, n);
-  return f3r_check_launch("f3r_upsample2x");
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n);
+  return f3r_check_launch("f3r_interp_bilinear");
+}
+
+extern "C" int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int out_h,
+                              int out_w, int dtype, f3r_stream_t stream) {
+  return f3r_interp_bilinear(in, in_lo, out, out_lo, batch, h, w, C, 2 * h, 2 * w, out_h, out_w, dtype, stream);
 }
 
 extern "C" int f3r_dpt_final(const void* x, const void* x_lo, const float* w, const float* b, int n_out, float* pts3d, float* conf,

@@ -89,6 +89,59 @@ class CroCoEncoder(_Params):
         self.enc_norm = nn.LayerNorm(embed_dim, eps=1e-6)
 
 
+class _LayerScale(_Params):
+    def __init__(self, dim, init_values=1.0):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class _DinoBlock(_Params):
+    """DINOv2 `Block` (dinov2/layers/block.py): x + ls1(attn(norm1(x))); x + ls2(mlp(norm2(x)))."""
+
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, qkv_bias=True)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.ls2 = _LayerScale(dim)
+
+
+class _DinoViT(_Params):
+    """Parameter layout of DINOv2's `DinoVisionTransformer` as torch.hub's `dinov2_vitl14` builds it (facebookresearch/dinov2
+    models/vision_transformer.py: img_size 518, patch 14, no register tokens, LayerScale, MLP ffn, block_chunks = 0): the keys under
+    `encoder.model.` are the hub checkpoint's own."""
+
+    def __init__(self, embed_dim, depth, num_heads, mlp_ratio, patch_size, pos_grid):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.patch_size, self.pos_grid = embed_dim, num_heads, patch_size, pos_grid
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 1 + pos_grid * pos_grid, embed_dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))  # in the checkpoint; unused at inference
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        self.blocks = nn.ModuleList([_DinoBlock(embed_dim, mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+
+
+class DinoEncoder(_Params):
+    """fast3r.py:561-651: DINOv2 ViT-L/14 patch tokens (`forward_features(...)['x_norm_patchtokens']`), portrait samples encoded upright
+    and their tokens put back in the stored (landscape) order.  The reference builds the backbone with torch.hub.load (network); here
+    the same architecture is built locally (random init; a checkpoint's `encoder.model.*` keys load as they are).  The size arguments
+    exist only so that tests can build a small one: the reference class is always ViT-L/14."""
+
+    def __init__(self, patch_size=14, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, pos_grid=37, **kwargs):
+        super().__init__()
+        assert patch_size == 14, "DINOv2 model must have patch size 14"  # fast3r.py:570
+        if embed_dim // num_heads != 64:
+            raise ValueError("fast3r_amd kernels are built for head_dim 64")
+        self.patch_size, self.embed_dim, self.num_heads, self.depth = patch_size, embed_dim, num_heads, depth
+        self.patch_embed_cls = "dino"
+        self.model = _DinoViT(embed_dim, depth, num_heads, mlp_ratio, patch_size, pos_grid)
+
+
 def sincos_1d_table(embed_dim, n_pos):
     """get_1d_sincos_pos_embed_from_grid (croco/models/pos_embed.py:58-76): [sin | cos], float64 -> float32."""
     omega = np.arange(embed_dim // 2, dtype=float)
@@ -304,6 +357,22 @@ def _pack_block(blk: _Block, lp, split=False):
     return p
 
 
+def _pack_dino_block(blk: _DinoBlock, lp, split=False):
+    """DINOv2 block -> the packed fields of a ViT block.  LayerScale is folded into the projection that precedes it:
+    gamma * (W a + b) = (gamma[:, None] * W) a + gamma * b -- exact in real arithmetic, no epilogue change."""
+    p = _PackedBlock()
+    p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
+    p.eps = blk.norm1.eps
+    g1, g2 = blk.ls1.gamma.detach().float(), blk.ls2.gamma.detach().float()
+    p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp, split), _f32(blk.attn.qkv.bias)
+    p.proj_w = ops.pack_linear_weight(g1[:, None] * blk.attn.proj.weight.detach().float(), lp, split)
+    p.proj_b = (g1 * blk.attn.proj.bias.detach().float()).contiguous()
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, split), _f32(blk.mlp.fc1.bias)
+    p.fc2_w = ops.pack_linear_weight(g2[:, None] * blk.mlp.fc2.weight.detach().float(), lp, split)
+    p.fc2_b = (g2 * blk.mlp.fc2.bias.detach().float()).contiguous()
+    return p
+
+
 def _pack_llama_block(blk: _LlamaBlock, n_heads, lp, split=False, n_kv_heads=None, causal=False):
     """LlamaDecoder layer -> the same packed fields as a ViT block: [wq; wk; wv] as one QKV matrix (q / k rows permuted per head, see
     _ROPE_PERM), [w1; w3] stacked for one up-projection GEMM, no biases, RMSNorm weights."""
@@ -468,7 +537,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             a.pop("encoder_type")
             self.encoder = CroCoEncoder(**a)
         elif encoder_args["encoder_type"] == "dino_v2":
-            raise ValueError("fast3r_amd: encoder_type 'dino_v2' is outside the MI355X hot path (SURVEY.md section 2.1 #2)")
+            a = deepcopy(dict(encoder_args))
+            a.pop("encoder_type")
+            self.encoder = DinoEncoder(**a)  # fast3r.py:80-83
         else:
             raise ValueError(f"Unsupported encoder type: {encoder_args['encoder_type']}")
 
@@ -600,10 +671,18 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         enc, dec = self.encoder, self.decoder
         hp = self.precision == "high"
         pk = dict(key=key)
-        pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
-        pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
-        pk["enc"] = [_pack_block(b, lp, hp) for b in enc.enc_blocks]
-        pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
+        if isinstance(enc, DinoEncoder):
+            vit = enc.model
+            pk["pe_w"] = ops.pack_linear_weight(vit.patch_embed.proj.weight.detach().float(), lp, hp)  # (D, 3*14*14 = 588) -> Kpad 640
+            pk["pe_b"] = _f32(vit.patch_embed.proj.bias)
+            pk["enc"] = [_pack_dino_block(b, lp, hp) for b in vit.blocks]
+            pk["enc_norm"] = (_f32(vit.norm.weight), _f32(vit.norm.bias), vit.norm.eps)
+            pk["dino_pos"] = {}  # (h, w) -> interpolated position rows, filled on demand (_dino_pos)
+        else:
+            pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
+            pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
+            pk["enc"] = [_pack_block(b, lp, hp) for b in enc.enc_blocks]
+            pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
         if isinstance(dec, LlamaDecoder):
@@ -686,9 +765,71 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             return ops.cast_lp(x_f32, self.compute_dtype, want_lo=True)
         return ops.cast_lp(x_f32, self.compute_dtype), None
 
+    def _dino_pos(self, pk, h, w, dev):
+        """DINOv2 `interpolate_pos_encoding` (models/vision_transformer.py) for an h x w token grid -> (cls row + pos[0] (D,), patch rows
+        (h*w, D)) fp32, cached per grid.  Parameter preprocessing on the host side of the boundary (like the RoPE tables): the trained
+        (pos_grid x pos_grid) table is resized bicubically with the hub models' settings (interpolate_offset 0.1, no antialias)."""
+        key = (h, w)
+        if key not in pk["dino_pos"]:
+            vit = self.encoder.model
+            pe = vit.pos_embed.detach().float().to(dev)
+            M, D = vit.pos_grid, vit.embed_dim
+            patch = pe[:, 1:]
+            if not (h * w == M * M and h == w):
+                patch = torch.nn.functional.interpolate(patch.reshape(1, M, M, D).permute(0, 3, 1, 2), mode="bicubic", antialias=False,
+                                                        scale_factor=(float(h + 0.1) / M, float(w + 0.1) / M))
+                assert tuple(patch.shape[-2:]) == (h, w)
+                patch = patch.permute(0, 2, 3, 1).reshape(1, h * w, D)
+            cls_row = (vit.cls_token.detach().float().to(dev)[0, 0] + pe[0, 0]).contiguous()
+            pk["dino_pos"][key] = (cls_row, patch[0].contiguous())
+        return pk["dino_pos"][key]
+
+    def _encode_dino(self, imgs, pk):
+        """DINOv2 forward_features -> x_norm_patchtokens (DinoEncoder._process_images, fast3r.py:636-651) for a batch of same-size,
+        upright images: patch embedding (k = s = 14) + [cls] + resized position table, the ViT blocks (no RoPE; LayerScale folded into
+        the packed weights), final LayerNorm, patch tokens only.  Same return convention as _encode."""
+        lp = self.compute_dtype
+        hp = self.precision == "high"
+        sp = "w2" if hp else None
+        vit = self.encoder.model
+        NV, _, H, W = imgs.shape
+        ps, D = vit.patch_size, vit.embed_dim
+        assert H % ps == 0 and W % ps == 0, f"Input image size ({H}, {W}) is not a multiple of the patch size ({ps})"
+        h, w = H // ps, W // ps
+        P = h * w
+        cls_row, pos_rows = self._dino_pos(pk, h, w, imgs.device)
+        out = torch.empty((NV * P, D), dtype=lp, device=imgs.device)
+        out_lo = torch.empty_like(out) if hp else None
+        kpad = pk["pe_w"].shape[1] // (2 if hp else 1)
+        step = max(1, self.max_parallel_views_for_encoder)
+        for v0 in range(0, NV, step):
+            v1 = min(NV, v0 + step)
+            n = v1 - v0
+            a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp, ld_out=kpad)
+            tok, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], res_f32=pos_rows.repeat(n, 1), want_f32=True, split=sp)
+            x = torch.empty((n, 1 + P, D), dtype=torch.float32, device=imgs.device)  # [cls | patches] per image
+            x[:, 0] = cls_row
+            x[:, 1:] = tok.view(n, P, D)
+            x = x.view(n * (1 + P), D)
+            ws = self._block_ws(pk["enc"][0], x.shape[0], D, n, 1 + P, imgs.device)
+            for pb in pk["enc"]:
+                self._block(x, pb, vit.num_heads, 64 ** -0.5, 1 + P, n, None, ws=ws)
+            w_, b_, eps = pk["enc_norm"]
+            if hp:
+                _, y = ops.layernorm(x, w_, b_, eps, lp, want_lp=False, want_f32=True)
+                hi, lo = ops.cast_lp(y, lp, want_lo=True)
+                out[v0 * P:v1 * P].view(n, P, D).copy_(hi.view(n, 1 + P, D)[:, 1:])
+                out_lo[v0 * P:v1 * P].view(n, P, D).copy_(lo.view(n, 1 + P, D)[:, 1:])
+            else:
+                y, _ = ops.layernorm(x, w_, b_, eps, lp)
+                out[v0 * P:v1 * P].view(n, P, D).copy_(y.view(n, 1 + P, D)[:, 1:])
+        return out, out_lo, P, (h, w)
+
     def _encode(self, imgs, pk):
         """CroCoEncoder.forward (fast3r.py:549-559) for a batch of same-size images -> enc_norm output [NV*P][D] as (lowp, low plane or
         None).  The high plane alone feeds decoder_embed; both planes are hook 0 of the heads in "high" precision."""
+        if isinstance(self.encoder, DinoEncoder):
+            return self._encode_dino(imgs, pk)
         lp = self.compute_dtype
         hp = self.precision == "high"
         sp = "w2" if hp else None
@@ -869,8 +1010,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         p1 = fusion(hk.ref[0], p2, ls[0])
         del ls, p4, p3, p2
         y = conv(p1, hk.h0_w, bias=hk.h0_b)["x"]                                        # head[0]
-        assert hk.patch_size == 16, "head Interpolate scale = patch_size / 8 (dpt_block.py:374): only x2 is fused"
-        u = ops.upsample2x(y[0], x_lo=y[1], want_lo=hp)                                 # head[1]
+        # head[1]: Interpolate(scale_factor = patch_size / 8, bilinear, align_corners=True) (dpt_block.py:374): x2 for patch 16, x1.75 for 14
+        full = (y[0].shape[1] * hk.patch_size // 8, y[0].shape[2] * hk.patch_size // 8)
+        u = ops.interp_bilinear(y[0], full, x_lo=y[1], want_lo=hp)
         y = conv(u if hp else (u, None), hk.h2_w, bias=hk.h2_b, act="relu")["x"]        # head[2], head[3]
         return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1], depth_mode=tuple(hk.depth_mode))  # head[4] + postprocess
 
@@ -904,7 +1046,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         back.  With PatchEmbedDust3R / landscape_only=False (what the inference loaders set, utils/checkpoint_utils.py:37-38) neither
         happens and `true_shape` must be identical for all samples of a view (misc.py:69).  Returns, per view, `enc_swap` (B bools),
         `head_hw` (B (H, W) pairs: the image size the head predicts at) and `head_swap` (B bools)."""
-        many_ar = self.encoder.patch_embed_cls == "ManyAR_PatchEmbed"
+        many_ar = self.encoder.patch_embed_cls in ("ManyAR_PatchEmbed", "dino")  # DinoEncoder.forward also encodes portraits upright (:592-599)
         plan, any_p = [], False
         for v in views:
             img = v["img"]
@@ -912,7 +1054,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             ts = v.get("true_shape", None)
             ts = torch.tensor([[H, W]] * B) if ts is None else torch.as_tensor(ts).cpu().reshape(B, 2).long()
             portrait = (ts[:, 1] < ts[:, 0]).tolist()
-            if many_ar:
+            if self.encoder.patch_embed_cls == "ManyAR_PatchEmbed":
                 assert W >= H, f"img should be in landscape mode, but got {W=} {H=}"  # patch_embed.py:62
             enc_swap = [bool(p) and many_ar for p in portrait]
             if self.landscape_only:  # wrapper_yes: by definition the batch is stored in landscape mode, W >= H (misc.py:77-80)
@@ -985,12 +1127,17 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     grids_i.append((hh // ps, ww // ps))
                 head_grid.append(grids_i)
                 head_swap.append(list(pl["head_swap"]))
+            untranspose = isinstance(enc, DinoEncoder)  # its portrait tokens go back to the stored (landscape) order (fast3r.py:601-622)
             for _, items in groups.items():
-                f, flo, P, _ = self._encode(torch.stack([im for _, _, im in items]).contiguous(), pk)
+                f, flo, P, (gh_, gw_) = self._encode(torch.stack([im for _, _, im in items]).contiguous(), pk)
                 f = f.view(len(items), P, -1)
                 flo = None if flo is None else flo.view(len(items), P, -1)
                 for j, (i, b, _) in enumerate(items):
-                    feats[i][b] = (f[j], None if flo is None else flo[j])
+                    fj, fl = f[j], (None if flo is None else flo[j])
+                    if untranspose and plan["views"][v_lo + i]["enc_swap"][b]:
+                        fj = fj.view(gh_, gw_, -1).transpose(0, 1).reshape(P, -1)
+                        fl = None if fl is None else fl.view(gh_, gw_, -1).transpose(0, 1).reshape(P, -1)
+                    feats[i][b] = (fj, fl)
         if profiling:
             torch.cuda.synchronize()
             prof["encode_images_time"] = time.time() - t0

@@ -80,14 +80,15 @@ def rope_tables(n_pos: int, base: float, device, half_dim: int = 32):
 
 
 # ----------------------------------------------------------------------------------------- kernels
-def patchify(img: torch.Tensor, ps: int, lp: torch.dtype) -> torch.Tensor:
-    """(B,3,H,W) fp32 -> [B*h*w][3*ps*ps] lowp rows for the patch-embed GEMM."""
+def patchify(img: torch.Tensor, ps: int, lp: torch.dtype, ld_out: int = 0) -> torch.Tensor:
+    """(B,3,H,W) fp32 -> [B*h*w][ld_out] lowp rows for the patch-embed GEMM; ld_out = 0: 3*ps*ps, else a zero-padded row stride."""
     require_gpu(img, "img")
     assert img.dtype == torch.float32 and img.is_contiguous()
     B, C, H, W = img.shape
     assert C == 3
-    out = torch.empty((B * (H // ps) * (W // ps), 3 * ps * ps), dtype=lp, device=img.device)
-    check(_lib.lib().f3r_patchify(ptr(img), ptr(out), B, H, W, ps, dtype_id(lp), stream_ptr()), "f3r_patchify")
+    ld = ld_out if ld_out else 3 * ps * ps
+    out = torch.empty((B * (H // ps) * (W // ps), ld), dtype=lp, device=img.device)
+    check(_lib.lib().f3r_patchify(ptr(img), ptr(out), B, H, W, ps, ld_out, dtype_id(lp), stream_ptr()), "f3r_patchify")
     return out
 
 
@@ -381,6 +382,18 @@ def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
 
 DEPTH_MODES = {"exp": 0, "linear": 1, "square": 2}
 CONF_MODES = {"exp": 0, "sigmoid": 1}
+
+
+def interp_bilinear(x, full_hw, x_lo=None, want_lo=False):
+    """F.interpolate(x, size=full_hw, mode="bilinear", align_corners=True) on NHWC lowp (+ low planes), any output size."""
+    require_gpu(x, "x")
+    B, h, w, C = x.shape
+    oh, ow = full_hw
+    out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
+    out_lo = torch.empty_like(out) if want_lo else None
+    check(_lib.lib().f3r_interp_bilinear(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, oh, ow, dtype_id(x.dtype), stream_ptr()),
+          "f3r_interp_bilinear")
+    return (out, out_lo) if want_lo else out
 
 
 def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.inf)):

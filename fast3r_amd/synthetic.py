@@ -45,6 +45,8 @@ def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64
                         mlp_ratio=4.0, qkv_bias=True, drop=0.0, attn_drop=0.0,
                         attn_implementation=attn_implementation,
                         attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)
+    if patch_embed_cls == "dino":  # DinoEncoder (fast3r.py:561-651) scaled down: the reference class is always ViT-L/14 with a 37 x 37 position grid
+        encoder_args = dict(encoder_type="dino_v2", patch_size=14, embed_dim=embed_dim, depth=enc_depth, num_heads=num_heads, mlp_ratio=4, pos_grid=5)
     if decoder_type == "llama":
         # configs/experiment/llama_dec/llama_dec.yaml:52-66 merged over configs/model/fast3r.yaml: the base keys stay in the dict (they
         # disappear into LlamaDecoder's **kwargs) and `depth` -- not n_layers -- is what the heads read (fast3r.py:137-148)
@@ -54,7 +56,7 @@ def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64
                             depth_init=True, depth=dec_depth, num_heads=num_heads, mlp_ratio=4.0, qkv_bias=True)
     head_args = dict(head_type="dpt", output_mode="pts3d", landscape_only=landscape_only,
                      depth_mode=["exp", -float("inf"), float("inf")], conf_mode=["exp", 1, float("inf")],
-                     patch_size=16, with_local_head=with_local_head)
+                     patch_size=14 if patch_embed_cls == "dino" else 16, with_local_head=with_local_head)
     return encoder_args, decoder_args, head_args
 
 
@@ -70,7 +72,9 @@ def synth_tensor(key: str, shape, seed: int = 0, dist: str = "default") -> torch
     """
     g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
     shape = tuple(shape)
-    is_norm = ".norm" in key or key.endswith("_norm.weight") or key.endswith("_norm.bias")
+    is_norm = ".norm" in key or key.endswith("_norm.weight") or key.endswith("_norm.bias") or key.endswith(".gamma")  # LayerScale ~ 1 + noise
+    if key.endswith("pos_embed") or key.endswith("cls_token"):  # DINOv2 position table / class token: O(1) so that they matter
+        return 0.5 * torch.randn(shape, generator=g)
     if is_norm:
         if key.endswith("weight"):
             return 1.0 + 0.1 * torch.randn(shape, generator=g)

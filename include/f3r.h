@@ -55,10 +55,12 @@ size_t f3r_sizeof(int what);
 /* ---------------------------------------------------------------------------------------------
  * f3r_patchify: fp32 NCHW image -> lowp im2col rows for the k=s=ps patch-embedding convolution.
  * Replaces the input side of PatchEmbedDust3R.forward's Conv2d (fast3r/dust3r/patch_embed.py:24-38,
- * fast3r/croco/models/blocks.py:412-415).  out[(b*h+py)*w+px][c*ps*ps+dy*ps+dx] = img[b][c][py*ps+dy][px*ps+dx]
- * (the Conv2d weight's own (c,dy,dx) order, so weight.view(D, 3*ps*ps) is the GEMM operand).
+ * fast3r/croco/models/blocks.py:412-415) and of DINOv2's PatchEmbed (DinoEncoder, fast3r/models/fast3r.py:561-651, ps = 14).
+ * out[(b*h+py)*w+px][c*ps*ps+dy*ps+dx] = img[b][c][py*ps+dy][px*ps+dx] (the Conv2d weight's own (c,dy,dx) order, so
+ * weight.view(D, 3*ps*ps) is the GEMM operand).  ld_out = row stride of `out` in elements (0 = 3*ps*ps; a multiple of 8;
+ * columns >= 3*ps*ps are written as zeros: 3*14*14 = 588 is padded to 640 this way).
  */
-int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int dtype, f3r_stream_t stream);
+int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, int ld_out, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_layernorm: rows of fp32 -> normalised lowp (GEMM operand) and/or fp32.
@@ -234,6 +236,11 @@ int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
  */
 int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int out_h, int out_w,
                    int dtype, f3r_stream_t stream);
+/* f3r_interp_bilinear: the same kernel for any nominal output size (full_h, full_w) >= (out_h, out_w): F.interpolate(size or
+ * scale_factor, mode="bilinear", align_corners=True), src = dst * (in - 1) / (full - 1).  The head's Interpolate(scale_factor =
+ * patch_size / 8) (dpt_block.py:374) is x2 for patch 16 and x1.75 for DINOv2's patch 14. */
+int f3r_interp_bilinear(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int full_h, int full_w,
+                        int out_h, int out_w, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_dpt_final: last 1x1 conv (Cin -> n_out) fused with postprocess.

@@ -46,7 +46,7 @@ def test_argument_errors_are_codes_not_crashes(built_lib):
     a.q, a.o, a.n_heads, a.batch, a.tq, a.n_seg = 0x1000, 0x2000, 2, 1, 64, 9
     assert built_lib.f3r_attn_fwd(ctypes.byref(a), None) == -1
     assert b"n_seg" in built_lib.f3r_last_error_string()
-    assert built_lib.f3r_patchify(0x1000, 0x2000, 1, 30, 32, 16, 0, None) == -1  # H not a multiple of the patch size
+    assert built_lib.f3r_patchify(0x1000, 0x2000, 1, 30, 32, 16, 0, 0, None) == -1  # H not a multiple of the patch size
     assert built_lib.f3r_layernorm(0x1000, 0x1000, None, 0x1000, None, 4, 30, 1e-6, 0, 0, None) == -1  # D % 4
     with pytest.raises(ValueError):
         _lib.check(-1, "x")

@@ -478,3 +478,17 @@ def test_gemm_qkv_grouped_query_split(built_lib, dt, M, Hq, Hkv, K, sels):
         assert_close(q.float(), ref[:, :Dq], lp_tol(dt), f"q sel={sel}")
         assert_close(k.float(), ref[:, Dq:Dq + Dkv], lp_tol(dt), f"k sel={sel}")
         assert_close(vt[0, :, :M].float().cpu().t(), ref[:, Dq + Dkv:], lp_tol(dt), f"v^T sel={sel}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_patchify_any_patch_size_and_general_bilinear(built_lib, dt):
+    """DINOv2's patch 14: im2col rows zero-padded to a row stride that is a multiple of 8; the head's Interpolate(scale_factor=14/8)."""
+    img = torch.rand(2, 3, 28, 42) * 2 - 1
+    got = ops.patchify(img.to(DEV), 14, dt, ld_out=640).cpu()
+    ref = F.unfold(img, kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588).to(dt)
+    assert got.shape == (2 * 2 * 3, 640) and torch.equal(got[:, :588], ref) and float(got[:, 588:].abs().sum()) == 0.0
+    x = rnd((2, 16, 24, 64), dt, 7)
+    up = ops.interp_bilinear(x.to(DEV), (28, 42))
+    want = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=1.75, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert up.shape == want.shape
+    assert_close(up.float(), want, lp_tol(dt), "bilinear x1.75")
