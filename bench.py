@@ -181,8 +181,10 @@ def main():
     placeholder = {"img": views[lo]["img"]}
     views = [v if v is not None else placeholder for v in views]  # never read outside [lo, hi)
 
-    def measure(dtype_name, precision):
+    def measure(dtype_name, precision, steps=None, warmup=None):
         """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         lp = torch.float16 if dtype_name == "fp16" else torch.bfloat16
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
         model.load_state_dict(sd, strict=True)
@@ -196,12 +198,12 @@ def main():
                 torch.manual_seed(1234)
                 return model(views)
         with torch.no_grad():
-            for _ in range(args.warmup):
+            for _ in range(warmup):
                 step_fn()
             ops.ATTN_TIMER = []
             barrier()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 step_fn()
             barrier()
             dt = time.perf_counter() - t0
@@ -214,8 +216,8 @@ def main():
         avg_ms = sum(ms for ms, _ in fus) / len(fus)
         achieved = big / (avg_ms * 1e-3) / 1e12
         prec = "" if precision == "fast" else "; split-precision GEMM operands (weights hi+lo in the transformer, both operands hi+lo in the heads)"
-        e2e = None if args.fusion_only else flops_forward(V) / (dt / args.steps) / 1e12 / world
-        res = {"value": V / (dt / args.steps), "ms_per_step": dt / args.steps * 1e3, "dtype": dtype_name, "precision": precision,
+        e2e = None if args.fusion_only else flops_forward(V) / (dt / steps) / 1e12 / world
+        res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
                "roofline": {"bound": "mfma", "kernel": "attn_kernel (fusion self-attention, one launch per fusion layer per rank)",
                             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
@@ -236,7 +238,8 @@ def main():
     # The same workload in the other operand format, measured in the same process: the default (fp16 operands, precision "high") is the
     # format that meets the 1e-3 parity bar on the stress fixture; bf16 / "fast" is the round-1 headline format (parity 2e-2 there).
     alt_fmt = ("bf16", "fast") if (args.dtype, args.precision) != ("bf16", "fast") else ("fp16", "high")
-    alt_res = None if args.no_alt else measure(*alt_fmt)
+    # (bounded: at most 3 timed steps after at most 1 warm-up, whatever --steps / --warmup ask of the main measurement)
+    alt_res = None if args.no_alt else measure(*alt_fmt, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
 
     if rank == 0:
         out = {
@@ -247,12 +250,12 @@ def main():
             "config": {"workload": workload, "views": V, "views_per_gpu": views_per_gpu,
                        "tokens": V * 1024, "image": "512x512", "parallelism": f"view-sharded x{world}, K/V all-gather per fusion layer" if world > 1 else "single GPU",
                        "operands": main_res["operands"]},
-            "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), pmc=load_pmc()),
+            "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), pmc=load_pmc(main_res["dtype"])),
         }
         if "parity" in main_res:
             out["parity"] = main_res["parity"]
         if alt_res is not None:
-            out["alt_format"] = {k: alt_res[k] for k in ("dtype", "precision", "value", "ms_per_step", "operands") if k in alt_res}
+            out["alt_format"] = {k: alt_res[k] for k in ("dtype", "precision", "value", "ms_per_step", "steps", "warmup", "operands") if k in alt_res}
             out["alt_format"]["roofline"] = {k: alt_res["roofline"][k] for k in ("achieved", "frac", "avg_launch_ms", "e2e")}
             if "parity" in alt_res:
                 out["alt_format"]["parity"] = alt_res["parity"]
@@ -318,14 +321,16 @@ def load_traffic(V, world):
     return out
 
 
-def load_pmc():
+def load_pmc(dtype_name="fp16"):
     """Matrix-pipe utilisation in cycles + effective clock of the same kernel from the newest committed rocprofv3 PMC pass
     (profiles/r*_attn_mfma_util.json, tools/pmc_mfma_util.sh): `frac` above is this times clock / 2.4 GHz."""
     try:
         import glob
         cands = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_attn_mfma_util.json")))
         d = json.load(open(cands[-1]))
+        d = d.get("formats", {}).get(dtype_name, d)  # round 2+: one entry per operand format
         return {"source": f"profiles/{os.path.basename(cands[-1])} (rocprofv3 --pmc, not measured in this run)", "shape": "T=%d" % (1024 * d["views"]),
+                "operands": dtype_name if "avg_dispatch_ms" in d else "bf16",
                 "mfma_util_cycles": d["mfma_util_cycles"], "mfma_util_useful_cycles": d["mfma_util_useful_cycles"],
                 "effective_clock_ghz": d["effective_clock_ghz"]}
     except Exception:

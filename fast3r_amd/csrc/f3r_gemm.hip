@@ -345,6 +345,9 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE((!a.out_lp_lo || (a.out_lp && al8(a.out_lp_lo))) && (!a.out_relu || (al8(a.out_relu) && a.ldo_lp % 4 == 0 && a.ldo_lp >= a.N)) &&
                 (!a.out_relu_lo || (a.out_relu && al8(a.out_relu_lo))), "f3r_gemm: out_lp_lo / out_relu alignment");
     F3R_REQUIRE(!a.rowadd || (al16(a.rowadd) && a.rowadd_div > 0), "f3r_gemm: rowadd alignment/div");
+    const int64_t ld_max = 1ll << 26;  // the epilogues address a row as 32-bit byte offsets: 15 rows * ld * 4 B < 2^32
+    F3R_REQUIRE((!a.out_f32 || a.ldo_f32 < ld_max) && (!a.out_lp || a.ldo_lp < ld_max) && (!a.res_f32 || (a.ldr_f32 >= 0 && a.ldr_f32 < ld_max)) &&
+                (!a.res_lp || (a.ldr_lp >= 0 && a.ldr_lp < ld_max)) && (!a.res_lp2 || (a.ldr_lp2 >= 0 && a.ldr_lp2 < ld_max)), "f3r_gemm: row strides must be < 2^26 elements");
     F3R_REQUIRE(!a.bias || al16(a.bias), "f3r_gemm: bias alignment");
   } else if (a.epi == F3R_EPI_QKV) {
     const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;

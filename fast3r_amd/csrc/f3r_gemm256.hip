@@ -58,6 +58,9 @@ struct IC {
 // LAB (tools/lab builds only, -DF3R_GEMM_LAB; 0 in the product): ablation / alternative bits measured by tools/kernel_bench.py --what lab
 //   1 no LDS-DMA in the loop   2 no fragment reads in the loop   4 no MFMAs   8 no vmcnt wait   16 no s_setprio
 //   32 buffer_load ... lds through a buffer descriptor instead of global_load_lds   64 no sched_barrier pinning of the load section
+//   256 / 512 de-phased start: the first round of workgroups starts (wg/8) % 2 resp. % 4 halves / quarters of a tile time late, so the
+//   epilogue store bursts of the CUs of an XCD no longer coincide
+//   128 s_memtime stamps of wave 0 (entry, main loop start, main loop end, epilogue issued, stores retired) -> (uint64*)p.rope_cos [wg][5]
 // (1, 2, 4, 8 compute garbage by construction: timing only)
 template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0>
 __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, int64_t m0, int n0) {
@@ -67,6 +70,21 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
   const int fr = lane & 15, fg = lane >> 4;
+  // PAIRED (every role but QKV, whose RoPE needs columns c and c + 16 in one lane): weight rows are handed to the MFMA so that a lane
+  // owns 8 consecutive output columns (GemmFragLayout in f3r_gemm_epi.h).  Fragment f of a wave's 32-row W group then reads rows
+  // (i/4)*8 + f*4 + i%4 instead of f*16 + i, and the W half tiles use the swizzle key ((r>>1)&1) | (((r>>3)&3)<<1), which is distinct
+  // over exactly those 16 rows x 2 parities (the A half tiles keep (r>>1)&7, distinct over 16 consecutive rows).
+  constexpr bool PAIRED = EPI != F3R_EPI_QKV;
+  static_assert(!(PAIRED && SWAP), "swapped roles exist only in the QKV role");
+  auto w_key = [](int r) { return PAIRED ? (((r >> 1) & 1) | (((r >> 3) & 3) << 1)) : ((r >> 1) & 7); };
+  uint64_t stamp[5] = {0, 0, 0, 0, 0};
+  if (LAB & 128) stamp[0] = __builtin_amdgcn_s_memtime();
+  if ((LAB & (256 | 512)) && blockIdx.x < 256) {
+    const int PH = (LAB & 512) ? 4 : 2;
+    const int phase = (blockIdx.x >> 3) & (PH - 1);
+    const int n = phase * (p.Kpad / BK) * (4 / PH);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(15);
+  }
 
   // ------------------------------------------------------------------ K segments (split precision) and tile counts
   const int nseg = p.split == F3R_SPLIT_NONE ? 1 : (p.split == F3R_SPLIT_W2 ? 2 : 3);
@@ -90,7 +108,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       const int lc = (lane & 7) ^ ((r >> 1) & 7);
       int n = n0 + (h < NH ? h : 0) * 128 + r;
       if (n >= p.N) n = p.N - 1;
-      w_off[h][i] = (uint32_t)(((int64_t)(n - n0) * p.Kpad + lc * 8) * 2);
+      w_off[h][i] = (uint32_t)(((int64_t)(n - n0) * p.Kpad + ((lane & 7) ^ w_key(r)) * 8) * 2);
       int64_t m = m0 + h * 128 + r;
       if (A_MODE == F3R_A_PLAIN) {
         if (m >= p.M) m = p.M - 1;
@@ -176,12 +194,12 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
 
   // ------------------------------------------------------------------ fragment read addressing (elements inside a half tile)
   const int sw = (fr >> 1) & 7;
+  const int w_row = wn * 32 + (PAIRED ? (fr >> 2) * 8 + (fr & 3) : fr);  // fragment nf adds nf * (PAIRED ? 4 : 16) rows: same key
   int a_rd[2], w_rd[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const int pc = ((ks * 4 + fg) ^ sw) << 3;
-    a_rd[ks] = (wm * 64 + fr) * 64 + pc;
-    w_rd[ks] = (wn * 32 + fr) * 64 + pc;
+    a_rd[ks] = (wm * 64 + fr) * 64 + (((ks * 4 + fg) ^ sw) << 3);
+    w_rd[ks] = w_row * 64 + (((ks * 4 + fg) ^ w_key(w_row)) << 3);
   }
 
   float4v acc[16 * NH];
@@ -201,7 +219,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
-        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * 16 * 64));
+        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * (PAIRED ? 4 : 16) * 64));
   };
   auto mma = [&](const typename T::vec8 (&f)[2][4], int mh, int nh) {
     if (LAB & 4) return;
@@ -280,7 +298,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   // ------------------------------------------------------------------ prologue
   // The bias and the additive epilogue terms (fp32 / lowp residuals, image-id rows) are loaded FIRST, straight into the accumulators:
   // they land under the latency of the first tiles (f3r_gemm_epi.h); the compiler's own wait covers their first use.
-  typedef GemmFragLayout<2 * NH, 8, 2, 4> Frag;  // 2 fragments from each W half, 4 fragments from each A half
+  typedef GemmFragLayout<2 * NH, 8, 2, 4, PAIRED> Frag;  // 2 fragments from each W half, 4 fragments from each A half
   const int64_t m_base = m0 + wm * 64;
   const int n_base = n0 + wn * 32;
   gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
@@ -309,6 +327,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   }
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
+  if (LAB & 128) stamp[1] = __builtin_amdgcn_s_memtime();
 
   if constexpr (NH == 2) {
     if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
@@ -331,10 +350,21 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   // before the workgroup's LDS can be handed to the next one.
   F3R_VMCNT(0);
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
+  if (LAB & 128) stamp[2] = __builtin_amdgcn_s_memtime();
 
   // ------------------------------------------------------------------ epilogue
   if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
   else gemm_epilogue_default<T, EPI, Frag, false>(p, acc, m_base, n_base, lane);
+  if (LAB & 128) {
+    __builtin_amdgcn_sched_barrier(0);
+    stamp[3] = __builtin_amdgcn_s_memtime();
+    F3R_VMCNT(0);
+    stamp[4] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      uint64_t* d = (uint64_t*)p.rope_cos + (int64_t)blockIdx.x * 5;
+      for (int i = 0; i < 5; ++i) d[i] = stamp[i];
+    }
+  }
 }
 
 template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
@@ -363,10 +393,13 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   const int64_t tm = first_m + rem_ % gm;
   const int64_t m0 = tm * BM;
   const int n0 = tn * BN;
-  if (EPI == F3R_EPI_QKV && n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3)))
-    gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
-  else
-    gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
+  if constexpr (EPI == F3R_EPI_QKV) {
+    if (n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3))) {  // the V part: swapped operand roles, V^T epilogue
+      gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
+      return;
+    }
+  }
+  gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
 }
 
 template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
@@ -432,7 +465,7 @@ int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream) {
   switch (a.kernel_sel - 16) {
 #define F3R_LAB_CASE(n) case n: return launch_lab<BF16, n>(a, stream);
     F3R_LAB_CASE(0) F3R_LAB_CASE(1) F3R_LAB_CASE(2) F3R_LAB_CASE(3) F3R_LAB_CASE(4) F3R_LAB_CASE(7) F3R_LAB_CASE(8) F3R_LAB_CASE(16)
-    F3R_LAB_CASE(32) F3R_LAB_CASE(33) F3R_LAB_CASE(64) F3R_LAB_CASE(96)
+    F3R_LAB_CASE(32) F3R_LAB_CASE(33) F3R_LAB_CASE(64) F3R_LAB_CASE(96) F3R_LAB_CASE(128) F3R_LAB_CASE(256) F3R_LAB_CASE(512) F3R_LAB_CASE(384) F3R_LAB_CASE(640)
 #undef F3R_LAB_CASE
   }
 #endif

@@ -12,11 +12,21 @@
 #pragma once
 #include "f3r_common.h"
 
-template <int NF_, int MF_, int NG_, int MG_>
+// PAIRED (256-tile kernel, every role but QKV): the kernel feeds the weight rows of a 32-column group to the two MFMA fragments of the
+// group in the order  row(fragment f, MFMA row i) = (i / 4) * 8 + f * 4 + i % 4,  so lane group fg holds columns fg*8 .. fg*8+3 in
+// fragment 0 and fg*8+4 .. fg*8+7 in fragment 1: EIGHT consecutive columns per lane and row -> 16-byte lowp stores / loads, 64 - 128 B
+// contiguous per row and instruction instead of 32 B (the epilogue of a K = 1024 tile is bound by the number of partial-line stores).
+// The lane's 4 columns of fragment nf are  n_base + col(nf) + fg * LW + 0..3  in both layouts.
+template <int NF_, int MF_, int NG_, int MG_, bool PAIRED_ = false>
 struct GemmFragLayout {
   static constexpr int NF = NF_, MF = MF_, NG = NG_, MG = MG_;
+  static constexpr bool PAIRED = PAIRED_;
+  static constexpr int LW = PAIRED_ ? 8 : 4;
+  static constexpr int STEP = PAIRED_ ? 2 : 1;  // fragments whose lane columns are contiguous
+  static_assert(!PAIRED_ || NG_ == 2, "paired columns: two fragments per 32-column group");
   static __device__ __forceinline__ int row(int mf) { return (mf / MG) * 128 + (mf % MG) * 16; }
-  static __device__ __forceinline__ int col(int nf) { return (nf / NG) * 128 + (nf % NG) * 16; }
+  static __device__ __forceinline__ int col(int nf) { return (nf / NG) * 128 + (nf % NG) * (PAIRED_ ? 4 : 16); }
+  static __device__ __forceinline__ int col_end() { return ((NF - 1) / NG) * 128 + NG * 16; }  // one past the sub-tile's last column
 };
 
 // Exact (erf) GELU, nn.GELU() default (blocks.py:84).  erfc(|z|) by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp,
@@ -33,6 +43,28 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float u = poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // erfc(z)
   const float h = 0.5f * x * u;
   return x >= 0.f ? x - h : h;
+}
+
+// The same function on a 4-vector, written with vector operations so that the multiplies and FMAs become v_pk_mul_f32 / v_pk_fma_f32
+// (two elements per instruction): ~11 instructions per element instead of 16.  |x| enters only through the rational argument t, the
+// exponent uses x*x, and  x >= 0 ? x - h : h  ==  max(x, 0) - |h|  (h has the sign of x).  Same polynomial, same 3.4e-7 bound.
+// (fmaxf would cost a second v_max per element: the compiler has to quiet a possible signalling NaN first.)
+__device__ __forceinline__ float4v gelu_erf4(float4v x) {
+  float4v t, e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(x[i]), 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float4v poly = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);  // the 0.5 of h = 0.5 x erfc(.) folded into the coefficients
+  poly = poly * t + (0.5f * 1.421413741f);
+  poly = poly * t + (0.5f * -0.284496736f);
+  poly = poly * t + (0.5f * 0.254829592f);
+  const float4v arg = (x * x) * (-0.5f * 1.44269504088896340736f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(arg[i]);
+  const float4v h = x * (poly * t * e);
+  float4v r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(x[i] + __builtin_fabsf(x[i]), 0.5f, -__builtin_fabsf(h[i]));  // max(x, 0) = (x + |x|) / 2, exact
+  return r;
 }
 
 // 4 fp32 -> 4 lowp (hi) and, when lo != nullptr, the 4 lowp remainders v - float(hi): hi + lo carries ~2x the significand bits
@@ -54,6 +86,35 @@ template <class T>
 __device__ __forceinline__ float4v load4_lp(const uint16_t* ptr) {
   const u32x2 r = *(const u32x2*)ptr;
   return float4v{lo_f<T>(r[0]), hi_f<T>(r[0]), lo_f<T>(r[1]), hi_f<T>(r[1])};
+}
+
+// STEP consecutive fragments of a lane = 4 * STEP consecutive columns: one 8- or 16-byte access per plane
+template <class T, int STEP>
+__device__ __forceinline__ void storeN_split(char* hi, char* lo, const float4v* v) {
+  if constexpr (STEP == 1) {
+    store4_split<T>((uint16_t*)hi, (uint16_t*)lo, v[0]);
+  } else {
+    u32x4 o;
+    o[0] = pack2<T>(v[0][0], v[0][1]); o[1] = pack2<T>(v[0][2], v[0][3]);
+    o[2] = pack2<T>(v[1][0], v[1][1]); o[3] = pack2<T>(v[1][2], v[1][3]);
+    *(u32x4*)hi = o;
+    if (lo) {
+      u32x4 r;
+      r[0] = pack2<T>(v[0][0] - lo_f<T>(o[0]), v[0][1] - hi_f<T>(o[0])); r[1] = pack2<T>(v[0][2] - lo_f<T>(o[1]), v[0][3] - hi_f<T>(o[1]));
+      r[2] = pack2<T>(v[1][0] - lo_f<T>(o[2]), v[1][1] - hi_f<T>(o[2])); r[3] = pack2<T>(v[1][2] - lo_f<T>(o[3]), v[1][3] - hi_f<T>(o[3]));
+      *(u32x4*)lo = r;
+    }
+  }
+}
+template <class T, int STEP>
+__device__ __forceinline__ void loadN_lp(const char* ptr, float4v* v) {
+  if constexpr (STEP == 1) {
+    v[0] = load4_lp<T>((const uint16_t*)ptr);
+  } else {
+    const u32x4 r = *(const u32x4*)ptr;
+    v[0] = float4v{lo_f<T>(r[0]), hi_f<T>(r[0]), lo_f<T>(r[1]), hi_f<T>(r[1])};
+    v[1] = float4v{lo_f<T>(r[2]), hi_f<T>(r[2]), lo_f<T>(r[3]), hi_f<T>(r[3])};
+  }
 }
 
 // ------------------------------------------------------------------ additive terms of the GENERIC epilogue
@@ -135,11 +196,92 @@ __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, f
     }
     return;
   }
+  if (SRC != F3R_ADD_ROWADD && m_base + L::row(MF - 1) + 16 <= p.M && n_base + L::col_end() <= p.N) {
+    // interior sub-tile: wave-uniform base + one 32-bit lane offset per tensor (see the interior epilogues below)
+    float4v b4[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+      b4[nf] = p.bias ? *(const float4v*)((const char*)(p.bias + n_base + L::col(nf)) + (uint32_t)(fg * L::LW * 4)) : float4v{0.f, 0.f, 0.f, 0.f};
+    if (SRC == F3R_ADD_NONE) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[nf * MF + mf] = b4[nf];
+      return;
+    }
+    if (SRC == F3R_ADD_RES_F32) {
+      const uint32_t off = (uint32_t)(fr * (int)p.ldr_f32 + fg * L::LW) * 4u;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const char* const row = (const char*)p.res_f32 + ((m_base + L::row(mf)) * p.ldr_f32 + n_base) * 4;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[nf * MF + mf] = *(const float4v*)(row + L::col(nf) * 4 + off);
+      }
+    } else {
+      const uint32_t off = (uint32_t)(fr * (int)p.ldr_lp + fg * L::LW) * 2u;
+      const uint32_t off2 = (uint32_t)(fr * (int)p.ldr_lp2 + fg * L::LW) * 2u;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t ro = ((m_base + L::row(mf)) * p.ldr_lp + n_base) * 2;
+#pragma unroll
+        for (int nf = 0; nf < NF; nf += L::STEP) {
+          float4v t[L::STEP];
+          loadN_lp<T, L::STEP>((const char*)p.res_lp + ro + L::col(nf) * 2 + off, t);
+#pragma unroll
+          for (int q = 0; q < L::STEP; ++q) acc[(nf + q) * MF + mf] = t[q];
+        }
+      }
+      if (p.res_lp_lo) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int64_t ro = ((m_base + L::row(mf)) * p.ldr_lp + n_base) * 2;
+#pragma unroll
+          for (int nf = 0; nf < NF; nf += L::STEP) {
+            float4v t[L::STEP];
+            loadN_lp<T, L::STEP>((const char*)p.res_lp_lo + ro + L::col(nf) * 2 + off, t);
+#pragma unroll
+            for (int q = 0; q < L::STEP; ++q) acc[(nf + q) * MF + mf] += t[q];
+          }
+        }
+      }
+      if (p.res_lp2) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int64_t ro = ((m_base + L::row(mf)) * p.ldr_lp2 + n_base) * 2;
+#pragma unroll
+          for (int nf = 0; nf < NF; nf += L::STEP) {
+            float4v t[L::STEP];
+            loadN_lp<T, L::STEP>((const char*)p.res_lp2 + ro + L::col(nf) * 2 + off2, t);
+#pragma unroll
+            for (int q = 0; q < L::STEP; ++q) acc[(nf + q) * MF + mf] += t[q];
+          }
+        }
+        if (p.res_lp2_lo) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const int64_t ro = ((m_base + L::row(mf)) * p.ldr_lp2 + n_base) * 2;
+#pragma unroll
+            for (int nf = 0; nf < NF; nf += L::STEP) {
+            float4v t[L::STEP];
+            loadN_lp<T, L::STEP>((const char*)p.res_lp2_lo + ro + L::col(nf) * 2 + off2, t);
+#pragma unroll
+            for (int q = 0; q < L::STEP; ++q) acc[(nf + q) * MF + mf] += t[q];
+          }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc[nf * MF + mf] += b4[nf];
+    return;
+  }
   int nbc[NF];
   float4v bias4[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    const int nb = n_base + L::col(nf) + fg * 4;
+    const int nb = n_base + L::col(nf) + fg * L::LW;
     nbc[nf] = nb < p.N ? nb : p.N - 4;
     bias4[nf] = p.bias ? *(const float4v*)(p.bias + nbc[nf]) : float4v{0.f, 0.f, 0.f, 0.f};
   }
@@ -198,16 +340,150 @@ __device__ __forceinline__ void gemm_acc_init_additive(const f3r_gemm_args& p, f
     for (int mf = 0; mf < MF; ++mf) acc[nf * MF + mf] += bias4[nf];
 }
 
+#define F3R_EPI_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)  /* vmcnt(0) */
+
+// ------------------------------------------------------------------ interior fast paths
+// A wave sub-tile that lies completely inside the matrix (a wave-uniform test) needs no per-row predicate, and every address is
+//     wave-uniform base (SGPR pair, scalar arithmetic)  +  ONE 32-bit lane offset shared by all fragments of a tensor,
+// i.e. `global_store v_off, v_data, s[base:base+1] offset:imm`: 3 instructions per fragment instead of ~20.  The general bodies below
+// (64-bit multiplies, compares and exec masking per fragment, 64-bit divisions per row in the QKV roles) made the epilogue a quarter of
+// the time of a K = 1024 tile (s_memtime stamps, profiles/r02_gemm256_tile_stamps.jsonl); they remain for the edge tiles.
+template <class L>
+__device__ __forceinline__ bool gemm_wave_interior(const f3r_gemm_args& p, int64_t m_base, int n_base) {
+  return m_base + L::row(L::MF - 1) + 16 <= p.M && n_base + L::col_end() <= p.N;
+}
+
+template <int V>
+struct EpiC {
+  static constexpr int value = V;
+};
+
+// GENERIC role, additive terms already in the accumulators
+template <class T, class L>
+__device__ __forceinline__ void gemm_epilogue_generic_interior(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
+  constexpr int NF = L::NF, MF = L::MF;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t off_f32 = (uint32_t)(fr * (int)p.ldo_f32 + fg * L::LW) * 4u;
+  const uint32_t off_lp = (uint32_t)(fr * (int)p.ldo_lp + fg * L::LW) * 2u;
+  const bool relu = p.act == F3R_ACT_RELU;  // wave-uniform branch per fragment; GELU is a compile-time variant of the body
+  // KIND: 0 out_lp only, 1 out_lp + out_lp_lo, 2 out_f32 only, 3 any combination (wave-uniform tests per fragment)
+  auto run = [&](auto act_c, auto kind_c) {
+    constexpr int ACT = decltype(act_c)::value, KIND = decltype(kind_c)::value;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t mrow = m_base + L::row(mf);
+      char* const bf = (KIND >= 2 && p.out_f32) ? (char*)p.out_f32 + (mrow * p.ldo_f32 + n_base) * 4 : nullptr;
+      const int64_t lp_row = (mrow * p.ldo_lp + n_base) * 2;
+      char* const bl = (KIND != 2 && p.out_lp) ? (char*)p.out_lp + lp_row : nullptr;
+      char* const bll = ((KIND == 1 || KIND == 3) && p.out_lp_lo) ? (char*)p.out_lp_lo + lp_row : nullptr;
+      char* const br = (KIND == 3 && p.out_relu) ? (char*)p.out_relu + lp_row : nullptr;
+      char* const brl = (KIND == 3 && p.out_relu_lo) ? (char*)p.out_relu_lo + lp_row : nullptr;
+#pragma unroll
+      for (int nf = 0; nf < NF; nf += L::STEP) {
+        float4v v[L::STEP];
+#pragma unroll
+        for (int q = 0; q < L::STEP; ++q) {
+          v[q] = acc[(nf + q) * MF + mf];
+          if (ACT == F3R_ACT_GELU) v[q] = gelu_erf4(v[q]);
+          else if (relu) v[q] = float4v{fmaxf(v[q][0], 0.f), fmaxf(v[q][1], 0.f), fmaxf(v[q][2], 0.f), fmaxf(v[q][3], 0.f)};
+        }
+        const int cb = L::col(nf);
+        if (KIND >= 2 && bf) {
+#pragma unroll
+          for (int q = 0; q < L::STEP; ++q) *(float4v*)(bf + (cb + q * 4) * 4 + off_f32) = v[q];
+        }
+        if (KIND != 2 && bl) storeN_split<T, L::STEP>(bl + cb * 2 + off_lp, (KIND == 1 || (KIND == 3 && bll)) ? bll + cb * 2 + off_lp : nullptr, v);
+        if (KIND == 3 && br) {
+          float4v r[L::STEP];
+#pragma unroll
+          for (int q = 0; q < L::STEP; ++q) r[q] = float4v{fmaxf(v[q][0], 0.f), fmaxf(v[q][1], 0.f), fmaxf(v[q][2], 0.f), fmaxf(v[q][3], 0.f)};
+          storeN_split<T, L::STEP>(br + cb * 2 + off_lp, brl ? brl + cb * 2 + off_lp : nullptr, r);
+        }
+      }
+    }
+  };
+  auto by_kind = [&](auto act_c) {
+    const bool f32 = p.out_f32 != nullptr, lp = p.out_lp != nullptr, lo = p.out_lp_lo != nullptr, rl = p.out_relu != nullptr;
+    if (lp && !f32 && !lo && !rl) run(act_c, EpiC<0>{});
+    else if (lp && lo && !f32 && !rl) run(act_c, EpiC<1>{});
+    else if (f32 && !lp && !rl) run(act_c, EpiC<2>{});
+    else run(act_c, EpiC<3>{});
+  };
+  if (p.act == F3R_ACT_GELU) by_kind(EpiC<F3R_ACT_GELU>{});
+  else by_kind(EpiC<F3R_ACT_NONE>{});
+}
+
+// q / k parts of the QKV role (bias already in the accumulators); rows < 2^31 (validated on the host) so that token -> (sequence, y, x)
+// is 32-bit unsigned arithmetic with wave-uniform divisors
+template <class T, class L>
+__device__ __forceinline__ void gemm_epilogue_qk_interior(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
+  constexpr int NF = L::NF, MF = L::MF, MB = 4;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int Dq = p.qkv_dq ? p.qkv_dq : p.N / 3;
+  const int Dkv = (p.N - Dq) / 2;
+  const int part = n_base < Dq ? 0 : 1;
+  const int Dm = part == 0 ? Dq : Dkv;
+  const int col0 = part == 0 ? 0 : Dq;
+  char* const dst = (char*)(part == 0 ? p.q : p.k);
+  const float qs = (part == 0 && p.q_scale != 0.f) ? p.q_scale : 1.f;
+  const uint32_t off = (uint32_t)(fr * Dm + fg * L::LW) * 2u;
+  const uint32_t seq = (uint32_t)p.seq_len, rw = (uint32_t)(p.rope_w > 0 ? p.rope_w : 1);
+#pragma unroll
+  for (int mb = 0; mb < MF; mb += MB) {
+    float4v c[MB][NF / 2], sn[MB][NF / 2];
+    if (p.rope_cos) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const uint32_t m = (uint32_t)(m_base + L::row(mb + i)) + (uint32_t)fr;
+        const uint32_t pos = m % seq;
+        const uint32_t py = pos / rw, px = pos - py * rw;
+        const uint32_t grp = m / rw;
+#pragma unroll
+        for (int j = 0; j < NF / 2; ++j) {
+          const int h = ((n_base + L::col(2 * j)) >> 5) & 1;
+          const int64_t toff = p.rope_mode == 1 ? (int64_t)grp * 32 + h * 16 : (int64_t)(h == 0 ? py : px) * 16;
+          c[i][j] = *(const float4v*)(p.rope_cos + toff + fg * 4);
+          sn[i][j] = *(const float4v*)(p.rope_sin + toff + fg * 4);
+        }
+      }
+      F3R_EPI_WAIT_LOADS();
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      char* const row = dst + ((m_base + L::row(mb + i)) * Dm + (n_base - col0)) * 2;
+      float4v v[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) v[nf] = acc[nf * MF + mb + i];
+      if (p.rope_cos) {
+#pragma unroll
+        for (int j = 0; j < NF / 2; ++j) {
+          const float4v a = v[2 * j], b = v[2 * j + 1];
+          v[2 * j] = a * c[i][j] - b * sn[i][j];
+          v[2 * j + 1] = b * c[i][j] + a * sn[i][j];
+        }
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) store4_split<T>((uint16_t*)(row + L::col(nf) * 2 + off), nullptr, v[nf] * qs);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ default roles: GENERIC / CONVT / the q and k thirds of QKV
 // ADD: the additive terms are applied here (128-tile kernel: two workgroups per CU cover each other's epilogue latency); otherwise
 // they are already in the accumulators (gemm_acc_init_additive).
 // Every batch of loads is followed by an explicit s_waitcnt vmcnt(0) OUTSIDE the per-fragment predication: hipcc's wait-count pass
 // loses track of a load waited for inside a conditionally executed fragment body and would wait vmcnt(0) -- i.e. for the previous
 // fragment's STORES too -- at the top of every body.
-#define F3R_EPI_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 template <class T, int EPI, class L, bool ADD>
 __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, const float4v* acc, int64_t m_base, int n_base, int lane) {
   constexpr int NF = L::NF, MF = L::MF;
+  if constexpr (!ADD && EPI != F3R_EPI_CONVT) {
+    if (gemm_wave_interior<L>(p, m_base, n_base) && p.M <= 0x7fffffffll) {
+      if constexpr (EPI == F3R_EPI_GENERIC) gemm_epilogue_generic_interior<T, L>(p, acc, m_base, n_base, lane);
+      else gemm_epilogue_qk_interior<T, L>(p, acc, m_base, n_base, lane);
+      return;
+    }
+  }
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int MB = 4;  // fragment rows per batch
   static_assert(MF % MB == 0, "MF must be a multiple of the batch");
@@ -215,7 +491,7 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
   float4v bias4[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
-    nb[nf] = n_base + L::col(nf) + fg * 4;
+    nb[nf] = n_base + L::col(nf) + fg * L::LW;
     nbc[nf] = nb[nf] < p.N ? nb[nf] : p.N - 4;
     bias4[nf] = (ADD && p.bias) ? *(const float4v*)(p.bias + nbc[nf]) : float4v{0.f, 0.f, 0.f, 0.f};  // !ADD: already in acc
   }
@@ -344,6 +620,24 @@ __device__ __forceinline__ void gemm_epilogue_vt(const f3r_gemm_args& p, const f
   const int Dm = (p.N - Dq) / 2;  // width of the k and of the v part
   uint16_t* vt = (uint16_t*)p.vt;
   const bool vec_ok = ((p.seq_len | p.ldvt) & 3) == 0;
+  if (!BIAS && vec_ok && p.M <= 0x7fffffffll && gemm_wave_interior<L>(p, m_base, n_base)) {
+    // interior sub-tile: token -> (sequence, position) once per fragment ROW in 32-bit arithmetic, address = A[mf] + B[nf]
+    const uint32_t seq = (uint32_t)p.seq_len;
+    int64_t A[MF], B[NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const uint32_t mb = (uint32_t)(m_base + L::row(mf)) + (uint32_t)(fg * 4);
+      const uint32_t sq = mb / seq, t = mb - sq * seq;
+      A[mf] = (int64_t)sq * Dm * p.ldvt + t;
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) B[nf] = (int64_t)(n_base + L::col(nf) + fr - Dq - Dm) * p.ldvt;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) store4_split<T>(vt + A[mf] + B[nf], nullptr, acc[mf * NF + nf]);
+    return;
+  }
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int n = n_base + L::col(nf) + fr;  // < N

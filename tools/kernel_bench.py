@@ -183,6 +183,46 @@ def bench_lab(M, N, K):
                           "tflops_nominal": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
 
 
+PAIRED_STORE_EXPERIMENT = 0
+
+
+def bench_labtime(M, N, K, act=None, bits=128):
+    """Where a 256 x 256 output tile spends its time (lab bit 128: s_memtime stamps of wave 0 of every workgroup)."""
+    from fast3r_amd import _lib
+    dt = torch.bfloat16
+    a = torch.randn((M, K), device=DEV).to(dt)
+    w = ops.pack_linear_weight(torch.randn((N, K), device=DEV) * K ** -0.5, dt)
+    bias = torch.randn(N, device=DEV)
+    olp = torch.empty((M, N), dtype=dt, device=DEV)
+    tiles = (M // 256) * (N // 256)
+    dbg = torch.zeros((tiles, 5), dtype=torch.int64, device=DEV)
+    L = _lib.lib()
+    orig = L.f3r_gemm
+
+    def patched(argp, stream):
+        argp._obj.rope_cos = dbg.data_ptr()  # unused by the generic epilogue: carries the stamp buffer
+        argp._obj.reserved1 = PAIRED_STORE_EXPERIMENT
+        return orig(argp, stream)
+    L.f3r_gemm = patched
+    try:
+        for _ in range(3):
+            ops.gemm(a, w, bias=bias, act=act, out_lp=olp, kernel_sel=16 + bits)
+        torch.cuda.synchronize()
+        ms = time_ms(lambda: ops.gemm(a, w, bias=bias, act=act, out_lp=olp, kernel_sel=16 + bits), rounds=3, inner=3)[0]
+    finally:
+        L.f3r_gemm = orig
+    d = dbg.cpu().double()
+    t0 = d[:, 0].min()
+    span = (d[:, 4].max() - t0).item()
+    seg = [(d[:, i + 1] - d[:, i]).mean().item() for i in range(4)]
+    tot = (d[:, 4] - d[:, 0]).mean().item()
+    rounds = -(-tiles // 256)
+    print(json.dumps({"kernel": "gemm256_lab stamps", "bits": bits, "paired": PAIRED_STORE_EXPERIMENT, "M": M, "N": N, "K": K, "act": act, "ms": round(ms, 3), "tiles": tiles, "rounds_of_256": rounds,
+                      "ticks_kernel_span": span, "ticks_per_tile_mean": tot, "prologue": seg[0], "main_loop": seg[1], "epilogue_issue": seg[2],
+                      "store_retire": seg[3], "ticks_per_us": round(span / (ms * 1e3), 1),
+                      "frac": {k: round(v / tot, 3) for k, v in zip(("prologue", "main_loop", "epilogue_issue", "store_retire"), seg)}}), flush=True)
+
+
 def bench_qkv(dt, M, D, seq, sels=(1, 2, 3)):
     a = torch.randn((M, D), device=DEV).to(dt)
     w = ops.pack_linear_weight(torch.randn((3 * D, D), device=DEV) * D ** -0.5, dt)
@@ -352,13 +392,14 @@ if __name__ == "__main__":
     ap.add_argument("--what", default="attn,gemm,conv")
     ap.add_argument("--variants", default="24,72", help="attention variants; anything but 24 53 55 70 71 72 84 needs a -DF3R_ATTN_LAB build")
     ap.add_argument("--views", default="20,100")
+    ap.add_argument("--attn-dtypes", default="bf16,fp16", help="attnproduct: which operand formats")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
     if args.what == "attnproduct":
         for nv in [int(v) for v in args.views.split(",")]:
-            bench_attn_product(torch.bfloat16, nv)
-            bench_attn_product(torch.float16, nv)
+            for d in (args.attn_dtypes.split(",")):
+                bench_attn_product({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv)
         sys.exit(0)
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
@@ -370,6 +411,36 @@ if __name__ == "__main__":
             bench_attn(dt, nv, variants)
         bench_attn(torch.float16, 20, variants[:3])
         bench_attn_encoder(dt, 64, variants)
+    if args.what == "labpaired":
+        M = 40 * 1024
+        for PAIRED_STORE_EXPERIMENT in (0, 1):
+            globals()["PAIRED_STORE_EXPERIMENT"] = PAIRED_STORE_EXPERIMENT
+            bench_labtime(M, 4096, 1024)
+            bench_labtime(8 * M, 4096, 1024)
+        sys.exit(0)
+    if args.what == "labtime":
+        M = 40 * 1024
+        for bits in (128, 384, 640):
+            bench_labtime(M, 4096, 1024, bits=bits)
+            bench_labtime(M, 4096, 1024, act="gelu", bits=bits)
+            bench_labtime(M, 1024, 4096, bits=bits)
+            bench_labtime(8 * M, 4096, 1024, act="gelu", bits=bits)
+        sys.exit(0)
+    if args.what == "labphase":  # plain timing (no stamps): baseline / 2 phases / 4 phases
+        M = 40 * 1024
+        dt = torch.bfloat16
+        for (m, n, k, act) in ((M, 4096, 1024, None), (M, 4096, 1024, "gelu"), (M, 1024, 1024, None), (M, 1024, 4096, None), (8 * M, 4096, 1024, "gelu"), (8 * M, 1024, 1024, None)):
+            a = torch.randn((m, k), device=DEV).to(dt)
+            w = ops.pack_linear_weight(torch.randn((n, k), device=DEV) * k ** -0.5, dt)
+            bias = torch.randn(n, device=DEV)
+            olp = torch.empty((m, n), dtype=dt, device=DEV)
+            for bits in (0, 256, 512):
+                f = lambda: ops.gemm(a, w, bias=bias, act=act, out_lp=olp, kernel_sel=16 + bits)
+                f()
+                ms = sorted(time_ms(f, rounds=3, inner=3)[0] for _ in range(3))[1]
+                print(json.dumps({"kernel": "gemm256_lab dephase", "bits": bits, "M": m, "N": n, "K": k, "act": act, "ms": round(ms, 3),
+                                  "tflops": round(2.0 * m * n * k / ms / 1e9, 1)}), flush=True)
+        sys.exit(0)
     if "lab" in args.what:
         bench_lab(40 * 1024, 4096, 1024)
         bench_lab(40 * 1024, 1024, 4096)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC over the GEMM micro-benchmark (M = 40960, the four ViT-L linear shapes + QKV): matrix-pipe utilisation in cycles and the
-# LDS / VMEM instruction mix per gemm_kernel instantiation.  Two --pmc passes (own runs, kernel-trace only).
+# LDS / VMEM instruction mix per gemm_kernel / gemm256_kernel instantiation and grid.  Two --pmc passes (own runs, kernel-trace only).
 mkdir -p gpurun_out/pmcg
 export TMPDIR=/tmp
 CMD="python tools/kernel_bench.py --what gemm"
@@ -15,8 +15,8 @@ for p in ("p1", "p2"):
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
-        if "gemm_kernel" in r["Kernel_Name"]:
-            key = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "") + f" grid={r.get('Grid_Size', '?')}"
+        if "gemm_kernel" in r["Kernel_Name"] or "gemm256_kernel" in r["Kernel_Name"]:
+            key = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(f3r_gemm_args")[0] + f" grid={r.get('Grid_Size', '?')}"
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         for c, v in d.items():
