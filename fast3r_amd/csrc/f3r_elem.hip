@@ -211,6 +211,66 @@ __global__ __launch_bounds__(256) void dpt_final_kernel(const uint16_t* __restri
   if (conf) conf[pix] = conf_mode == F3R_CONF_EXP ? vmin + fminf(expf(a3), vmax - vmin) : (vmax - vmin) * (1.f / (1.f + expf(-a3))) + vmin;
 }
 
+// Cin == 128 (the DPT head's last_dim): the one-pixel-per-lane walk above reads 16 B from 64 different 256-byte rows per load
+// instruction (measured ~1 TB/s of the ~8 TB/s HBM roof).  Here a one-wave workgroup stages its 64 pixels by LDS-DMA -- every
+// global_load_lds moves 1 KiB of CONTIGUOUS memory (4 pixels x 256 B) -- and each lane then reads its own pixel's row from LDS.  The
+// 16-byte chunk c of pixel p is stored at chunk c ^ (p & 15) of the row (swizzle applied on the source address), so the 16 lanes of a
+// ds_read_b128 group hit all 64 banks once.  16 KiB per plane; four to five workgroups per CU hide each other's DMA latency.
+template <class T, bool HAS_LO>
+__global__ __launch_bounds__(64) void dpt_final128_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x_lo,
+                                                          const float* __restrict__ w, const float* __restrict__ bias, int n_out,
+                                                          float* __restrict__ pts, float* __restrict__ conf, int64_t npix, float vmin,
+                                                          float vmax, int depth_mode, int conf_mode) {
+  constexpr int Cin = 128;
+  __shared__ __attribute__((aligned(16))) uint16_t tile[(HAS_LO ? 2 : 1) * 64 * Cin];
+  __shared__ float wsh[4 * Cin];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int lane = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = i * 4 + (lane >> 4);
+    int64_t gp = p0 + p;
+    if (gp >= npix) gp = npix - 1;
+    const int64_t src = gp * Cin + (((lane & 15) ^ (p & 15)) << 3);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(x + src), (lds_ptr_t)(tile + i * 512), 16, 0, 0);
+    if (HAS_LO) __builtin_amdgcn_global_load_lds((glb_ptr_t)(x_lo + src), (lds_ptr_t)(tile + 64 * Cin + i * 512), 16, 0, 0);
+  }
+  for (int i = lane; i < 4 * Cin; i += 64) wsh[i] = i < n_out * Cin ? w[i] : 0.f;
+  __syncthreads();  // (the compiler drains vmcnt before the barrier: the tile has landed)
+  float a0 = bias[0], a1 = bias[1], a2 = bias[2], a3 = n_out > 3 ? bias[3] : 0.f;
+  const uint16_t* row = tile + lane * Cin;
+#pragma unroll 4
+  for (int c = 0; c < 16; ++c) {
+    const int pc = (c ^ (lane & 15)) << 3;
+    const u32x4 v = *(const u32x4*)(row + pc);
+    u32x4 vl = {0u, 0u, 0u, 0u};
+    if (HAS_LO) vl = *(const u32x4*)(row + 64 * Cin + pc);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f0 = lo_f<T>(v[k]), f1 = hi_f<T>(v[k]);
+      if (HAS_LO) { f0 += lo_f<T>(vl[k]); f1 += hi_f<T>(vl[k]); }
+      const int cc = c * 8 + 2 * k;
+      a0 = __builtin_fmaf(f0, wsh[cc], a0);            a0 = __builtin_fmaf(f1, wsh[cc + 1], a0);
+      a1 = __builtin_fmaf(f0, wsh[Cin + cc], a1);      a1 = __builtin_fmaf(f1, wsh[Cin + cc + 1], a1);
+      a2 = __builtin_fmaf(f0, wsh[2 * Cin + cc], a2);  a2 = __builtin_fmaf(f1, wsh[2 * Cin + cc + 1], a2);
+      a3 = __builtin_fmaf(f0, wsh[3 * Cin + cc], a3);  a3 = __builtin_fmaf(f1, wsh[3 * Cin + cc + 1], a3);
+    }
+  }
+  const int64_t pix = p0 + lane;
+  if (pix >= npix) return;
+  float sc = 1.f;  // postprocess exactly as in dpt_final_kernel
+  if (depth_mode != F3R_DEPTH_LINEAR) {
+    const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    sc = (depth_mode == F3R_DEPTH_EXP ? expm1f(d) : d * d) / fmaxf(d, 1e-8f);
+  }
+  pts[pix * 3 + 0] = a0 * sc;
+  pts[pix * 3 + 1] = a1 * sc;
+  pts[pix * 3 + 2] = a2 * sc;
+  if (conf) conf[pix] = conf_mode == F3R_CONF_EXP ? vmin + fminf(expf(a3), vmax - vmin) : (vmax - vmin) * (1.f / (1.f + expf(-a3))) + vmin;
+}
+
 template <class T>
 __global__ void cast_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, int64_t n8) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,6 +466,15 @@ extern "C" int f3r_dpt_final(const void* x, const void* x_lo, const float* w, co
   F3R_REQUIRE(conf_mode == F3R_CONF_EXP || conf_mode == F3R_CONF_SIGMOID, "f3r_dpt_final: bad conf_mode %d", conf_mode);
   if (npix <= 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (Cin == 128) {  // the DPT head: LDS-DMA staged, fully coalesced
+    const dim3 grid(nblk(npix, 64)), block(64);
+#define F3R_DPT128(TT, LO) hipLaunchKernelGGL((dpt_final128_kernel<TT, LO>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, \
+                                              pts3d, conf, npix, conf_vmin, conf_vmax, depth_mode, conf_mode)
+    if (dtype == F3R_F16) { if (x_lo) F3R_DPT128(F16, true); else F3R_DPT128(F16, false); }
+    else { if (x_lo) F3R_DPT128(BF16, true); else F3R_DPT128(BF16, false); }
+#undef F3R_DPT128
+    return f3r_check_launch("f3r_dpt_final");
+  }
   const size_t sh = (size_t)4 * Cin * sizeof(float);
   if (dtype == F3R_F16)
     hipLaunchKernelGGL(dpt_final_kernel<F16>, dim3(nblk(npix, 256)), dim3(256), sh, s, (const uint16_t*)x, (const uint16_t*)x_lo, w, b, n_out, pts3d,

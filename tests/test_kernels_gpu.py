@@ -82,6 +82,23 @@ def test_dpt_final(built_lib, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,pair", [(128, True), (64, False), (64, True), (256, False)])
+def test_dpt_final_planes_and_widths(built_lib, dt, cin, pair):
+    """Cin == 128 runs the LDS-DMA staged kernel (with / without the low plane of a split-precision activation), every other width the
+    one-pixel-per-lane kernel; 1000 pixels = 15 full groups of 64 + a ragged one."""
+    x32 = torch.randn((1, 25, 40, cin), generator=torch.Generator().manual_seed(5))
+    hi = x32.to(dt)
+    lo = (x32 - hi.float()).to(dt) if pair else None
+    w, b = torch.randn(4, cin) * 0.1, torch.randn(4) * 0.1
+    pts, conf = ops.dpt_final(hi.to(DEV), w.to(DEV), b.to(DEV), ["exp", 1, float("inf")], x_lo=None if lo is None else lo.to(DEV))
+    xin = hi.double() + (lo.double() if pair else 0.0)
+    y = xin @ w.double().t() + b.double()
+    d = y[..., :3].norm(dim=-1, keepdim=True)
+    assert_close(pts, y[..., :3] / d.clip(min=1e-8) * torch.expm1(d), 1e-5, "pts3d")
+    assert_close(conf, 1 + y[..., 3].exp(), 1e-5, "conf")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("depth_mode,conf_mode", [("linear", ("sigmoid", 0.5, 3.0)), ("square", ("exp", 1, 20.0)), ("exp", None), ("square", ("sigmoid", 0.0, 1.0))])
 def test_dpt_final_other_modes(built_lib, dt, depth_mode, conf_mode):
     """heads/postprocess.py:27-64: depth 'linear' / 'square' / 'exp', conf 'exp' with a finite vmax (clip) / 'sigmoid' / no confidence channel

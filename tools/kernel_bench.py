@@ -277,6 +277,21 @@ def bench_conv(dt, B, H, W, Ci, Co, name, stride=1, sels=(1, 2, 3), split=None):
                               "tflops_mfma": round(fl * mult / ms / 1e9, 1)}), flush=True)
 
 
+def bench_dpt_final(n_views=25, H=512, W=512):
+    """head[4] 1x1 conv + postprocess over one head chunk: algorithmic bytes = npix * (Cin * 2 [* 2 planes] + 16)."""
+    for dt in (torch.bfloat16, torch.float16):
+        for pair in (False, True):
+            x = torch.randn((n_views, H, W, 128), device=DEV).to(dt)
+            lo = (torch.randn((n_views, H, W, 128), device=DEV) * 2.0 ** -11).to(dt) if pair else None
+            w, b = torch.randn(4, 128, device=DEV) * 0.1, torch.randn(4, device=DEV) * 0.1
+            f = lambda: ops.dpt_final(x, w, b, ["exp", 1, float("inf")], x_lo=lo)
+            f()
+            ms = sorted(time_ms(f, rounds=3, inner=3)[0] for _ in range(3))[1]
+            nbytes = n_views * H * W * (128 * 2 * (2 if pair else 1) + 16)
+            print(json.dumps({"kernel": "dpt_final", "dtype": str(dt).split(".")[-1], "planes": 2 if pair else 1, "views": n_views, "ms": round(ms, 3),
+                              "GBps_algorithmic": round(nbytes / ms / 1e6, 1)}), flush=True)
+
+
 def bench_align(n_views=320, H=512, W=512, pct=85):
     """align_local_pts3d_to_global at the headline shape: HBM-bound.  Algorithmic bytes per view: conf 4 B x (6 radix passes + 1)
     + local/global points 2 x 12 B (moments) + local 12 B + out 12 B (apply) = 76 B per pixel."""
@@ -458,6 +473,8 @@ if __name__ == "__main__":
         bench_gemm(torch.float16, M, 1024, 1024, "proj+res w2", res=True, split="w2")
         bench_gemm(torch.float16, M, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2")
         bench_gemm(torch.float16, M, 1024, 1024, "proj+res x3", res=True, split="x3")
+    if "dptfinal" in args.what:
+        bench_dpt_final()
     if "focal" in args.what:
         bench_focal()
     if "pnp" in args.what:
