@@ -70,11 +70,13 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
   const int fr = lane & 15, fg = lane >> 4;
-  // PAIRED (every role but QKV, whose RoPE needs columns c and c + 16 in one lane): weight rows are handed to the MFMA so that a lane
+  // PAIRED (lowp-output roles; not QKV, whose RoPE needs columns c and c + 16 in one lane): weight rows are handed to the MFMA so that a lane
   // owns 8 consecutive output columns (GemmFragLayout in f3r_gemm_epi.h).  Fragment f of a wave's 32-row W group then reads rows
   // (i/4)*8 + f*4 + i%4 instead of f*16 + i, and the W half tiles use the swizzle key ((r>>1)&1) | (((r>>3)&3)<<1), which is distinct
   // over exactly those 16 rows x 2 parities (the A half tiles keep (r>>1)&7, distinct over 16 consecutive rows).
-  constexpr bool PAIRED = EPI != F3R_EPI_QKV;
+  // Kernels whose additive term is fp32 (x + attn(..), x + mlp(..), the image-id rows) read and write fp32 rows: 4 columns are already 16 B
+  // there, and the unpaired order keeps a store instruction's 64 B per row contiguous (paired, it would write 16-byte pieces 32 B apart).
+  constexpr bool PAIRED = EPI != F3R_EPI_QKV && (ADDSRC == F3R_ADD_NONE || ADDSRC == F3R_ADD_RES_LP);
   static_assert(!(PAIRED && SWAP), "swapped roles exist only in the QKV role");
   auto w_key = [](int r) { return PAIRED ? (((r >> 1) & 1) | (((r >> 3) & 3) << 1)) : ((r >> 1) & 7); };
   uint64_t stamp[5] = {0, 0, 0, 0, 0};
