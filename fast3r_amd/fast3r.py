@@ -1022,9 +1022,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if len(views) == 0:
             return ([], {}) if profiling else []
         if self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder):
-            out = self._graphs.run(self, views)
-            if out is not None:
-                return out
+            dev = views[0]["img"].device
+            if dev.type == "cuda":  # (anything else: the eager path raises its F3RError)
+                with torch.cuda.device(dev):  # capture and replay on the tensors' device, whatever the caller's current device is
+                    out = self._graphs.run(self, views)
+                if out is not None:
+                    return out
         return self._forward_eager(views, profiling)
 
     def enable_graphs(self, on=True, max_views=64):

@@ -4,8 +4,9 @@ with the reference's signature and return type (:1081-1109), plus a batched form
 
 The reference computes, per view on CPU tensors: torch.quantile -> boolean indexing -> 100 Weiszfeld iterations of whole-array torch
 ops (fast3r/dust3r/post_process.py:77-142).  Here a view is one workgroup of one kernel launch (f3r_post.hip::focal_kernel) and all
-views of a scene run side by side.  The PnP pose solve that follows in the reference (cv2.solvePnPRansac, SQPnP) is not part of
-this path yet: `MultiViewDUSt3RLitModule.estimate_camera_poses` still raises NotImplementedError.
+views of a scene run side by side.  The PnP pose solve that follows in the reference (cv2.solvePnPRansac, SQPnP) is fast3r_amd/pose.py
+(`MultiViewDUSt3RLitModule.estimate_camera_poses`).  CPU tensors (what `inference()` returns) are moved to the GPU for the kernel and the
+result comes back on the caller's device.
 """
 import math
 

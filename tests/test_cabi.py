@@ -42,6 +42,9 @@ def test_argument_errors_are_codes_not_crashes(built_lib):
     assert b"Kpad" in built_lib.f3r_last_error_string()
     g.Kpad, g.N = 64, 130  # N % 4 != 0
     assert built_lib.f3r_gemm(ctypes.byref(g), None) == -1
+    g.N, g.out_lp, g.ldo_lp = 128, 0x3000, 1 << 26  # the epilogues address rows with 32-bit byte offsets: strides stay below 2^26 elements
+    assert built_lib.f3r_gemm(ctypes.byref(g), None) == -1
+    assert b"row strides" in built_lib.f3r_last_error_string()
     a = _lib.AttnArgs()
     a.q, a.o, a.n_heads, a.batch, a.tq, a.n_seg = 0x1000, 0x2000, 2, 1, 64, 9
     assert built_lib.f3r_attn_fwd(ctypes.byref(a), None) == -1
