@@ -37,8 +37,13 @@ CASES = {
     # the training-config pair ManyAR_PatchEmbed + landscape_only=True (configs/model/fast3r.yaml:55,77): images are STORED landscape
     # (48 x 64) and `true_shape` says which samples are portrait pictures: view 0 all landscape, view 1 all portrait, view 2 mixed
     "tiny_portrait_b2": (dict(enc_depth=1, patch_embed_cls="ManyAR_PatchEmbed", landscape_only=True), [(48, 64)] * 3, 2, 6, 11, "default"),
+    # encoder_type 'dino_v2' (fast3r.py:79-83,561-651) with the backbone that torch.hub would download replaced by oracle/dino_stub.py (DINOv2's
+    # parameter names, forward_features = our restatement): the reference's DinoEncoder.forward incl. the portrait split, its decoder on
+    # enc_embed_dim features and its DPT heads at patch size 14 (Interpolate 14/8) run for real; the inside of the backbone stays unpinned
+    "tiny_dino_portrait_b2": (dict(patch_embed_cls="dino", enc_depth=2, landscape_only=True), [(56, 70)] * 3, 2, 8, 3, "default"),
 }
-TRUE_SHAPES = {"tiny_portrait_b2": [[[48, 64], [48, 64]], [[64, 48], [64, 48]], [[64, 48], [48, 64]]]}
+TRUE_SHAPES = {"tiny_portrait_b2": [[[48, 64], [48, 64]], [[64, 48], [64, 48]], [[64, 48], [48, 64]]],
+               "tiny_dino_portrait_b2": [[[56, 70], [56, 70]], [[70, 56], [70, 56]], [[70, 56], [56, 70]]]}
 
 
 def views_for(shapes, batch, seed=1000, true_shapes=None):
@@ -59,7 +64,15 @@ def main(only=None):
         if only and name not in only:
             continue
         enc, dec, head = tiny_args(**kw)
-        model = Fast3R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head)).eval()
+        hub_load = torch.hub.load
+        if enc["encoder_type"] == "dino_v2":  # no network: hand the reference a local backbone instead of the download (oracle/dino_stub.py)
+            from oracle.dino_stub import DinoStub
+            torch.hub.load = lambda *a, **k: DinoStub(embed_dim=enc["embed_dim"], depth=enc["depth"], num_heads=enc["num_heads"],
+                                                      mlp_ratio=enc["mlp_ratio"], pos_grid=enc["pos_grid"])
+        try:
+            model = Fast3R(copy.deepcopy(enc), copy.deepcopy(dec), copy.deepcopy(head)).eval()
+        finally:
+            torch.hub.load = hub_load
         shp = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         model.load_state_dict(synth_state_dict(shp, wseed, wdist), strict=True)
         views = views_for(shapes, batch, true_shapes=TRUE_SHAPES.get(name))

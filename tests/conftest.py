@@ -12,9 +12,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The CPU oracle (torch fp32) is the checker of most GPU tests.  On the GPU boxes torch defaults to one thread per hardware thread
     # (256): the ViT-L oracle then runs ~100x SLOWER than at 32 threads (measured: 239 s vs 2.2 s per 512x512 view), which turned the
-    # GPU suite into 15 minutes of CPU oversubscription.  Cap it.
+    # GPU suite into 15 minutes of CPU oversubscription.  Cap it at the count bench.py's cpu_baseline sweep finds fastest on those boxes
+    # (8 threads 2.2 s per view, 16 -> 1.35, 32 -> 1.73).
     import torch
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")

@@ -203,12 +203,12 @@ def test_gemm_qkv_epilogue(built_lib, dt, n_seq, gh, gw, D, use_rope):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("rows_per_group", [24, 1])
-def test_gemm_qkv_rope_by_row_group(built_lib, dt, rows_per_group):
+@pytest.mark.parametrize("rows_per_group,n_groups,D,sel", [(24, 5, 128, 0), (1, 5, 128, 0), (24, 30, 256, 2), (1, 30, 256, 2), (24, 30, 256, 1)])
+def test_gemm_qkv_rope_by_row_group(built_lib, dt, rows_per_group, n_groups, D, sel):
     """rope_mode 1 (LlamaDecoder): one angle set per row group, complex pairs (2j, 2j+1) of the reference (llama.py:96-122) realised
     as a row permutation of the q / k weights + the half-split rotation of the epilogue.  Scores q . k must be those of the reference."""
     from fast3r_amd.fast3r import _ROPE_PERM
-    n_groups, D, K = 5, 128, 128
+    K = 128  # (D = 256, sel = 2: the 256-tile kernel, interior and edge sub-tiles of M = 720)
     M = n_groups * 24
     a = rnd((M, K), dt, 21)
     wq, wk, wv = (rnd((D, K), dt, 22 + i, K ** -0.5) for i in range(3))
@@ -220,7 +220,7 @@ def test_gemm_qkv_rope_by_row_group(built_lib, dt, rows_per_group):
     q = torch.empty((M, D), dtype=dt, device=DEV)
     k = torch.empty((M, D), dtype=dt, device=DEV)
     vt = torch.zeros((1, D, ops.vt_ld(M)), dtype=dt, device=DEV)
-    ops.gemm_qkv(a.to(DEV), wp, None, q, k, vt, M, (cos.to(DEV), sin.to(DEV), rows_per_group), rope_mode=1)
+    ops.gemm_qkv(a.to(DEV), wp, None, q, k, vt, M, (cos.to(DEV), sin.to(DEV), rows_per_group), rope_mode=1, kernel_sel=sel)
 
     def ref_rot(w):  # reference arithmetic in fp64: view_as_complex on adjacent pairs, times cis(angle of the row's group)
         x = (a.double() @ w.double().t()).reshape(M, D // 64, 32, 2)
@@ -230,8 +230,9 @@ def test_gemm_qkv_rope_by_row_group(built_lib, dt, rows_per_group):
     rq, rk = ref_rot(wq), ref_rot(wk)
     assert_close(q.float().cpu()[:, torch.argsort(perm)], rq, lp_tol(dt), "q (un-permuted)")
     assert_close(k.float().cpu()[:, torch.argsort(perm)], rk, lp_tol(dt), "k (un-permuted)")
-    sc = (q.float().cpu().reshape(M, 2, 64).transpose(0, 1) @ k.float().cpu().reshape(M, 2, 64).transpose(0, 1).transpose(1, 2))
-    sc_ref = rq.reshape(M, 2, 64).transpose(0, 1) @ rk.reshape(M, 2, 64).transpose(0, 1).transpose(1, 2)
+    nh = D // 64
+    sc = (q.float().cpu().reshape(M, nh, 64).transpose(0, 1) @ k.float().cpu().reshape(M, nh, 64).transpose(0, 1).transpose(1, 2))
+    sc_ref = rq.reshape(M, nh, 64).transpose(0, 1) @ rk.reshape(M, nh, 64).transpose(0, 1).transpose(1, 2)
     assert_close(sc, sc_ref, 4 * lp_tol(dt), "scores are permutation invariant")
     assert_close(vt[0, :, :M].float().cpu().t(), a.double() @ wv.double().t(), lp_tol(dt), "v^T")
 
