@@ -1,6 +1,6 @@
 """align_local_pts3d_to_global (reference fast3r/models/multiview_dust3r_module.py:427-549).
-The reference function is not importable and its solver lives in the un-vendored, un-pinned `roma` package (not installable: no
-network), so the row cannot be pinned on the reference's own outputs.  Its pin is an INDEPENDENT closed form of the same least-squares
+Its solver lives in the un-vendored, un-pinned `roma` package (not installable: no network).  The reference METHOD is run for real around a
+stand-in for it (oracle/roma_stub.py; last section of this file); the solver's pin is an INDEPENDENT closed form of the same least-squares
 problem -- Horn's unit-quaternion solution in float64 (oracle/align_pin.py) -- against which both the oracle restatement (Umeyama /
 SVD) and the HIP path (raw fp64 moments + Jacobi SVD) are checked, on exact, noisy, mirrored and planar clouds; plus construction
 properties of the oracle (CPU, below) and HIP path == oracle on the same inputs (GPU): quantile thresholds bit-exact vs
@@ -248,3 +248,39 @@ def test_hip_alignment_matches_the_independent_pin(built_lib):
         assert abs(sg - float(s)) < 2e-6 * float(s) and float((tg - t).abs().max()) < 1e-5, name
         ref = (s * xf.double() @ R.t() + t).view(1, 20, 20, 3)
         assert float((got[0]["pts3d_local_aligned_to_global"].double().cpu() - ref).abs().max()) < 2e-5 * float(ref.abs().max()), name
+
+
+# ------------------------------------------------------------------------------------------------ the reference's method, run for real
+# tests/golden/align_cases.pt (oracle/make_golden_align.py): MultiViewDUSt3RLitModule.align_local_pts3d_to_global imported from the
+# reference checkout and run unmodified -- torch.quantile threshold, `conf >= thr & valid_mask`, both fall-backs, the application to every
+# pixel -- with `roma` (not installable) replaced by oracle/roma_stub.py (Horn's quaternion closed form in float64).
+def _align_cases():
+    import os
+    return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "align_cases.pt"), weights_only=False)["cases"]
+
+
+def _max_rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def test_oracle_matches_the_reference_method():
+    for c in _align_cases():
+        out = align_oracle([{k: v.clone() for k, v in p.items()} for p in c["preds"]], c["views"], min_conf_thr_percentile=c["pct"])
+        for v, (o, ref) in enumerate(zip(out, c["aligned"])):
+            assert o["pts3d_local_aligned_to_global"].shape == ref.shape
+            assert _max_rel(o["pts3d_local_aligned_to_global"], ref) <= 2e-5, (c["name"], v)
+    # the fall-backs were really taken: view 3 of pct85_b2 has one valid pixel -> identity (reference :501-506)
+    c = [c for c in _align_cases() if c["name"] == "pct85_b2"][0]
+    assert torch.equal(c["aligned"][3], c["preds"][3]["pts3d_local"])
+    assert not torch.equal(c["aligned"][2], c["preds"][2]["pts3d_local"])  # 5 valid pixels, none confident: solved on valid_mask only (:488-497)
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_reference_method(built_lib):
+    from fast3r_amd import align_local_pts3d_to_global
+    for c in _align_cases():
+        views = [{k: v.cuda() for k, v in vw.items()} for vw in c["views"]]
+        got = align_local_pts3d_to_global(_to_gpu(c["preds"]), views, min_conf_thr_percentile=c["pct"])
+        for v, (o, ref) in enumerate(zip(got, c["aligned"])):
+            a = o["pts3d_local_aligned_to_global"].cpu()
+            assert a.shape == ref.shape and _max_rel(a, ref) <= 3e-5, (c["name"], v, _max_rel(a, ref))
