@@ -211,7 +211,7 @@ def load_images(folder_or_list, size, square_ok=False, verbose=True, rotate_cloc
             geo = Geometry(pic.size, size, square_ok, crop_to_landscape)
             if geo.pre_crop is not None:
                 pic = pic.crop(geo.pre_crop)
-            pixels = torch.from_numpy(np.asarray(pic)).to(dev)  # (h, w, 3) uint8: the only upload of this picture
+            pixels = torch.from_numpy(np.array(pic)).to(dev)  # (h, w, 3) uint8 (a writable copy of the decoder's buffer): the only upload of this picture
             pixels = resize_u8(pixels, geo.resized[0], geo.resized[1], geo.filter, table_cache)
             tensor = img_norm_crop(pixels, geo.box)
             h_out, w_out = tensor.shape[-2:]

@@ -119,3 +119,42 @@ def test_geometry_plan_equals_the_reference_arithmetic():
     for (w, h), size, sq, crop in itertools.product(sizes, [224, 512, 384], [False, True], [False, True]):
         g = Geometry((w, h), size, sq, crop)
         assert (g.pre_crop, g.resized, g.filter, tuple(g.box)) == reference(w, h, size, sq, crop), (w, h, size, sq, crop)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's function, run for real
+# tests/golden/load_images_cases.json (oracle/make_golden_images.py): fast3r.dust3r.utils.image.load_images imported from the reference
+# checkout and run unmodified on deterministic PNG files (real Pillow; torchvision's ToTensor / Normalize through oracle/torchvision_stub.py):
+# per returned view shape, true_shape, idx / instance and the SHA-256 of the float32 image.
+def _load_images_fixture():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "load_images_cases.json")))
+
+
+def test_recipe_restatement_equals_the_reference_function(tmp_path):
+    """CPU: the PIL + numpy recipe the other tests use as their yardstick reproduces the reference function's bytes (size 512 calls)."""
+    from oracle.make_golden_images import digest, write_pictures
+    write_pictures(str(tmp_path))
+    fix = _load_images_fixture()
+    for case in fix["cases"]:
+        kw = case["kwargs"]
+        if set(kw) - {"size", "square_ok"} or kw["size"] == 224:
+            continue
+        for i, v in enumerate(case["views"]):
+            ref, ts = _reference_recipe(str(tmp_path / f"im{i:02d}.png"), kw["size"], kw.get("square_ok", False))
+            assert list(ref.shape) == v["shape"] and ts.tolist() == v["true_shape"]
+            assert digest(torch.from_numpy(ref)) == v["sha256"], (kw, i)
+
+
+@pytest.mark.gpu
+def test_load_images_equals_the_reference_function_bit_for_bit(built_lib, tmp_path):
+    from fast3r_amd.image import load_images
+    from oracle.make_golden_images import digest, write_pictures
+    write_pictures(str(tmp_path))
+    fix = _load_images_fixture()
+    for case in fix["cases"]:
+        out = load_images(str(tmp_path), verbose=False, **case["kwargs"])
+        assert len(out) == len(case["views"])
+        for o, v in zip(out, case["views"]):
+            assert list(o["img"].shape) == v["shape"] and np.asarray(o["true_shape"]).tolist() == v["true_shape"], (case["kwargs"], v)
+            assert o["idx"] == v["idx"] and o["instance"] == v["instance"] and o["img"].dtype == torch.float32
+            assert digest(o["img"]) == v["sha256"], (case["kwargs"], v["idx"])
