@@ -183,9 +183,6 @@ def bench_lab(M, N, K):
                           "tflops_nominal": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
 
 
-PAIRED_STORE_EXPERIMENT = 0
-
-
 def bench_labtime(M, N, K, act=None, bits=128):
     """Where a 256 x 256 output tile spends its time (lab bit 128: s_memtime stamps of wave 0 of every workgroup)."""
     from fast3r_amd import _lib
@@ -201,7 +198,6 @@ def bench_labtime(M, N, K, act=None, bits=128):
 
     def patched(argp, stream):
         argp._obj.rope_cos = dbg.data_ptr()  # unused by the generic epilogue: carries the stamp buffer
-        argp._obj.reserved1 = PAIRED_STORE_EXPERIMENT
         return orig(argp, stream)
     L.f3r_gemm = patched
     try:
@@ -217,7 +213,7 @@ def bench_labtime(M, N, K, act=None, bits=128):
     seg = [(d[:, i + 1] - d[:, i]).mean().item() for i in range(4)]
     tot = (d[:, 4] - d[:, 0]).mean().item()
     rounds = -(-tiles // 256)
-    print(json.dumps({"kernel": "gemm256_lab stamps", "bits": bits, "paired": PAIRED_STORE_EXPERIMENT, "M": M, "N": N, "K": K, "act": act, "ms": round(ms, 3), "tiles": tiles, "rounds_of_256": rounds,
+    print(json.dumps({"kernel": "gemm256_lab stamps", "bits": bits, "M": M, "N": N, "K": K, "act": act, "ms": round(ms, 3), "tiles": tiles, "rounds_of_256": rounds,
                       "ticks_kernel_span": span, "ticks_per_tile_mean": tot, "prologue": seg[0], "main_loop": seg[1], "epilogue_issue": seg[2],
                       "store_retire": seg[3], "ticks_per_us": round(span / (ms * 1e3), 1),
                       "frac": {k: round(v / tot, 3) for k, v in zip(("prologue", "main_loop", "epilogue_issue", "store_retire"), seg)}}), flush=True)
@@ -426,13 +422,6 @@ if __name__ == "__main__":
             bench_attn(dt, nv, variants)
         bench_attn(torch.float16, 20, variants[:3])
         bench_attn_encoder(dt, 64, variants)
-    if args.what == "labpaired":
-        M = 40 * 1024
-        for PAIRED_STORE_EXPERIMENT in (0, 1):
-            globals()["PAIRED_STORE_EXPERIMENT"] = PAIRED_STORE_EXPERIMENT
-            bench_labtime(M, 4096, 1024)
-            bench_labtime(8 * M, 4096, 1024)
-        sys.exit(0)
     if args.what == "labtime":
         M = 40 * 1024
         for bits in (128, 384, 640):
