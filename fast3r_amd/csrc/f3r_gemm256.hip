@@ -1,479 +1,8 @@
-// f3r_gemm256: the large-shape path of f3r_gemm -- out = epilogue(A(M,K) * W(N,K)^T) on a 256 x 256 x 64 tile for gfx950.
-//
-// One 512-thread workgroup (8 waves, 2 per SIMD) per CU, 128 KiB of LDS: two K-tile buffers of four 16 KiB HALF TILES each
-// (A rows 0-127 / 128-255, W rows 0-127 / 128-255; [128 rows][64 k] 16-bit, 128-byte rows, 16-byte chunk c of row r stored at chunk
-// c ^ ((r >> 1) & 7): every ds_read_b128 lane group covers the 64 banks exactly once).  Waves are 2 (M) x 4 (N); a wave owns 128 x 64
-// outputs = 8 x 4 fragments of v_mfma_f32_16x16x32 (128 fp32 accumulator registers), taken as rows wm*64..+63 of BOTH A half tiles and
-// columns wn*32..+31 of BOTH W half tiles: an output quadrant (A half mh, W half nh) then touches exactly one A and one W half tile, every
-// half tile is read in ONE phase of the K-tile by all waves, and its LDS slot is free for the next load two phases later.
-//
-// Schedule (cdna_hip_programming.md "256^2 8-phase", re-derived here because every wait below is placed by counting):
-//   * a K-tile is 4 PHASES, one 64 x 32 output quadrant x K = 64 each (16 MFMAs); quadrants (A0,W0) (A1,W0) (A1,W1) (A0,W1) keep
-//     both A halves in registers: 12 / 8 / 4 / 0 ds_read_b128 per phase = 24 per 64 MFMAs (0.375 per MFMA);
-//   * all global -> LDS traffic is LDS-DMA (global_load_lds, 16 B per lane, no staging registers), ONE half tile (2 instructions per
-//     wave) per phase, each issued 5-6 phases (~1.5 K-tiles, ~3000 cycles: HBM latency under load) before the phase that reads it:
-//         phase 0 of tile t:  A half 1 of tile t+1        phase 1:  W half 1 of tile t+1
-//         phase 2          :  A half 0 of tile t+2        phase 3:  W half 0 of tile t+2
-//     with s_waitcnt vmcnt(8) in phases 0, 1 and 3: the DMA queue is never drained in the loop, FOUR half tiles stay in flight across
-//     the barriers, and what each wait retires is exactly the half tile the NEXT phase reads;
-//   * the two wave rows (wm = 0 / 1, one wave of each per SIMD) run STAGGERED by one barrier: while one does its 16 MFMAs (s_setprio 1)
-//     the other issues its ds_reads and LDS-DMA, so the matrix pipe and the LDS / TA pipes alternate owners instead of colliding;
-//   * every phase is  [ds_reads, LDS-DMA, (vmcnt)] s_barrier [lgkmcnt(0), 16 MFMA] s_barrier.
-// Hazards, with the stagger (a wave of row 1 is one barrier behind a wave of row 0):
-//   RAW  LDS-DMA data may be read one phase after the phase whose FIRST barrier follows the issuers' vmcnt wait;
-//   WAR  a half tile may be re-staged two phases after the phase that issued its last read.  Reads: A0, W0 in phase 0, A1 in phase 1, W1
-//        in phase 2.  Restaged: A0 in phase 2, W0 in phase 3, A1 in phase 0 of the next tile (other buffer: 3 phases), W1 in phase 1.
-//
-// Operand roles, epilogues, the split-precision K segments and the LDS swizzle are those of f3r_gemm.hip; the implicit-GEMM 3x3
-// convolution stages its operand by LDS-DMA too: out-of-image taps read a 16-byte zero line instead of being predicated.
-#include "f3r_common.h"
-#include "f3r_gemm_epi.h"
+// f3r_gemm256: the large-shape path of f3r_gemm -- host-side selection + the fp16 instantiations of f3r_gemm256_impl.h
+// (the bf16 ones live in f3r_gemm256_bf16.hip so that the two halves compile in parallel).
+#include "f3r_gemm256_impl.h"
 
-__device__ __attribute__((aligned(128))) uint32_t f3r_zero_line[32];  // 128 B of zeros: the source of every padded conv tap
-
-namespace {
-
-constexpr int BM = 256, BK = 64, NT = 512;
-constexpr int HT = 128 * 64;          // elements of a half tile
-// NH = W half tiles per K-tile: 2 -> 256 x 256 outputs, two K-tile buffers (128 KiB); 1 -> 256 x 128 outputs (the 128-channel
-// convolutions of the DPT head and every N that is an odd multiple of 128), three K-tile buffers of 3 half tiles (144 KiB)
-template <int NH> struct TileCfg {
-  static constexpr int BN = 128 * NH;
-  static constexpr int BUF = (2 + NH) * HT;          // A_h0 A_h1 W_h0 [W_h1]
-  static constexpr int NBUF = NH == 2 ? 2 : 3;
-  static constexpr int LDS_BYTES = NBUF * BUF * 2;   // 131072 / 147456
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-template <int V>
-struct IC {
-  static constexpr int value = V;
-};
-
-#define F3R_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))   /* vmcnt(n), n <= 15; lgkmcnt / expcnt untouched */
-#define F3R_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)      /* lgkmcnt(0); vmcnt untouched */
-
-// LAB (tools/lab builds only, -DF3R_GEMM_LAB; 0 in the product): ablation / alternative bits measured by tools/kernel_bench.py --what lab
-//   1 no LDS-DMA in the loop   2 no fragment reads in the loop   4 no MFMAs   8 no vmcnt wait   16 no s_setprio
-//   32 buffer_load ... lds through a buffer descriptor instead of global_load_lds   64 no sched_barrier pinning of the load section
-//   256 / 512 de-phased start: the first round of workgroups starts (wg/8) % 2 resp. % 4 halves / quarters of a tile time late, so the
-//   epilogue store bursts of the CUs of an XCD no longer coincide
-//   128 s_memtime stamps of wave 0 (entry, main loop start, main loop end, epilogue issued, stores retired) -> (uint64*)p.rope_cos [wg][5]
-// (1, 2, 4, 8 compute garbage by construction: timing only)
-template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0>
-__device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, int64_t m0, int n0) {
-  constexpr int BUF = TileCfg<NH>::BUF;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-  // PAIRED (lowp-output roles; not QKV, whose RoPE needs columns c and c + 16 in one lane): weight rows are handed to the MFMA so that a lane
-  // owns 8 consecutive output columns (GemmFragLayout in f3r_gemm_epi.h).  Fragment f of a wave's 32-row W group then reads rows
-  // (i/4)*8 + f*4 + i%4 instead of f*16 + i, and the W half tiles use the swizzle key ((r>>1)&1) | (((r>>3)&3)<<1), which is distinct
-  // over exactly those 16 rows x 2 parities (the A half tiles keep (r>>1)&7, distinct over 16 consecutive rows).
-  // Kernels whose additive term is fp32 (x + attn(..), x + mlp(..), the image-id rows) read and write fp32 rows: 4 columns are already 16 B
-  // there, and the unpaired order keeps a store instruction's 64 B per row contiguous (paired, it would write 16-byte pieces 32 B apart).
-  constexpr bool PAIRED = EPI != F3R_EPI_QKV && (ADDSRC == F3R_ADD_NONE || ADDSRC == F3R_ADD_RES_LP);
-  static_assert(!(PAIRED && SWAP), "swapped roles exist only in the QKV role");
-  auto w_key = [](int r) { return PAIRED ? (((r >> 1) & 1) | (((r >> 3) & 3) << 1)) : ((r >> 1) & 7); };
-  uint64_t stamp[5] = {0, 0, 0, 0, 0};
-  if (LAB & 128) stamp[0] = __builtin_amdgcn_s_memtime();
-  if ((LAB & (256 | 512)) && blockIdx.x < 256) {
-    const int PH = (LAB & 512) ? 4 : 2;
-    const int phase = (blockIdx.x >> 3) & (PH - 1);
-    const int n = phase * (p.Kpad / BK) * (4 / PH);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(15);
-  }
-
-  // ------------------------------------------------------------------ K segments (split precision) and tile counts
-  const int nseg = p.split == F3R_SPLIT_NONE ? 1 : (p.split == F3R_SPLIT_W2 ? 2 : 3);
-  const int Kpad1 = p.split == F3R_SPLIT_NONE ? p.Kpad : p.Kpad / 2;
-  const int nk1 = Kpad1 / BK;
-  const int nk = nseg * nk1;
-  const int ctiles = A_MODE == F3R_A_CONV3X3 ? p.conv_C / 64 : 1;
-
-  // ------------------------------------------------------------------ LDS-DMA source addressing
-  // wave w, instruction i of a half tile: rows (w*2 + i)*8 + lane/8, physical chunk lane%8 <- logical chunk (lane%8) ^ ((row>>1)&7)
-  uint32_t a_off[2][2], w_off[2][2];  // byte offsets of this lane's 16 B inside the tile's operand panel [half][i]
-  uint32_t a_msk[2][2];               // CONV: bit tap = the tap of this lane's pixel lies inside the image
-  const char* const Ab = (const char*)p.A;
-  const char* const Alo = (const char*)p.A_lo;
-  const char* const Wb = (const char*)p.W + (int64_t)n0 * p.Kpad * 2;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((r >> 1) & 7);
-      int n = n0 + (h < NH ? h : 0) * 128 + r;
-      if (n >= p.N) n = p.N - 1;
-      w_off[h][i] = (uint32_t)(((int64_t)(n - n0) * p.Kpad + ((lane & 7) ^ w_key(r)) * 8) * 2);
-      int64_t m = m0 + h * 128 + r;
-      if (A_MODE == F3R_A_PLAIN) {
-        if (m >= p.M) m = p.M - 1;
-        a_off[h][i] = (uint32_t)(((m - m0) * p.lda + lc * 8) * 2);
-        a_msk[h][i] = 0;
-      } else {
-        const bool ok = m < p.M;
-        const int64_t per_img = (int64_t)p.conv_OH * p.conv_OW;
-        const int64_t mm = ok ? m : 0;
-        const int b = (int)(mm / per_img);
-        const int rem = (int)(mm % per_img);
-        const int oy = rem / p.conv_OW, ox = rem - oy * p.conv_OW;
-        a_off[h][i] = (uint32_t)(((((int64_t)b * p.conv_H + oy) * p.conv_W + ox) * p.conv_C + lc * 8) * 2);
-        uint32_t msk = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-          if (ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W) msk |= 1u << tap;
-        }
-        a_msk[h][i] = msk;
-      }
-    }
-
-  // cursors: which K-tile the NEXT A / W half-tile pair is loaded for (wave-uniform; clamped at the last tile, see the loop tail)
-  int a_seg = 0, a_kk = 0, a_tap = 0, a_ct = 0, a_t = 0;
-  int w_seg = 0, w_kk = 0, w_t = 0;
-  auto a_advance = [&]() {
-    if (a_t + 1 < nk) {
-      ++a_t; ++a_kk; ++a_ct;
-      if (a_ct == ctiles) { a_ct = 0; ++a_tap; }
-      if (a_kk == nk1) { a_kk = 0; a_tap = 0; a_ct = 0; ++a_seg; }
-    }
-  };
-  auto w_advance = [&]() {
-    if (w_t + 1 < nk) {
-      ++w_t; ++w_kk;
-      if (w_kk == nk1) { w_kk = 0; ++w_seg; }
-    }
-  };
-  bool in_loop = false;  // LAB only
-  auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
-    if ((LAB & 1) && in_loop) return;
-    const char* plane = (a_seg == 2) ? Alo : Ab;
-    uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
-    if (A_MODE == F3R_A_PLAIN) {
-      const char* base = plane + (m0 * p.lda + (int64_t)a_kk * BK) * 2;
-      if (LAB & 32) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(plane + m0 * p.lda * 2), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)a_off[h][i], a_kk * BK * 2, 0, 0);
-        return;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + a_off[h][i]), (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
-    } else {
-      const int dy = a_tap / 3 - 1, dx = a_tap - (a_tap / 3) * 3 - 1;
-      const char* base = plane + (((int64_t)dy * p.conv_W + dx) * p.conv_C + a_ct * 64) * 2;
-      const char* zl = (const char*)f3r_zero_line;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char* src = ((a_msk[h][i] >> a_tap) & 1u) ? base + a_off[h][i] : zl;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
-      }
-    }
-  };
-  auto issue_w = [&](int h, int buf) {
-    if ((LAB & 1) && in_loop) return;
-    const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
-    uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
-    if (LAB & 32) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)w_off[h][i], ((w_seg == 1 ? Kpad1 : 0) + w_kk * BK) * 2, 0, 0);
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + w_off[h][i]), (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
-  };
-
-  // ------------------------------------------------------------------ fragment read addressing (elements inside a half tile)
-  const int sw = (fr >> 1) & 7;
-  const int w_row = wn * 32 + (PAIRED ? (fr >> 2) * 8 + (fr & 3) : fr);  // fragment nf adds nf * (PAIRED ? 4 : 16) rows: same key
-  int a_rd[2], w_rd[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    a_rd[ks] = (wm * 64 + fr) * 64 + (((ks * 4 + fg) ^ sw) << 3);
-    w_rd[ks] = w_row * 64 + (((ks * 4 + fg) ^ w_key(w_row)) << 3);
-  }
-
-  float4v acc[16 * NH];
-  typename T::vec8 fa0[2][4], fa1[2][4], fw[2][2];
-
-  auto read_a = [&](typename T::vec8 (&f)[2][4], int buf, int mh) {
-    if ((LAB & 2) && in_loop) return;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
-        f[ks][mf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[ks] + mf * 16 * 64));
-  };
-  auto read_w = [&](int buf, int nh) {
-    if ((LAB & 2) && in_loop) return;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * (PAIRED ? 4 : 16) * 64));
-  };
-  auto mma = [&](const typename T::vec8 (&f)[2][4], int mh, int nh) {
-    if (LAB & 4) return;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          const int NF = nh * 2 + nf, MF = mh * 4 + mf;
-          if (SWAP) acc[MF * (2 * NH) + NF] = T::mfma16(f[ks][mf], fw[ks][nf], acc[MF * (2 * NH) + NF]);
-          else      acc[NF * 8 + MF] = T::mfma16(fw[ks][nf], f[ks][mf], acc[NF * 8 + MF]);
-        }
-  };
-
-  // one K-tile out of buffer B (compile-time), 4 phases
-#define F3R_PHASE_MMA(FA, MH, NH)                        \
-  __builtin_amdgcn_sched_barrier(0);                     \
-  __builtin_amdgcn_s_barrier();                          \
-  F3R_LGKMCNT0();                                        \
-  __builtin_amdgcn_sched_barrier(0);                     \
-  if (!(LAB & 16)) __builtin_amdgcn_s_setprio(1);        \
-  mma(FA, MH, NH);                                       \
-  if (!(LAB & 16)) __builtin_amdgcn_s_setprio(0);        \
-  __builtin_amdgcn_sched_barrier(0);                     \
-  __builtin_amdgcn_s_barrier();
-  auto tile = [&](auto bufc) {
-    constexpr int B = decltype(bufc)::value;
-    // ---- phase 0: quadrant (A0, W0); A half 1 of the next tile; retire what phase 1 reads (A half 1 of this tile)
-    read_w(B, 0);
-    if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
-    read_a(fa0, B, 0);
-    issue_a(1, B ^ 1);
-    a_advance();
-    if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa0, 0, 0)
-    // ---- phase 1: quadrant (A1, W0); W half 1 of the next tile; retire W half 1 of this tile (phase 2 reads it)
-    read_a(fa1, B, 1);
-    issue_w(1, B ^ 1);
-    w_advance();
-    if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa1, 1, 0)
-    // ---- phase 2: quadrant (A1, W1); A half 0 two tiles ahead (its slot was last read in phase 0)
-    read_w(B, 1);
-    issue_a(0, B);
-    F3R_PHASE_MMA(fa1, 1, 1)
-    // ---- phase 3: quadrant (A0, W1); W half 0 two tiles ahead; retire A half 0 and W half 0 of the next tile (its phase 0 reads them)
-    issue_w(0, B);
-    if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa0, 0, 1)
-  };
-  // NH == 1 (256 x 128 outputs): a K-tile is 2 phases -- quadrants (A0, W) and (A1, W), 16 MFMAs each -- and 3 half tiles; three
-  // buffers, tile t in buffer t % 3.  Reads: A0 and W in phase 0, A1 in phase 1; a slot is restaged two phases after its read:
-  //     phase 0 of tile t:  A half 0 + W of tile t+2, then vmcnt(10) (retires A half 1 of tile t, read in phase 1)
-  //     phase 1          :  A half 1 of tile t+2,     then vmcnt(8)  (retires A half 0 + W of tile t+1, read in its phase 0)
-  // i.e. every half tile is issued 3 phases before the wait that retires it.
-  auto tile1 = [&](auto bufc) {
-    constexpr int B = decltype(bufc)::value;
-    constexpr int B2 = (B + 2) % 3;
-    read_w(B, 0);
-    if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
-    read_a(fa0, B, 0);
-    issue_a(0, B2);
-    issue_w(0, B2);
-    w_advance();
-    if (!(LAB & 8)) F3R_VMCNT(10);
-    F3R_PHASE_MMA(fa0, 0, 0)
-    read_a(fa1, B, 1);
-    issue_a(1, B2);
-    a_advance();
-    if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa1, 1, 0)
-  };
-#undef F3R_PHASE_MMA
-
-  // ------------------------------------------------------------------ prologue
-  // The bias and the additive epilogue terms (fp32 / lowp residuals, image-id rows) are loaded FIRST, straight into the accumulators:
-  // they land under the latency of the first tiles (f3r_gemm_epi.h); the compiler's own wait covers their first use.
-  typedef GemmFragLayout<2 * NH, 8, 2, 4, PAIRED> Frag;  // 2 fragments from each W half, 4 fragments from each A half
-  const int64_t m_base = m0 + wm * 64;
-  const int n_base = n0 + wn * 32;
-  gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
-  if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
-    issue_a(0, 0);
-    issue_w(0, 0);
-    issue_a(1, 0);
-    a_advance();
-    issue_w(1, 0);
-    w_advance();
-    issue_a(0, 1);
-    issue_w(0, 1);
-    F3R_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed; the four younger half tiles stay in flight
-  } else {                  // tiles 0 and 1
-    issue_a(0, 0);
-    issue_w(0, 0);
-    w_advance();
-    issue_a(1, 0);
-    a_advance();
-    issue_a(0, 1);
-    issue_w(0, 1);
-    w_advance();
-    issue_a(1, 1);
-    a_advance();
-    F3R_VMCNT(8);  // A half 0 and W of tile 0 have landed
-  }
-  __builtin_amdgcn_s_barrier();
-  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
-  if (LAB & 128) stamp[1] = __builtin_amdgcn_s_memtime();
-
-  if constexpr (NH == 2) {
-    if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
-      tile(IC<0>{});
-      if (nk > 1) tile(IC<1>{});
-      in_loop = true;
-    }
-    for (int t = LAB ? 2 : 0; t < nk; t += 2) {
-      tile(IC<0>{});
-      if (t + 1 < nk) tile(IC<1>{});
-    }
-  } else {
-    for (int t = 0; t < nk; t += 3) {
-      tile1(IC<0>{});
-      if (t + 1 < nk) tile1(IC<1>{});
-      if (t + 2 < nk) tile1(IC<2>{});
-    }
-  }
-  // Past the last tile the cursors stay clamped, so the tail re-loads the last tile into half tiles nobody reads any more; drain them
-  // before the workgroup's LDS can be handed to the next one.
-  F3R_VMCNT(0);
-  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
-  if (LAB & 128) stamp[2] = __builtin_amdgcn_s_memtime();
-
-  // ------------------------------------------------------------------ epilogue
-  if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
-  else gemm_epilogue_default<T, EPI, Frag, false>(p, acc, m_base, n_base, lane);
-  if (LAB & 128) {
-    __builtin_amdgcn_sched_barrier(0);
-    stamp[3] = __builtin_amdgcn_s_memtime();
-    F3R_VMCNT(0);
-    stamp[4] = __builtin_amdgcn_s_memtime();
-    if (tid == 0) {
-      uint64_t* d = (uint64_t*)p.rope_cos + (int64_t)blockIdx.x * 5;
-      for (int i = 0; i < 5; ++i) d[i] = stamp[i];
-    }
-  }
-}
-
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
-__global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  constexpr int BN = TileCfg<NH>::BN;
-  // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous run of tiles, and
-  // inside the run walk GM m-tiles x all n-tiles with m fastest, so the ~32 tiles an XCD runs at once share 8 A panels and all of W
-  // through its private 4 MiB L2.
-  const int n_tiles_n = (p.N + BN - 1) / BN;
-  const int64_t n_tiles_m = (p.M + BM - 1) / BM;
-  const int64_t n_wg = n_tiles_m * n_tiles_n;
-  int64_t wg = blockIdx.x;
-  {
-    const int64_t q = n_wg / 8, r = n_wg % 8;
-    const int64_t xcd = wg % 8, idx = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GM = 8;
-  const int64_t per_group = (int64_t)GM * n_tiles_n;
-  const int64_t grp = wg / per_group;
-  const int64_t first_m = grp * GM;
-  const int gm = (int)((n_tiles_m - first_m) < GM ? (n_tiles_m - first_m) : GM);
-  const int64_t rem_ = wg - grp * per_group;
-  const int tn = (int)(rem_ / gm);
-  const int64_t tm = first_m + rem_ % gm;
-  const int64_t m0 = tm * BM;
-  const int n0 = tn * BN;
-  if constexpr (EPI == F3R_EPI_QKV) {
-    if (n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3))) {  // the V part: swapped operand roles, V^T epilogue
-      gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
-      return;
-    }
-  }
-  gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
-}
-
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
-int launch256(const f3r_gemm_args& a, hipStream_t stream) {
-  static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH>;
-  constexpr int LDS_BYTES = TileCfg<NH>::LDS_BYTES, BN = TileCfg<NH>::BN;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
-  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, a);
-  return f3r_check_launch("f3r_gemm(256)");
-}
-
-// 256-wide tiles when N fills them; 128-wide tiles when N is an odd multiple of 128 (no half-empty tile) -- QKV needs the wide tile
-inline int tile_halves(const f3r_gemm_args& a) { return (a.N % 256 == 0 || a.epi == F3R_EPI_QKV) ? 2 : 1; }
-
-template <class T>
-int dispatch256(const f3r_gemm_args& a, hipStream_t stream, int stagger) {
-#define F3R_L256H(AM, EP, AD, NHV) (stagger ? launch256<T, AM, EP, 1, AD, NHV>(a, stream) : launch256<T, AM, EP, 0, AD, NHV>(a, stream))
-#define F3R_L256(AM, EP, AD) (nh == 2 ? F3R_L256H(AM, EP, AD, 2) : F3R_L256H(AM, EP, AD, 1))
-  const int add = gemm_additive_pattern(a);
-  const int nh = tile_halves(a);
-  if (a.a_mode == F3R_A_CONV3X3) return add == F3R_ADD_RES_LP ? F3R_L256(F3R_A_CONV3X3, F3R_EPI_GENERIC, F3R_ADD_RES_LP) : F3R_L256(F3R_A_CONV3X3, F3R_EPI_GENERIC, F3R_ADD_NONE);
-  switch (a.epi) {
-    case F3R_EPI_GENERIC:
-      return add == F3R_ADD_RES_F32 ? F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_RES_F32)
-           : add == F3R_ADD_ROWADD ? F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_ROWADD) : F3R_L256(F3R_A_PLAIN, F3R_EPI_GENERIC, F3R_ADD_NONE);
-    case F3R_EPI_QKV: return F3R_L256H(F3R_A_PLAIN, F3R_EPI_QKV, F3R_ADD_NONE, 2);
-    default: return F3R_L256(F3R_A_PLAIN, F3R_EPI_CONVT, F3R_ADD_NONE);
-  }
-#undef F3R_L256
-#undef F3R_L256H
-}
-
-#ifdef F3R_GEMM_LAB
-template <class T, int LAB>
-__global__ __launch_bounds__(NT, 1) void gemm256_lab_kernel(const f3r_gemm_args p) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  constexpr int BN = 256;
-  const int n_tiles_n = (p.N + BN - 1) / BN;
-  const int64_t wg = blockIdx.x;
-  gemm256_body<T, F3R_A_PLAIN, F3R_EPI_GENERIC, false, 1, F3R_ADD_NONE, 2, LAB>(p, smem, (wg / n_tiles_n) * BM, (int)(wg % n_tiles_n) * BN);
-}
-template <class T, int LAB>
-int launch_lab(const f3r_gemm_args& a, hipStream_t stream) {
-  auto kern = gemm256_lab_kernel<T, LAB>;
-  constexpr int BN = 256, LDS_BYTES = TileCfg<2>::LDS_BYTES;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, a);
-  return f3r_check_launch("f3r_gemm(256 lab)");
-}
-#endif
-
-}  // namespace
-
-// Measurement builds only: kernel_sel = 16 + LAB bits (bf16, plain operand, generic epilogue, no additive terms)
-int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream) {
-#ifdef F3R_GEMM_LAB
-  switch (a.kernel_sel - 16) {
-#define F3R_LAB_CASE(n) case n: return launch_lab<BF16, n>(a, stream);
-    F3R_LAB_CASE(0) F3R_LAB_CASE(1) F3R_LAB_CASE(2) F3R_LAB_CASE(3) F3R_LAB_CASE(4) F3R_LAB_CASE(7) F3R_LAB_CASE(8) F3R_LAB_CASE(16)
-    F3R_LAB_CASE(32) F3R_LAB_CASE(33) F3R_LAB_CASE(64) F3R_LAB_CASE(96) F3R_LAB_CASE(128) F3R_LAB_CASE(256) F3R_LAB_CASE(512) F3R_LAB_CASE(384) F3R_LAB_CASE(640)
-#undef F3R_LAB_CASE
-  }
-#endif
-  f3r_set_error("f3r_gemm: kernel_sel %d is not available in this build", a.kernel_sel);
-  return F3R_ERR_ARG;
-}
+int f3r_gemm256_run_bf16(const f3r_gemm_args& a, hipStream_t stream, int stagger);  // f3r_gemm256_bf16.hip
 
 // Whether the 256-tile kernel takes this (already validated) problem: everything its LDS-DMA staging cannot express -- K tails, ragged
 // channel counts, strided or pre-activated conv operands, small or narrow outputs -- stays on the 128-tile kernel.
@@ -513,5 +42,5 @@ int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger) 
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + 127) / 128);
   if (tiles <= 0) return F3R_OK;
   F3R_REQUIRE(tiles < (1ll << 31), "f3r_gemm: grid too large");
-  return a.dtype == F3R_F16 ? dispatch256<F16>(a, stream, stagger) : dispatch256<BF16>(a, stream, stagger);
+  return a.dtype == F3R_F16 ? dispatch256<F16>(a, stream, stagger) : f3r_gemm256_run_bf16(a, stream, stagger);
 }

@@ -27,6 +27,24 @@ def test_oracle_matches_golden(name):
             assert rel_l2(o[k], g[k]) < TOL, (name, k, rel_l2(o[k], g[k]))
 
 
+@pytest.mark.parametrize("name", ["tiny_hot_3x64", "tiny_mixed"])
+def test_oracle_fused_attention_equals_the_written_out_form(name):
+    """ATTN_IMPL = "sdpa" (F.scaled_dot_product_attention, blocks.py:171-179 -- what bench.py's cpu_baseline and the 20 480-token parity test
+    run) is the same function as the written-out softmax (blocks.py:158-169) that produced the goldens, to fp32 summation order."""
+    fix = load_golden(name)
+    enc, dec, head, sd, views = golden_model_inputs(fix)
+    impl = O.ATTN_IMPL
+    try:
+        O.ATTN_IMPL = "sdpa"
+        torch.manual_seed(fix["rng_seed"])
+        out = O.forward(views, sd, enc, dec, head)
+    finally:
+        O.ATTN_IMPL = impl
+    for o, g in zip(out, fix["preds"]):
+        for k in g:
+            assert rel_l2(o[k], g[k]) < TOL, (name, k, rel_l2(o[k], g[k]))
+
+
 def test_oracle_image_ids_match_reference_recipe():
     fix = load_golden("tiny_3x64")
     torch.manual_seed(fix["rng_seed"])
