@@ -31,12 +31,9 @@ bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
   return true;
 }
 
-// Whether the 256-tile kernel is also the FASTER choice: one workgroup per CU, so below ~3/4 of a round of tiles (256 CUs) the 128-tile
-// kernel (2 workgroups per CU, 4x the tiles) fills the chip better (measured: 462 vs 545 TF at 128 tiles).
-bool f3r_gemm256_preferred(const f3r_gemm_args& a) {
-  const int bn = tile_halves(a) == 2 ? 256 : 128;
-  return ((a.M + BM - 1) / BM) * ((a.N + bn - 1) / bn) >= 192;
-}
+// Whether the 256-tile kernel (in the tile form tile_halves picks) is also the FASTER choice: one workgroup per CU, so with few tiles or
+// an unlucky tail round the 128-tile kernel (2 workgroups per CU, 4x the tiles) fills the chip better -- see tile_score.
+bool f3r_gemm256_preferred(const f3r_gemm_args& a) { return score_256(a, tile_halves(a)) >= score_128(a); }
 
 int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger) {
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + 127) / 128);

@@ -421,7 +421,26 @@ int launch256(const f3r_gemm_args& a, hipStream_t stream) {
 }
 
 // 256-wide tiles when N fills them; 128-wide tiles when N is an odd multiple of 128 (no half-empty tile) -- QKV needs the wide tile
-inline int tile_halves(const f3r_gemm_args& a) { return (a.N % 256 == 0 || a.epi == F3R_EPI_QKV) ? 2 : 1; }
+// Which tile form fills the 256 CUs best.  score = (fraction of the last round's slots that do work, over all rounds) x (relative
+// main-loop efficiency of the form: 256x256 1.0, 256x128 0.82, 128x128 with two workgroups per CU 0.72 -- tools/kernel_bench.py
+// --what gemmsmall / gemm, profiles/r02_kernel_microbench_gemm_small.jsonl).  E.g. 8 views (M = 8192, N = 1024): 128 tiles of 256^2 = half a
+// round (0.50), 256 tiles of 256x128 = one full round (0.82), 512 tiles of 128^2 = one full round (0.72) -> 256x128.
+inline float tile_score(int64_t tiles, int slots, float eff) {
+  if (tiles <= 0) return 0.f;
+  const int64_t rounds = (tiles + slots - 1) / slots;
+  return eff * (float)tiles / (float)(rounds * slots);
+}
+inline float score_256(const f3r_gemm_args& a, int nh) {
+  return tile_score(((a.M + 255) / 256) * ((a.N + 128 * nh - 1) / (128 * nh)), 256, nh == 2 ? 1.0f : 0.82f);
+}
+inline float score_128(const f3r_gemm_args& a) { return tile_score(((a.M + 127) / 128) * ((a.N + 127) / 128), 512, 0.72f); }
+
+inline int tile_halves(const f3r_gemm_args& a) {
+  if (a.epi == F3R_EPI_QKV) return 2;
+  if (a.N % 256 != 0 || a.kernel_sel == 4) return 1;
+  if (a.kernel_sel == 2 || a.kernel_sel == 3) return 2;
+  return score_256(a, 1) > score_256(a, 2) ? 1 : 2;
+}
 
 template <class T>
 int dispatch256(const f3r_gemm_args& a, hipStream_t stream, int stagger) {

@@ -137,8 +137,8 @@ typedef struct f3r_gemm_args {
      F3R_SPLIT_X3: A_hi.W_hi + A_hi.W_lo + A_lo.W_hi.  With split != 0, W is [N][2][Kpad/2] (plane 0 = hi, plane 1 = lo; Kpad is still
      the row stride, K the real depth of ONE plane) and, for X3, A_lo is the low plane of A (same layout / strides as A). */
   int32_t split;     /* f3r_split */
-  int32_t kernel_sel; /* 0 = pick the kernel by shape; 1 = 128x128-tile kernel; 2 / 3 = 256x256-tile kernel with / without staggered wave rows
-                         (measurement only: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
+  int32_t kernel_sel; /* 0 = pick the kernel by shape; 1 = 128x128-tile kernel; 2 / 3 = 256x256-tile kernel with / without staggered wave rows;
+                         4 = its 256x128 tile form (measurement only: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
   const void* A_lo;
   /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
      their high planes.  Same leading dimensions as the high planes. */

@@ -2,7 +2,8 @@
 
 Reference = torch fp64 on CPU on the SAME 16-bit-rounded operands (single-plane cases) or on the UNROUNDED fp32 operands (split
 cases: there the claim is that hi + lo planes recover fp32-class accuracy).  Every case runs the 128-tile kernel (kernel_sel 1) and
-both schedules of the 256-tile kernel (2 = staggered wave rows, 3 = lock-step): all three must agree with the reference, and the
+both schedules of the 256-tile kernel (2 = staggered wave rows, 3 = lock-step) plus its 256 x 128 tile form (4; by shape it takes N = odd
+multiples of 128 and the launches whose 256 x 256 tiles would leave CUs idle): all must agree with the reference, and the
 shapes include ragged M / N, every epilogue the model uses on this path, and K-tile counts that are odd (the loop runs two tiles per
 iteration) and minimal (one tile).
 """
@@ -16,7 +17,7 @@ from fast3r_amd import ops
 from test_kernels_gpu import DEV, DTYPES, _rope_ref, assert_close, lp_tol, rnd
 
 pytestmark = pytest.mark.gpu
-SELS = [1, 2, 3]
+SELS = [1, 2, 3, 4, 0]  # 0 = the kernel and tile form f3r_gemm picks by shape
 
 
 @pytest.mark.parametrize("dt", DTYPES)

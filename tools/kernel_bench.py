@@ -122,7 +122,7 @@ def bench_attn_encoder(dt, views, variants, H=16):
     lab_lib().f3r_attn_set_variant(-1)
 
 
-SEL_NAME = {1: "128-tile", 2: "256-tile staggered", 3: "256-tile lock-step"}
+SEL_NAME = {1: "128-tile", 2: "256-tile staggered", 3: "256-tile lock-step", 4: "256x128-tile"}
 
 
 def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
@@ -407,6 +407,12 @@ if __name__ == "__main__":
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
+    if args.what == "gemmsmall":  # scenes of 3 - 40 views: which tile form fills 256 CUs best
+        for M in (3072, 8192, 20480, 40960):
+            bench_gemm(dt, M, 1024, 1024, f"proj+res M={M}", res=True, sels=(1, 2, 4))
+            bench_gemm(dt, M, 1024, 4096, f"fc2+res M={M}", res=True, sels=(1, 2, 4))
+            bench_gemm(dt, M, 4096, 1024, f"fc1+gelu M={M}", act="gelu", out="lp", sels=(1, 2, 4))
+        sys.exit(0)
     if args.what == "attnproduct":
         for nv in [int(v) for v in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):

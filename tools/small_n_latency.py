@@ -9,10 +9,13 @@ from fast3r_amd.synthetic import make_views, synth_state_dict, vit_large_args
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", default="2,3,8,20")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+ap.add_argument("--precision", default="fast", choices=["fast", "high"])
+ap.add_argument("--no-graph", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda")
 enc, dec, head = vit_large_args()
-model = Fast3R(enc, dec, head, compute_dtype=torch.bfloat16).eval()
+model = Fast3R(enc, dec, head, compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16, precision=args.precision).eval()
 model.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0), strict=True)
 model = model.to(dev)
 
@@ -35,7 +38,9 @@ with torch.no_grad():
             v["img"] = v["img"].to(dev)
         model.enable_graphs(False)
         eager = timed(lambda: model(views), args.iters)
-        model.enable_graphs(True, max_views=max(64, n))
-        graph = timed(lambda: model(views), args.iters)
-        print(json.dumps({"views": n, "eager_ms": round(eager, 2), "graph_ms": round(graph, 2), "eager_views_per_s": round(n / eager * 1e3, 1),
+        graph = float("nan")
+        if not args.no_graph:
+            model.enable_graphs(True, max_views=max(64, n))
+            graph = timed(lambda: model(views), args.iters)
+        print(json.dumps({"views": n, "dtype": args.dtype, "precision": args.precision, "eager_ms": round(eager, 2), "graph_ms": round(graph, 2), "eager_views_per_s": round(n / eager * 1e3, 1),
                           "graph_views_per_s": round(n / graph * 1e3, 1)}), flush=True)
