@@ -101,6 +101,9 @@ class F3RError(RuntimeError):
     pass
 
 
+ABI_VERSION = 200  # f3r_version() of include/f3r.h this file mirrors
+
+
 def lib():
     """Load (once) and return the shared library.  Raises loudly if it is missing: there is no CPU path."""
     global _lib
@@ -116,6 +119,8 @@ def lib():
         if l.f3r_sizeof(0) != ctypes.sizeof(GemmArgs) or l.f3r_sizeof(1) != ctypes.sizeof(AttnArgs):
             raise F3RError("fast3r_amd/_lib.py struct layout does not match include/f3r.h "
                            f"(gemm {l.f3r_sizeof(0)} vs {ctypes.sizeof(GemmArgs)}, attn {l.f3r_sizeof(1)} vs {ctypes.sizeof(AttnArgs)})")
+        if l.f3r_version() < ABI_VERSION:
+            raise F3RError(f"{LIB_PATH} is version {l.f3r_version()}, this host code needs >= {ABI_VERSION}: rebuild it (fast3r_amd/csrc/build.sh)")
         _lib = l
     return _lib
 

@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);
+int f3r_version(void);  /* 200 = 0.2.0, the round-2 ABI (split-precision planes, kv_group / causal attention, block workspace) */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
