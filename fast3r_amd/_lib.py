@@ -87,6 +87,8 @@ SYMBOLS = {
     "f3r_imgnorm_u8": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_silu_mul": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_rows_add_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
+    "f3r_rope2d_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
+    "f3r_attn_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, _c_vp]),
 }

@@ -503,15 +503,18 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                       "high": split-precision operands (f3r.h f3r_split) -- transformer weights as hi + lo planes (2 MFMA passes per
                       GEMM), both operands of the DPT heads as hi + lo planes (3 passes, activations kept as two planes in HBM);
                       attention unchanged.  With fp16 this brings the stress fixture inside 1e-3 of the fp32 reference (DESIGN.md
-                      section 4, oracle/precision_study.py) at ~1.15x the time of "fast" at N=320."""
+                      section 4, oracle/precision_study.py) at ~1.15x the time of "fast" at N=320.
+                      "exact": what `inference(dtype="32")` means in the reference (no autocast): BOTH operands of every GEMM / conv as
+                      hi + lo planes (~22 significand bits each, 3 MFMA passes), the attention core in plain fp32 (f3r_attn_f32).  A
+                      validation mode for scenes of tens of views; CroCo / DINOv2 encoder + Fast3R decoder on one GPU only."""
 
     def __init__(self, encoder_args: dict, decoder_args: dict, head_args: dict, freeze="none",
                  compute_dtype: torch.dtype = torch.float16, precision: str = "fast"):
         super().__init__()
         if isinstance(compute_dtype, str):  # config.json round trip stores the dtype as text
             compute_dtype = getattr(torch, compute_dtype.replace("torch.", ""))
-        if precision not in ("fast", "high"):
-            raise ValueError(f"precision must be 'fast' or 'high', got {precision!r}")
+        if precision not in ("fast", "high", "exact"):
+            raise ValueError(f"precision must be 'fast', 'high' or 'exact', got {precision!r}")
         self.encoder_args = dict(encoder_args)
         self.build_encoder(encoder_args)
         self.decoder_args = dict(decoder_args)
@@ -655,6 +658,20 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         step change it, so packed (device, 16-bit) weights and captured graphs built from older values are never reused."""
         return sum(p._version for p in self.parameters())
 
+    @property
+    def _hp(self):
+        """split (hi + lo) weight planes and head activations: "high" and "exact"."""
+        return self.precision in ("high", "exact")
+
+    @property
+    def _sp(self):
+        """split mode of the transformer's linear layers: weights only ("w2") in "high", both operands ("x3") in "exact"."""
+        return {"fast": None, "high": "w2", "exact": "x3"}[self.precision]
+
+    def _pair(self, x_f32):
+        """fp32 -> (hi, lo) lowp planes."""
+        return ops.cast_lp(x_f32, self.compute_dtype, want_lo=True)
+
     def _pack(self, device):
         lp = self.compute_dtype
         key = (lp, self.precision, str(device), self._params_version())
@@ -669,7 +686,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             self._graphs.clear()
         self._packed_alt = self._packed
         enc, dec = self.encoder, self.decoder
-        hp = self.precision == "high"
+        hp = self._hp
         pk = dict(key=key)
         if isinstance(enc, DinoEncoder):
             vit = enc.model
@@ -714,6 +731,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single.
         ws: the pass's BlockWorkspace (made here when absent): no per-layer allocation."""
         lp = self.compute_dtype
+        if self.precision == "exact":
+            return self._block_exact(x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange)
         sp = "w2" if self.precision == "high" else None
         D = x.shape[1]
         T = x.shape[0]
@@ -759,9 +778,29 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split=sp)
         return x
 
+    def _block_exact(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange):
+        """precision "exact": the same block with every operand as hi + lo planes and fp32 attention.  LayerNorm -> fp32 -> planes; QKV
+        through the generic epilogue into an fp32 [T][3D] buffer (+ RoPE-2D in place); f3r_attn_f32 -> planes; proj / fc1 (+GELU, planes
+        out) / fc2 as X3 GEMMs with the fp32 residual epilogue."""
+        if kv_exchange is not None or pb.rms or pb.swiglu_hidden or pb.kv_group > 1 or pb.causal:
+            raise NotImplementedError("precision='exact' covers the CroCo / DINOv2 encoders and the Fast3R decoder on one GPU")
+        lp = self.compute_dtype
+        _, hf = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, want_lp=False, want_f32=True)
+        h, hl = self._pair(hf)
+        qkv, _ = ops.gemm(h, pb.qkv_w, bias=pb.qkv_b, want_f32=True, split="x3", a_lo=hl)
+        if rope is not None:
+            ops.rope2d_f32(qkv, n_heads, seq_len, rope)
+        o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp)
+        ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split="x3", a_lo=ol)
+        _, hf = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, want_lp=False, want_f32=True, out_f32=hf)
+        h, hl = self._pair(hf)
+        _, hid, hid_lo = ops.gemm(h, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, want_lo=True, split="x3", a_lo=hl)
+        ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split="x3", a_lo=hid_lo)
+        return x
+
     def _planes(self, x_f32):
         """fp32 -> the operand format of the DPT heads: (hi, lo) planes in "high" precision, (lowp, None) otherwise."""
-        if self.precision == "high":
+        if self._hp:
             return ops.cast_lp(x_f32, self.compute_dtype, want_lo=True)
         return ops.cast_lp(x_f32, self.compute_dtype), None
 
@@ -789,8 +828,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         upright images: patch embedding (k = s = 14) + [cls] + resized position table, the ViT blocks (no RoPE; LayerScale folded into
         the packed weights), final LayerNorm, patch tokens only.  Same return convention as _encode."""
         lp = self.compute_dtype
-        hp = self.precision == "high"
-        sp = "w2" if hp else None
+        hp, sp = self._hp, self._sp
         vit = self.encoder.model
         NV, _, H, W = imgs.shape
         ps, D = vit.patch_size, vit.embed_dim
@@ -806,7 +844,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             v1 = min(NV, v0 + step)
             n = v1 - v0
             a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp, ld_out=kpad)
-            tok, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], res_f32=pos_rows.repeat(n, 1), want_f32=True, split=sp)
+            tok, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], res_f32=pos_rows.repeat(n, 1), want_f32=True, split=sp,
+                              a_lo=self._patch_lo(imgs[v0:v1], ps, kpad))
             x = torch.empty((n, 1 + P, D), dtype=torch.float32, device=imgs.device)  # [cls | patches] per image
             x[:, 0] = cls_row
             x[:, 1:] = tok.view(n, P, D)
@@ -825,14 +864,21 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 out[v0 * P:v1 * P].view(n, P, D).copy_(y.view(n, 1 + P, D)[:, 1:])
         return out, out_lo, P, (h, w)
 
+    def _patch_lo(self, imgs, ps, ld_out):
+        """precision "exact": the low plane of the im2col rows = the im2col rows of the image's low plane (patchify only moves and rounds:
+        its output is lowp(img), so lowp(img - lowp(img)) patchified is exactly the remainder plane); None otherwise."""
+        if self.precision != "exact":
+            return None
+        _, lo = ops.cast_lp(imgs.contiguous(), self.compute_dtype, want_lo=True)
+        return ops.patchify(lo.float(), ps, self.compute_dtype, ld_out=ld_out)
+
     def _encode(self, imgs, pk):
         """CroCoEncoder.forward (fast3r.py:549-559) for a batch of same-size images -> enc_norm output [NV*P][D] as (lowp, low plane or
         None).  The high plane alone feeds decoder_embed; both planes are hook 0 of the heads in "high" precision."""
         if isinstance(self.encoder, DinoEncoder):
             return self._encode_dino(imgs, pk)
         lp = self.compute_dtype
-        hp = self.precision == "high"
-        sp = "w2" if hp else None
+        hp, sp = self._hp, self._sp
         enc = self.encoder
         NV, _, H, W = imgs.shape
         ps = enc.patch_size
@@ -847,7 +893,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         for v0 in range(0, NV, step):
             v1 = min(NV, v0 + step)
             a = ops.patchify(imgs[v0:v1].contiguous(), ps, lp)
-            x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True, split=sp)
+            x, _ = ops.gemm(a, pk["pe_w"], bias=pk["pe_b"], want_f32=True, split=sp, a_lo=self._patch_lo(imgs[v0:v1], ps, 0))
             ws = self._block_ws(pk["enc"][0], x.shape[0], enc.embed_dim, v1 - v0, P, imgs.device)
             for pb in pk["enc"]:
                 self._block(x, pb, enc.num_heads, (enc.embed_dim // enc.num_heads) ** -0.5, P, v1 - v0, rope, ws=ws)
@@ -870,7 +916,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         to the heads' operand format (decode_tokens: parity of the decoder alone)."""
         dec = self.decoder
         lp = self.compute_dtype
-        sp = "w2" if self.precision == "high" else None
+        sp = self._sp
+        a_lo = enc_lo if sp == "x3" else None  # "exact": decoder_embed reads both planes of the encoder tokens
         dev = enc_hi.device
         L = dec.depth
         llama = isinstance(dec, LlamaDecoder)
@@ -882,7 +929,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
         ws = self._block_ws(pk["dec"][0], T_loc, D, 1, T_loc, dev)  # one allocation for the intermediates of all L blocks
         planes = (lambda t: (t.clone(), None)) if f32_hooks else self._planes
-        want_f32_norm = f32_hooks or self.precision == "high"
+        want_f32_norm = f32_hooks or self._hp
+        if llama and self.precision == "exact":
+            raise NotImplementedError("precision='exact' covers the CroCo / DINOv2 encoders and the Fast3R decoder on one GPU")
         if llama:
             # embed; per layer add view0_embed to the tokens of view 0, then the block with the rotary angles of each token's view;
             # outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
@@ -911,12 +960,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     taps[L] = (ops.layernorm(x, w_, None, eps, lp, rms=True)[0], None)
         else:
             if len(set(Ps)) == 1:
-                ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo:v_lo + n_loc].contiguous(), rowadd_div=Ps[0], out_f32=x, split=sp)
+                ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo:v_lo + n_loc].contiguous(), rowadd_div=Ps[0], out_f32=x, split=sp,
+                         a_lo=a_lo)
             else:
                 r0 = 0
                 for i in range(n_loc):
                     ops.gemm(enc_hi[r0:r0 + Ps[i]], pk["de_w"], bias=pk["de_b"], rowadd=emb_rows[v_lo + i:v_lo + i + 1].contiguous(),
-                             rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]], split=sp)
+                             rowadd_div=Ps[i], out_f32=x[r0:r0 + Ps[i]], split=sp, a_lo=None if a_lo is None else a_lo[r0:r0 + Ps[i]])
                     r0 += Ps[i]
             taps = {0: (enc_hi.float(), None) if f32_hooks else (enc_hi, enc_lo)}
             for li, pb in enumerate(pk["dec"]):
@@ -945,7 +995,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             assert ids.numel() == len(tokens_per_view)
             emb_rows = self.decoder.image_idx_emb.to(dev)[ids]
             enc_lo = None
-            if self.precision == "high" and not isinstance(self.decoder, LlamaDecoder):
+            if self._hp and not isinstance(self.decoder, LlamaDecoder):
                 enc_lo = torch.zeros_like(enc_tokens)
             out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None, f32_hooks=return_f32)
             return [t[0] for t in out]
@@ -957,7 +1007,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         each in "high" precision, every conv then runs split="x3"); accumulation fp32.  A ResidualConvUnit reads relu(x) for its first
         conv and x for its skip add (dpt_block.py:143-154): the PRODUCER of x writes both (f3r_gemm_args.out_relu), so no conv
         pre-activates its operand while staging it and all of them can use LDS-DMA."""
-        hp = self.precision == "high"
+        hp = self._hp
         sp = "x3" if hp else None
         ld = hk.dims
 

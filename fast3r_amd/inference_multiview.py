@@ -7,10 +7,15 @@ demo passes -- silently falls through to the *default* autocast dtype (SURVEY.md
 selects the operand format of the HIP kernels:
     "16-mixed" / torch.float16                                     fp16 operands, the model's `precision`
     "bf16-mixed" / "bf16-mixed-no-grad-scaling" / torch.bfloat16   bf16 operands, the model's `precision`
-    "32" / torch.float32                                           the closest thing this path has to fp32: fp16 operands with
-                                                                   precision="high" (split hi + lo planes, ~22 significand bits on the
-                                                                   weights and in the heads) -- NOT an fp32 MFMA
-                                                                   path; a one-time warning says so
+    "32" / 32                                                      precision="exact": both operands of every GEMM / conv as fp16
+                                                                   hi + lo planes (~22 significand bits), attention in plain fp32 --
+                                                                   ~1e-6 of the reference's fp32 path, a validation mode (slow: no
+                                                                   16-bit attention).  Models it does not cover (LlamaDecoder, view
+                                                                   sharding) run precision="high" instead, with a warning
+    torch.float32                                                  (in the reference: NOT fp32 but the default autocast dtype, SURVEY.md
+                                                                   section 0.3) fp16 operands with precision="high" (split weights,
+                                                                   split head operands, fp16 attention); a
+                                                                   one-time warning says so
     anything else                                                  the model's own compute_dtype / precision
 Accumulation, residual stream, LayerNorm, softmax and outputs are always fp32; the measured distance of every mode to the
 reference's true-fp32 CPU path is recorded in DESIGN.md.
@@ -75,10 +80,14 @@ def _operand_format(precision, model):
     if precision in ("bf16-mixed", "bf16-mixed-no-grad-scaling", torch.bfloat16):
         return torch.bfloat16, model.precision
     if precision in ("32", 32, torch.float32):
+        from .fast3r import LlamaDecoder
+        exact_ok = precision is not torch.float32 and model.sharding is None and not isinstance(model.decoder, LlamaDecoder)
+        if exact_ok:
+            return torch.float16, "exact"
         if not _warned_fp32:
-            warnings.warn("fast3r_amd.inference(dtype='32'): there is no fp32 MFMA path; running fp16 operands with split hi + lo planes "
-                          "(precision='high': ~22-bit weights and head activations, fp16 attention operands, fp32 accumulation).",
-                          stacklevel=3)
+            warnings.warn(f"fast3r_amd.inference(dtype={precision!r}): running fp16 operands with split hi + lo planes (precision='high': ~22-bit "
+                          "weights and head activations, fp16 attention operands, fp32 accumulation); the fp32-equivalent mode is "
+                          "dtype='32' on an unsharded Fast3R-decoder model (precision='exact').", stacklevel=3)
             _warned_fp32 = True
         return torch.float16, "high"
     return model.compute_dtype, model.precision

@@ -420,6 +420,32 @@ def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.
     return pts, conf
 
 
+def rope2d_f32(qkv, n_heads, seq_len, rope):
+    """precision "exact": RoPE-2D in place on the q and k parts (first 2 * n_heads * 64 columns) of the fp32 qkv[T][3D] buffer;
+    rope = (cos, sin, tokens_per_row) as for gemm_qkv."""
+    require_gpu(qkv, "qkv")
+    assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1
+    check(_lib.lib().f3r_rope2d_f32(ptr(qkv), qkv.shape[0], qkv.stride(0), n_heads, seq_len, int(rope[2]), ptr(rope[0]), ptr(rope[1]), stream_ptr()),
+          "f3r_rope2d_f32")
+    return qkv
+
+
+def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False):
+    """precision "exact": fp32 softmax attention over qkv[T][3D] fp32 (q | k | v column blocks, 64 per head) -> (o_hi, o_lo) lowp planes
+    [T][D] (the A operand of the X3 projection) [, o fp32 with want_f32]."""
+    require_gpu(qkv, "qkv")
+    assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1
+    T, D = qkv.shape[0], n_heads * 64
+    assert qkv.shape[1] == 3 * D and T == n_seq * seq_len
+    o_hi = torch.empty((T, D), dtype=lp, device=qkv.device)
+    o_lo = torch.empty((T, D), dtype=lp, device=qkv.device)
+    o32 = torch.empty((T, D), dtype=torch.float32, device=qkv.device) if want_f32 else None
+    base = qkv.data_ptr()
+    check(_lib.lib().f3r_attn_f32(base, base + D * 4, base + 2 * D * 4, qkv.stride(0), ptr(o_hi), ptr(o_lo), ptr(o32), D, n_seq, seq_len, n_heads,
+                                  float(scale), dtype_id(lp), stream_ptr()), "f3r_attn_f32")
+    return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
+
+
 def cast_lp(x, lp, out=None, want_lo=False):
     """fp32 -> lowp [, low plane lowp(x - float(hi)) with want_lo]."""
     require_gpu(x, "x")

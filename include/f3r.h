@@ -334,6 +334,21 @@ int f3r_imgnorm_u8(const uint8_t* in, float* out, int H, int W, int x0, int y0, 
 int f3r_silu_mul(const void* ab, void* out, int64_t rows, int hidden, int dtype, f3r_stream_t stream);
 int f3r_rows_add_f32(float* x, const float* vec, int64_t rows, int D, f3r_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * precision "exact" -- what `inference(dtype="32")` means in the reference (fast3r/dust3r/inference_multiview.py:41-52: no autocast, fp32
+ * everywhere).  Every GEMM / conv of that mode is f3r_gemm with split = F3R_SPLIT_X3 (both operands as hi + lo planes); the attention
+ * core (blocks.py:158-169) runs in plain fp32 on q / k / v taken from an fp32 buffer -- a validation mode for scenes of tens of views.
+ * f3r_rope2d_f32: RoPE-2D (pos_embed.py:162-183) in place on the q and k parts of qkv[rows][ld] (the first 2 * n_heads * 64 columns);
+ *   tables as in f3r_gemm_args.rope_cos / rope_sin ([n_pos][16]), token t of a sequence sits at (t / rope_w, t % rope_w).
+ * f3r_attn_f32: o[r][h*64 + d] = sum_j softmax_j(q[r] . k[j] * scale) v[j][d] over the keys of r's sequence (n_seq sequences of seq_len
+ *   rows; q, k, v row stride ld floats, 64 floats per head).  Output as fp32 (o_f32) and / or as lowp hi [+ lo] planes ([rows][ldo]), the
+ *   A operand of the X3 projection that follows.
+ */
+int f3r_rope2d_f32(float* qkv, int64_t rows, int64_t ld, int n_heads, int64_t seq_len, int rope_w, const float* rope_cos,
+                   const float* rope_sin, f3r_stream_t stream);
+int f3r_attn_f32(const float* q, const float* k, const float* v, int64_t ld, void* o_hi, void* o_lo, float* o_f32, int64_t ldo,
+                 int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, f3r_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

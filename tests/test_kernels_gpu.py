@@ -499,6 +499,34 @@ def test_gemm_qkv_grouped_query_split(built_lib, dt, M, Hq, Hkv, K, sels):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n_seq,gh,gw,H", [(2, 16, 16, 2), (3, 7, 10, 4), (1, 1, 300, 1)])
+def test_exact_mode_rope_and_fp32_attention(built_lib, dt, n_seq, gh, gw, H):
+    """precision "exact": f3r_rope2d_f32 in place on the q / k parts of an fp32 [T][3D] buffer and f3r_attn_f32 (fp32 softmax attention, hi +
+    lo output planes) vs fp64; sequences of 256 / 70 (ragged key tile and query block) / 300 tokens."""
+    S, D = gh * gw, H * 64
+    T = n_seq * S
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn((T, 3 * D), generator=g)
+    cos, sin = ops.rope_tables(max(gh, gw), 100.0, DEV)
+    buf = qkv.clone().to(DEV)
+    ops.rope2d_f32(buf, H, S, (cos, sin, gw))
+    p = torch.arange(T) % S
+    py, px = p // gw, p % gw
+    rq = _rope_ref(qkv[:, :D].double().reshape(T, H, 64), py, px, cos.cpu(), sin.cpu()).reshape(T, D)
+    rk = _rope_ref(qkv[:, D:2 * D].double().reshape(T, H, 64), py, px, cos.cpu(), sin.cpu()).reshape(T, D)
+    assert_close(buf[:, :D], rq, 2e-6, "rope q")
+    assert_close(buf[:, D:2 * D], rk, 2e-6, "rope k")
+    assert torch.equal(buf[:, 2 * D:].cpu(), qkv[:, 2 * D:])  # v untouched
+    scale = 0.125
+    o_hi, o_lo, o32 = ops.attention_f32(buf, H, n_seq, S, scale, dt, want_f32=True)
+    q64, k64, v64 = (t.reshape(n_seq, S, H, 64).transpose(1, 2) for t in (rq, rk, qkv[:, 2 * D:].double()))
+    ref = (torch.softmax(q64 @ k64.transpose(-1, -2) * scale, dim=-1) @ v64).transpose(1, 2).reshape(T, D)
+    assert_close(o32, ref, 3e-6, "fp32 attention")
+    # hi + lo planes carry the fp32 result to 2^-21 (fp16) / 2^-16 (bf16)
+    assert_close(o_hi.float().cpu().double() + o_lo.float().cpu().double(), ref, 3e-6 if dt == torch.float16 else 3e-5, "hi + lo planes")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_patchify_any_patch_size_and_general_bilinear(built_lib, dt):
     """DINOv2's patch 14: im2col rows zero-padded to a row stride that is a multiple of 8; the head's Interpolate(scale_factor=14/8)."""
     img = torch.rand(2, 3, 28, 42) * 2 - 1
