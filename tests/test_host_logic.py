@@ -95,6 +95,25 @@ def test_no_cpu_fallback():
         inference(make_views(2, 32, 32), lit, "cpu", "32", verbose=False)
 
 
+def test_inference_dtype_argument_selects_the_operand_format():
+    """fast3r_amd/inference_multiview.py::_operand_format against the reference's table (inference_multiview.py:41-52, SURVEY.md 0.3):
+    "32" is the only true-fp32 spelling there -> precision "exact" here; torch.float32 is NOT fp32 there (default autocast dtype)."""
+    import warnings
+    from fast3r_amd.inference_multiview import _operand_format
+    m = Fast3R(*tiny_args(), compute_dtype=torch.bfloat16, precision="fast")
+    assert _operand_format("16-mixed", m) == (torch.float16, "fast") and _operand_format(torch.float16, m) == (torch.float16, "fast")
+    assert _operand_format("bf16-mixed", m) == (torch.bfloat16, "fast") and _operand_format(torch.bfloat16, m) == (torch.bfloat16, "fast")
+    assert _operand_format("32", m) == (torch.float16, "exact") and _operand_format(32, m) == (torch.float16, "exact")
+    assert _operand_format(None, m) == (torch.bfloat16, "fast")  # anything else: the model's own format
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert _operand_format(torch.float32, m) == (torch.float16, "high")
+        llama = Fast3R(*tiny_args(decoder_type="llama"))
+        assert _operand_format("32", llama) == (torch.float16, "high")  # not covered by "exact": the closest mode, with a warning
+    with pytest.raises(ValueError, match="precision"):
+        Fast3R(*tiny_args(), precision="fp32")
+
+
 def test_split_range_is_contiguous_and_balanced():
     for n in (0, 1, 7, 8, 320, 1500):
         for w in (1, 2, 3, 8):
