@@ -143,7 +143,17 @@ class ViewSharding:
         return [int(v) for v in out.cpu().tolist()]
 
     def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None):
-        return KVExchange(self.group, self.world, self.rank, t_loc, self.all_token_counts(t_loc, dev), D, dtype, dev, n_heads, q_dim)
+        """The exchange of one forward pass.  The (tiny) token-count all-gather runs every time -- it is what tells a rank that another
+        rank's shard changed -- but the buffers (2 x world x T_max x D operands + the parked softmax state) are kept between forwards
+        of the same geometry instead of being rebuilt: the local K / V^T rows are fully rewritten by every layer's QKV epilogue and
+        the padding stays zero."""
+        t_all = self.all_token_counts(t_loc, dev)
+        key = (t_loc, tuple(t_all), D, dtype, str(dev), n_heads, q_dim)
+        cache = self.__dict__.setdefault("_kvx_cache", {})
+        if key not in cache:
+            cache.clear()  # one geometry at a time: a different scene releases the previous buffers
+            cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim)
+        return cache[key]
 
     def gather_results(self, results, n_total, dev):
         """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with
