@@ -56,10 +56,12 @@ def views_for(shapes, batch, seed=1000, true_shapes=None):
     return vs
 
 
-def main(only=None):
+def main(only=None, check=False):
+    """check: regenerate in memory and compare with the committed fixtures instead of writing (exit code 1 on a difference)."""
     warnings.filterwarnings("ignore")
     Fast3R, inference = load_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
+    bad = []
     for name, (kw, shapes, batch, wseed, rseed, wdist) in CASES.items():
         if only and name not in only:
             continue
@@ -93,9 +95,20 @@ def main(only=None):
                    preds=[{k: v.clone() for k, v in p.items()} for p in preds],
                    torch_version=torch.__version__)
         path = os.path.join(OUT_DIR, name + ".pt")
+        if check:
+            old = torch.load(path, weights_only=False)
+            same = old["state_shapes"] == shp and all(torch.equal(a[k], b[k]) for a, b in zip(old["preds"], fix["preds"]) for k in b) and \
+                (old["image_ids"] is None) == (ids is None) and (ids is None or torch.equal(old["image_ids"], ids))
+            print(name, "bit-identical to the committed fixture" if same else "DIFFERS from the committed fixture")
+            if not same:
+                bad.append(name)
+            continue
         torch.save(fix, path)
         print(name, os.path.getsize(path) // 1024, "KB", {k: tuple(v.shape) for k, v in preds[0].items()})
+    if bad:
+        sys.exit(1)
 
 
 if __name__ == "__main__":
-    main(set(sys.argv[1:]))  # optional: only the named cases (the others stay as committed)
+    names = set(a for a in sys.argv[1:] if not a.startswith("--"))
+    main(names, check="--check" in sys.argv)  # optional: only the named cases (the others stay as committed)

@@ -74,6 +74,11 @@ def main():
         cases.append(dict(name=name, pct=pct, preds=preds, views=views, aligned=[w["pts3d_local_aligned_to_global"].clone() for w in work]))
         err = max(float((w["pts3d_local_aligned_to_global"] - p["pts3d_in_other_view"]).abs().mean()) for w, p in zip(work, preds))
         print(name, "views", nv, "B", B, "pct", pct, "max mean |aligned - global| =", f"{err:.3f}")
+    if "--check" in sys.argv:  # compare with the committed fixture instead of writing it
+        old = torch.load(OUT, weights_only=False)["cases"]
+        same = len(old) == len(cases) and all(all(torch.equal(x, y) for x, y in zip(a["aligned"], b["aligned"])) for a, b in zip(old, cases))
+        print("align fixture:", "bit-identical to the committed one" if same else "DIFFERS from the committed one")
+        sys.exit(0 if same else 1)
     torch.save(dict(cases=cases, torch_version=torch.__version__), OUT)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB")
 

@@ -50,6 +50,12 @@ def main():
             cases.append(dict(seed=seed, H=H, W=W, true_focal=f, percentile=pct, pts3d=pts, conf=conf, focal=float(out.ravel()[0])))
             print(f"case seed={seed} {H}x{W} pct={pct}: true {f} reference {float(out.ravel()[0]):.6f}")
     out_path = os.path.join(ROOT, "tests", "golden", "focal_cases.pt")
+    if "--check" in sys.argv:  # compare with the committed fixture instead of writing it
+        old = torch.load(out_path, weights_only=False)
+        same = len(old) == len(cases) and all(a["focal"] == b["focal"] and torch.equal(a["pts3d"], b["pts3d"]) and torch.equal(a["conf"], b["conf"])
+                                              for a, b in zip(old, cases))
+        print("focal fixture:", "bit-identical to the committed one" if same else "DIFFERS from the committed one")
+        sys.exit(0 if same else 1)
     torch.save(cases, out_path)
     print("wrote", out_path, os.path.getsize(out_path), "bytes")
 

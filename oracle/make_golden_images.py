@@ -57,7 +57,12 @@ def main():
             cases.append(dict(kwargs=kw, views=[dict(shape=list(v["img"].shape), true_shape=np.asarray(v["true_shape"]).tolist(), idx=v["idx"],
                                                      instance=v["instance"], sha256=digest(v["img"])) for v in views]))
             print(kw, [tuple(v["img"].shape[-2:]) for v in views])
-    json.dump(dict(pictures=PICTURES, cases=cases), open(OUT, "w"), indent=1)
+    new = dict(pictures=[list(p) for p in PICTURES], cases=cases)
+    if "--check" in sys.argv:  # compare with the committed fixture instead of writing it
+        same = json.load(open(OUT)) == json.loads(json.dumps(new))
+        print("load_images fixture:", "identical to the committed one" if same else "DIFFERS from the committed one")
+        sys.exit(0 if same else 1)
+    json.dump(new, open(OUT, "w"), indent=1)
     print("wrote", OUT)
 
 

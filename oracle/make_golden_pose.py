@@ -97,6 +97,14 @@ def main():
         V, B = sc[1], sc[2]
         err = max(float(np.abs(out["first_view_from_global_head"]["poses"][b][v] - gt[v][b].numpy()).max()) for v in range(V) for b in range(B))
         print(sc, "max |pose - gt| =", f"{err:.2e}", "focals", [round(f, 2) for f in out["individual"]["focals"][0]])
+    if "--check" in sys.argv:  # compare with the committed fixture instead of writing it
+        old = torch.load(OUT, weights_only=False)["cases"]
+        same = len(old) == len(cases) and all(
+            all(torch.equal(pa[k], pb[k]) for pa, pb in zip(a["preds"], b["preds"]) for k in pb) and
+            all(np.array_equal(x, y) for m in a["reference"] for sa, sb in zip(a["reference"][m]["poses"], b["reference"][m]["poses"]) for x, y in zip(sa, sb)) and
+            all(a["reference"][m]["focals"] == b["reference"][m]["focals"] for m in a["reference"]) for a, b in zip(old, cases))
+        print("pose fixture:", "bit-identical to the committed one" if same else "DIFFERS from the committed one")
+        sys.exit(0 if same else 1)
     torch.save(dict(cases=cases, torch_version=torch.__version__), OUT)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KB")
 

@@ -79,3 +79,24 @@ def test_oracle_matches_live_reference():
     for o, g in zip(ora, ref):
         for k in g:
             assert rel_l2(o[k], g[k]) < TOL, (k, rel_l2(o[k], g[k]))
+
+
+# ------------------------------------------------------------------------------------------------ fixtures are what the reference returns
+_GENERATORS = ["oracle.make_golden", "oracle.make_golden_focal", "oracle.make_golden_align", "oracle.make_golden_images",
+               pytest.param("oracle.make_golden_pose", marks=pytest.mark.skipif(__import__("os").environ.get("F3R_SLOW_CHECKS") != "1",
+                                                                                reason="4.5 min of numpy RANSAC: set F3R_SLOW_CHECKS=1"))]
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference checkout only exists in the build container")
+@pytest.mark.parametrize("module", _GENERATORS)
+def test_committed_fixtures_are_reproduced_by_the_live_reference(module):
+    """Every fixture under tests/golden/ is the output of reference code run here (forward pass, estimate_focal, align_local_pts3d_to_global,
+    load_images, estimate_camera_poses; un-installable third-party packages behind the stand-ins in oracle/): `python -m <generator>
+    --check` re-runs the reference in a fresh interpreter (the stand-ins replace modules at import time) and compares bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", module, "--check"], cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIFFERS" not in r.stdout
