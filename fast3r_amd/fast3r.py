@@ -1071,7 +1071,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device."""
         if len(views) == 0:
             return ([], {}) if profiling else []
-        if self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder):
+        if (self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
+                and self.precision != "exact"):  # (the validation mode allocates per layer: it always runs eagerly)
             dev = views[0]["img"].device
             if dev.type == "cuda":  # (anything else: the eager path raises its F3RError)
                 with torch.cuda.device(dev):  # capture and replay on the tensors' device, whatever the caller's current device is
