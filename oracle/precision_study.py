@@ -14,7 +14,11 @@ Zones: "tr" = encoder + fusion transformer, "hd" = DPT heads.  A design is {zone
     "f16w2"   weights split hi + lo, activations single fp16
     "f16x3"   both split: a_hi w_hi + a_lo w_hi + a_hi w_lo
     "bf16x3"  same with bf16 pieces (3 x 8 bits; the classic bf16x3 ~ fp32-ish emulation)
+    "f16w2_8" / "f16x3_8"   like f16w2 / f16x3, but the CORRECTION products (a w_lo, a_lo w_hi) have both operands rounded to fp8 e4m3 with a
+              per-tensor power-of-two scale -- what a block-scaled FP8 MFMA (2x the fp16 rate on gfx950) would compute: a candidate for cutting
+              the cost of precision="high" from 2x / 3x to 1.5x / 2x of the 16-bit GEMMs
 """
+import math
 import os
 import sys
 import types
@@ -31,6 +35,15 @@ DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 def rnd(x, dt):
     return x.to(dt).float()
+
+
+def rnd8(x):
+    """fp8 e4m3 with a per-tensor power-of-two scale into its range (max 448; subnormals below 2^-6 of the scaled value)."""
+    m = float(x.abs().max())
+    if m == 0.0:
+        return x
+    sc = 2.0 ** math.floor(math.log2(240.0 / m))
+    return (x * sc).to(torch.float8_e4m3fn).float() / sc
 
 
 def split2(x, dt):
@@ -66,6 +79,14 @@ def _apply(fn, a, w, *rest, **kw):
         ah = rnd(a, dt)
         wh, wl = split2(w, dt)
         out = fn(ah, wh, None, *rest, **kw) + fn(ah, wl, None, *rest, **kw)
+    elif base in ("f16w2_8", "f16x3_8"):
+        dt = torch.float16
+        ah, al = split2(a, dt)
+        wh, wl = split2(w, dt)
+        a1 = ah if base == "f16x3_8" else rnd(a, dt)
+        out = fn(a1, wh, None, *rest, **kw) + fn(rnd8(a1), rnd8(wl), None, *rest, **kw)
+        if base == "f16x3_8":
+            out = out + fn(rnd8(al), rnd8(wh), None, *rest, **kw)
     elif base in ("f16x3", "bf16x3"):
         dt = DT[base[:-2]]
         ah, al = split2(a, dt)
@@ -164,6 +185,9 @@ def main():
         ("f16", "f16+store", None), ("f16", "f16", None), ("f16", "f16x2", None), ("f16", "f16x3", None), ("f16", "f32", None),
         ("f32", "f16", None), ("f32", "bf16", None),
         ("bf16", "f16x3", {"qk": "f16"}), ("bf16", "f32", {"qk": "f16"}), ("bf16", "f32", {"qk": "f16", "pv": "f16"}),
+        # the product's "high" mode and its variations: attention format per product, correction terms in fp8
+        ("f16w2", "f16x3", {"qk": "f16", "pv": "f16"}), ("f16w2", "f16x3", {"qk": "f16", "pv": "bf16"}), ("f16w2", "f16x3", {"qk": "bf16", "pv": "f16"}),
+        ("f16w2_8", "f16x3", {"qk": "f16", "pv": "f16"}), ("f16w2", "f16x3_8", {"qk": "f16", "pv": "f16"}), ("f16w2_8", "f16x3_8", {"qk": "f16", "pv": "f16"}),
     ]
     for dist in ("hot", "default"):
         sd = synth_state_dict(shp, 0, dist)
