@@ -239,3 +239,36 @@ def test_half_and_bfloat16_modules_still_pack():
         blk = pk["dec"][0]
         assert blk.qkv_w.dtype == m.compute_dtype and blk.qkv_b.dtype == torch.float32 and blk.n1w.dtype == torch.float32
         assert torch.isfinite(blk.qkv_w.float()).all() and pk["head"] is not None
+
+
+def test_the_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under fast3r_amd/ imports it, importing the package (and building a model) loads no oracle
+    module, and bench.py reaches it only inside its cpu_baseline leg."""
+    import ast
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        hits = []
+        for node in ast.walk(ast.parse(open(path).read())):
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node.lineno)
+        return hits
+    for f in glob.glob(os.path.join(root, "fast3r_amd", "**", "*.py"), recursive=True):
+        assert oracle_imports(f) == [], f
+    code = ("import sys; import fast3r_amd; from fast3r_amd.synthetic import tiny_args; fast3r_amd.Fast3R(*tiny_args()); "
+            "print([m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')])")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("[]"), r.stdout + r.stderr
+    # bench.py: the only import of the oracle sits inside cpu_baseline()
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        inner = [n for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle"]
+        assert (len(inner) > 0) == (fn.name == "cpu_baseline"), fn.name
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n)]
+    assert top == []
