@@ -272,3 +272,18 @@ def test_the_product_never_touches_the_oracle():
         assert (len(inner) > 0) == (fn.name == "cpu_baseline"), fn.name
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n)]
     assert top == []
+
+
+def test_a_missing_or_stale_library_fails_loudly(tmp_path, monkeypatch):
+    """No silent fallback: without libf3r_hip.so (or with one built for an older ABI) the first kernel call raises F3RError."""
+    from fast3r_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libf3r_hip.so"))
+    with pytest.raises(F3RError, match="not found"):
+        _lib.lib()
+    monkeypatch.undo()
+    real = _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", real.f3r_version() + 1)
+    with pytest.raises(F3RError, match="rebuild"):
+        _lib.lib()
