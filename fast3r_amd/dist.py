@@ -120,6 +120,7 @@ class ViewSharding:
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
         self.gather_outputs = gather_outputs
+        self._kvx_cache = {}  # geometry -> KVExchange (make_kv_exchange)
         if self.world > 8:
             raise ValueError("the attention kernel takes at most 8 K/V segments (one MI355X node)")
 
@@ -149,7 +150,7 @@ class ViewSharding:
         the padding stays zero."""
         t_all = self.all_token_counts(t_loc, dev)
         key = (t_loc, tuple(t_all), D, dtype, str(dev), n_heads, q_dim)
-        cache = self.__dict__.setdefault("_kvx_cache", {})
+        cache = self._kvx_cache
         if key not in cache:
             cache.clear()  # one geometry at a time: a different scene releases the previous buffers
             cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim)
