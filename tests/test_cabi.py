@@ -55,3 +55,18 @@ def test_argument_errors_are_codes_not_crashes(built_lib):
         _lib.check(-1, "x")
     with pytest.raises(_lib.F3RError):
         _lib.check(-3, "x")
+
+
+def test_ctypes_prototypes_have_the_header_arity(built_lib):
+    """Every ctypes prototype in fast3r_amd/_lib.py takes as many arguments as the declaration in include/f3r.h (a drift here is a silent
+    stack mismatch, not an exception)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    decls = re.findall(r"\b(f3r_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    seen = set()
+    for name, params in decls:
+        params = " ".join(params.split())
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert name in _lib.SYMBOLS, name
+        assert len(_lib.SYMBOLS[name][1]) == n, (name, n, len(_lib.SYMBOLS[name][1]))
+        seen.add(name)
+    assert seen == set(_lib.SYMBOLS), set(_lib.SYMBOLS) ^ seen
