@@ -59,6 +59,7 @@ class AttnArgs(ctypes.Structure):
         ("scale", _c_f32), ("q_prescaled", _c_i32),
         ("st_o", _c_vp), ("st_ml", _c_vp), ("state_in", _c_i32), ("state_out", _c_i32),
         ("kv_group", _c_i32), ("causal", _c_i32), ("q_pos0", _c_i64), ("seg_pos0", _c_i64 * F3R_MAX_SEG),
+        ("kernel_sel", _c_i32), ("reserved0", _c_i32),
     ]
 
 
@@ -103,7 +104,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 200  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 300  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():

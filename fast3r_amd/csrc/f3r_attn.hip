@@ -413,7 +413,17 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   if (a.state_in || a.state_out) {
     F3R_REQUIRE(a.st_o && a.st_ml && (((uintptr_t)a.st_o) & 15) == 0 && (((uintptr_t)a.st_ml) & 15) == 0, "f3r_attn_fwd: state buffers null/misaligned");
   }
+  F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 2, "f3r_attn_fwd: kernel_sel %d", a.kernel_sel);
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (a.kernel_sel != 1) {  // the hand-scheduled one-wave-per-SIMD kernel where the launch allows it (include/f3r.h)
+    const char* why = "";
+    const int seg = (a.n_heads < 65536 && a.batch < 65536) ? f3r_attn_asm_segment(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why) : -1;
+    if (seg >= 0) return f3r_attn_asm_launch(a, seg, s);
+    if (a.kernel_sel == 2) {
+      f3r_set_error("f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) but the launch is not eligible: %s", why[0] ? why : "grid too large");
+      return F3R_ERR_UNSUPPORTED;
+    }
+  }
   return a.dtype == F3R_F16 ? attn_launch<F16>(a, s) : attn_launch<BF16>(a, s);
 }

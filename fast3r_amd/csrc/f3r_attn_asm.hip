@@ -1,0 +1,117 @@
+// Host side of the hand-scheduled attention kernel: the code object assembled from csrc/asm/attn_gen.py is embedded in the library
+// (obj/f3r_attn_asm_blob.cpp, written by build.sh), loaded once per device with hipModuleLoadData and launched with
+// hipModuleLaunchKernel on the caller's stream (capturable in a hipGraph like any other launch).  f3r_attn_fwd (f3r_attn.hip)
+// decides per call whether a launch goes here (f3r_attn_args.kernel_sel, include/f3r.h).
+#include <mutex>
+
+#include "f3r_common.h"
+
+extern "C" const unsigned char f3r_attn_asm_hsaco[];
+extern "C" const unsigned int f3r_attn_asm_hsaco_len;
+
+namespace {
+
+// kernel argument block: the ARG_* offsets of csrc/asm/attn_gen.py
+struct f3r_attn_asm_args {
+  const void* q;
+  const void* k;
+  const void* vt;
+  void* o;
+  uint32_t ldq_b, ldk_b, ldvt_b, ldo_b;  // row strides in bytes
+  uint32_t n_tiles, flags;
+  uint64_t q_bs, k_bs, vt_bs, o_bs;      // batch strides in bytes
+  uint32_t kv_shift, pad;
+};
+static_assert(sizeof(f3r_attn_asm_args) == 96, "must match ARG_SIZE of attn_gen.py");
+
+constexpr int MAX_DEV = 16;
+struct DevKernels {
+  bool tried = false;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn[2] = {nullptr, nullptr};  // F3R_F16, F3R_BF16
+};
+DevKernels g_dev[MAX_DEV];
+std::mutex g_mu;
+
+hipFunction_t get_fn(int dtype) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  DevKernels& d = g_dev[dev];
+  if (!d.tried) {
+    d.tried = true;
+    if (hipModuleLoadData(&d.mod, f3r_attn_asm_hsaco) == hipSuccess) {
+      if (hipModuleGetFunction(&d.fn[F3R_F16], d.mod, "f3r_attn_asm_f16") != hipSuccess) d.fn[F3R_F16] = nullptr;
+      if (hipModuleGetFunction(&d.fn[F3R_BF16], d.mod, "f3r_attn_asm_bf16") != hipSuccess) d.fn[F3R_BF16] = nullptr;
+    }
+    (void)hipGetLastError();
+  }
+  return d.fn[dtype];
+}
+
+bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+// The one non-empty segment of an eligible launch (-1 if the launch is not eligible); *why names the first obstacle.
+int f3r_attn_asm_segment(const f3r_attn_args& a, int64_t min_keys, const char** why) {
+  static const char* none = "";
+  *why = none;
+  if (a.causal) { *why = "causal mask"; return -1; }
+  if (a.state_in || a.state_out) { *why = "carried softmax state"; return -1; }
+  if (!a.q_prescaled) { *why = "q not pre-scaled"; return -1; }
+  if (a.tq <= 0 || a.tq % 512 != 0) { *why = "tq not a multiple of 512"; return -1; }
+  if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return -1; }
+  int seg = -1;
+  for (int s = 0; s < a.n_seg; ++s) {
+    if (a.seg_len[s] == 0) continue;
+    if (seg >= 0) { *why = "more than one K/V segment"; return -1; }
+    seg = s;
+  }
+  if (seg < 0) { *why = "no keys"; return -1; }
+  if (a.seg_len[seg] % 64 != 0) { *why = "keys not a multiple of 64"; return -1; }
+  if (a.seg_len[seg] < min_keys) { *why = "fewer keys than F3R_ATTN_ASM_MIN_KEYS"; return -1; }
+  if (a.seg_len[seg] / 64 >= (1ll << 31)) { *why = "too many keys"; return -1; }
+  // 32-bit lane offsets: 128 query rows, 64 key rows, 64 V^T rows must span < 4 GiB
+  if (128 * a.ldq * 2 >= (1ll << 32) || 128 * a.ldo * 2 >= (1ll << 32) || 64 * a.ldk * 2 >= (1ll << 32) || 64 * a.ldvt[seg] * 2 >= (1ll << 32)) {
+    *why = "row strides too large for 32-bit lane offsets";
+    return -1;
+  }
+  if (a.tq / 512 >= (1ll << 31)) { *why = "grid too large"; return -1; }
+  return seg;
+}
+
+int f3r_attn_asm_launch(const f3r_attn_args& a, int seg, hipStream_t stream) {
+  hipFunction_t fn = get_fn(a.dtype);
+  if (!fn) {
+    f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");
+    return F3R_ERR_LAUNCH;
+  }
+  f3r_attn_asm_args k;
+  k.q = a.q;
+  k.k = a.k_seg[seg];
+  k.vt = a.vt_seg[seg];
+  k.o = a.o;
+  k.ldq_b = (uint32_t)(a.ldq * 2);
+  k.ldk_b = (uint32_t)(a.ldk * 2);
+  k.ldvt_b = (uint32_t)(a.ldvt[seg] * 2);
+  k.ldo_b = (uint32_t)(a.ldo * 2);
+  k.n_tiles = (uint32_t)(a.seg_len[seg] / 64);
+  k.flags = 0;
+  k.q_bs = (uint64_t)a.q_batch_stride * 2;
+  k.k_bs = (uint64_t)a.k_batch_stride[seg] * 2;
+  k.vt_bs = (uint64_t)a.vt_batch_stride[seg] * 2;
+  k.o_bs = (uint64_t)a.o_batch_stride * 2;
+  int sh = 0;
+  for (int gsz = a.kv_group > 1 ? a.kv_group : 1; gsz > 1; gsz >>= 1) ++sh;
+  k.kv_shift = (uint32_t)sh;
+  k.pad = 0;
+  size_t size = sizeof(k);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.tq / 512), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
+  if (e != hipSuccess) {
+    f3r_set_error("f3r_attn_fwd: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+    return F3R_ERR_LAUNCH;
+  }
+  return f3r_check_launch("f3r_attn_fwd(asm)");
+}

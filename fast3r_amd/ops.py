@@ -321,10 +321,11 @@ def attention_state(tq_total: int, n_heads: int, device):
 
 
 def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
-              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None):
+              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][kv_heads*64][ldvt].  kv_group: query heads per K / V head (grouped-query attention).
-    causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices)."""
+    causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices).
+    kernel_sel: 0 = automatic, 1 = the general HIP kernel, 2 = the hand-scheduled kernel (include/f3r.h, f3r_attn_args.kernel_sel)."""
     require_gpu(q, "q")
     lp = q.dtype
     assert 1 <= len(segments) <= F3R_MAX_SEG
@@ -343,6 +344,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     a.scale = float(scale)
     a.q_prescaled = int(q_prescaled)
     a.kv_group, a.causal, a.q_pos0 = int(kv_group), int(bool(causal)), int(q_pos0)
+    a.kernel_sel = int(kernel_sel)
     if causal:
         pos = [0] * len(segments)
         if seg_pos0 is None:  # consecutive segments of one sequence starting at position 0

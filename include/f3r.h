@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 200 = 0.2.0, the round-2 ABI (split-precision planes, kv_group / causal attention, block workspace) */
+int f3r_version(void);  /* 300 = 0.3.0, the round-3 ABI (f3r_attn_args.kernel_sel, head_dim field); 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
@@ -222,7 +222,15 @@ typedef struct f3r_attn_args {
   int32_t causal;
   int64_t q_pos0;
   int64_t seg_pos0[F3R_MAX_SEG];
+  /* Kernel choice (per call, like f3r_gemm_args.kernel_sel; no process-wide switch):
+       0 = automatic: the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_gen.py: 512-query workgroups, 128 queries per
+           wave) when the launch is eligible -- no causal mask, q_prescaled, tq a multiple of 512, every non-empty K/V segment a
+           multiple of 64 keys, at least F3R_ATTN_ASM_MIN_KEYS keys, kv_group a power of two -- and the general HIP kernel otherwise;
+       1 = the general HIP kernel;  2 = the hand-scheduled kernel (F3R_ERR_UNSUPPORTED if the launch is not eligible). */
+  int32_t kernel_sel;
+  int32_t reserved0;
 } f3r_attn_args;
+#define F3R_ATTN_ASM_MIN_KEYS 2048
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
 

@@ -1,0 +1,155 @@
+"""The hand-scheduled attention kernel (fast3r_amd/csrc/asm/attn_gen.py, f3r_attn_args.kernel_sel = 2) on a real MI355X, through the
+C ABI: against fp64 on the same rounded operands, against the general HIP kernel, and on the inputs that exercise its rare path (the
+lazy softmax reference moving mid-stream).  Tolerances as in test_kernels_gpu.py: 2 x 2^-9 (fp16) / 2 x 2^-6 (bf16) of the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+from fast3r_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float16, torch.bfloat16]
+LOG2E = 1.4426950408889634
+
+
+def lp_tol(dt):
+    return 2.0 ** -9 if dt == torch.float16 else 2.0 ** -6
+
+
+def rnd(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt)
+
+
+def assert_close(got, ref, tol, what=""):
+    got, ref = got.detach().double().cpu(), ref.double()
+    scale = float(ref.abs().max().clamp_min(1e-6))
+    err = float((got - ref).abs().max())
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol:.1e})"
+
+
+def ref_prescaled(qs, k, v, H, Hkv=None):
+    """qs already holds q * scale * log2(e) (rounded to lowp): softmax in base 2 over the rounded operands, fp64."""
+    Hkv = Hkv or H
+    Tq = qs.shape[0]
+    qh = qs.double().reshape(Tq, H, 64).transpose(0, 1)
+    kh = k.double().reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    vh = v.double().reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    s = (qh @ kh.transpose(1, 2)) * math.log(2.0)
+    return (s.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+def vt_of(v, Hkv):
+    T = v.shape[0]
+    vt = torch.zeros((Hkv * 64, ops.vt_ld(T)), dtype=v.dtype)
+    vt[:, :T] = v.t()
+    return vt
+
+
+def run(qs, k, v, H, Hkv=None, sel=2):
+    Hkv = Hkv or H
+    o = torch.full((qs.shape[0], H * 64), float("nan"), dtype=qs.dtype, device=DEV)
+    ops.attention(qs.to(DEV), o, H, 1.0, [(k.to(DEV), vt_of(v, Hkv).to(DEV), k.shape[0], 0, 0)], q_prescaled=True, kv_group=H // Hkv, kernel_sel=sel)
+    return o
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Tq,Tk,H", [(512, 64, 1), (512, 128, 2), (1024, 192, 2), (512, 1024, 3), (1536, 4096, 2)])
+def test_asm_kernel_vs_fp64(built_lib, dt, Tq, Tk, H):
+    qs = rnd((Tq, H * 64), dt, 1, 0.125 * LOG2E * 1.5)
+    k, v = rnd((Tk, H * 64), dt, 2, 1.5), rnd((Tk, H * 64), dt, 3)
+    o = run(qs, k, v, H)
+    assert_close(o.float(), ref_prescaled(qs, k, v, H), 2 * lp_tol(dt), f"asm attn {Tq}x{Tk}")
+    hip = run(qs, k, v, H, sel=1)
+    assert_close(o.float(), hip.float().cpu(), 2 * lp_tol(dt), "asm vs HIP kernel")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_asm_kernel_forced_rebase(built_lib, dt):
+    """keys far above the rest in late tiles (and one inside the first tile): the lazy reference must move and everything accumulated
+    so far -- O, l, the already computed scores of the next half tile -- be rescaled exactly once"""
+    Tq, Tk, H = 512, 1280, 1
+    q = rnd((Tq, 64), dt, 10).float()
+    k, v = rnd((Tk, 64), dt, 11, 0.3), rnd((Tk, 64), dt, 12)
+    k[900] = (q[7] * 3.0).to(dt)
+    k[130] = (q[300] * 2.0).to(dt)
+    k[1279] = (q[511] * 4.0).to(dt)     # in the very last half tile
+    k[33] = (q[100] * 2.5).to(dt)       # second half of the first tile
+    qs = (q * (0.125 * LOG2E)).to(dt)
+    o = run(qs, k, v, H)
+    assert torch.isfinite(o.float()).all()
+    assert_close(o.float(), ref_prescaled(qs, k, v, H), 2 * lp_tol(dt), "forced rebase")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pattern", ["drift_up", "stairs", "outlier_first", "all_equal"])
+def test_asm_kernel_lazy_reference_patterns(built_lib, dt, pattern):
+    """score sequences built to sit on the re-base trigger (see test_kernels_gpu.py::test_attention_lazy_reference_patterns)"""
+    Tq, Tk, H = 512, 640, 1
+    g = torch.Generator().manual_seed(90)
+    u = torch.randn(64, generator=g)
+    u = u / u.norm()
+    a = torch.linspace(0.5, 8.0, Tq)
+    tile = torch.arange(Tk) // 64
+    if pattern == "drift_up":
+        b = 0.35 * tile.float() + 0.01 * torch.randn(Tk, generator=g)
+    elif pattern == "stairs":
+        b = torch.where(torch.arange(Tk) < 200, 0.0, torch.where(torch.arange(Tk) < 500, 6.0, 15.0)) + 0.05 * torch.randn(Tk, generator=g)
+    elif pattern == "outlier_first":
+        b = -4.0 + 0.5 * torch.randn(Tk, generator=g)
+        b[3] = 12.0
+    else:
+        b = torch.full((Tk,), 1.5)
+    qs = (a[:, None] * u[None, :] * (8.0 * 0.125 * LOG2E)).to(dt)
+    k = (b[:, None] * u[None, :]).to(dt)
+    v = rnd((Tk, 64), dt, 91)
+    o = run(qs, k, v, H)
+    assert torch.isfinite(o.float()).all()
+    assert_close(o.float(), ref_prescaled(qs, k, v, H), 2 * lp_tol(dt), f"lazy reference {pattern}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_asm_kernel_grouped_query_and_batch(built_lib, dt):
+    """kv_group 2 (4 query heads on 2 K/V heads) and a batch of 2 independent sequences with strided batch access"""
+    nb, Tq, Tk, H, Hkv = 2, 512, 320, 4, 2
+    D, Dk = H * 64, Hkv * 64
+    qs = rnd((nb * Tq, D), dt, 20, 0.125 * LOG2E * 1.5)
+    k, v = rnd((nb * Tk, Dk), dt, 21, 1.5), rnd((nb * Tk, Dk), dt, 22)
+    ld = ops.vt_ld(Tk)
+    vt = torch.zeros((nb, Dk, ld), dtype=dt)
+    for b in range(nb):
+        vt[b, :, :Tk] = v[b * Tk:(b + 1) * Tk].t()
+    o = torch.full((nb * Tq, D), float("nan"), dtype=dt, device=DEV)
+    ops.attention(qs.to(DEV), o, H, 1.0, [(k.to(DEV), vt.to(DEV), Tk, Tk * Dk, Dk * ld)], tq=Tq, batch=nb, q_batch_stride=Tq * D, o_batch_stride=Tq * D,
+                  q_prescaled=True, kv_group=2, kernel_sel=2)
+    ref = torch.cat([ref_prescaled(qs[b * Tq:(b + 1) * Tq], k[b * Tk:(b + 1) * Tk], v[b * Tk:(b + 1) * Tk], H, Hkv) for b in range(nb)])
+    assert_close(o.float(), ref, 2 * lp_tol(dt), "gqa + batch")
+
+
+def test_asm_kernel_is_the_automatic_choice_and_refuses_what_it_cannot_do(built_lib):
+    dt = torch.float16
+    H, Tq, Tk = 1, 512, 2048
+    qs, k, v = rnd((Tq, 64), dt, 30, 0.2), rnd((Tk, 64), dt, 31), rnd((Tk, 64), dt, 32)
+    auto, forced = run(qs, k, v, H, sel=0), run(qs, k, v, H, sel=2)
+    assert torch.equal(auto, forced)  # >= F3R_ATTN_ASM_MIN_KEYS keys, eligible: kernel_sel 0 takes the hand-scheduled kernel
+    with pytest.raises(ValueError, match="not eligible"):
+        run(qs[:300], k, v, H, sel=2)  # tq not a multiple of 512
+    with pytest.raises(ValueError, match="not eligible"):
+        run(qs, k[:100], v[:100], H, sel=2)  # keys not a multiple of 64
+    o = torch.empty((Tq, 64), dtype=dt, device=DEV)
+    with pytest.raises(ValueError, match="not eligible"):
+        ops.attention(qs.to(DEV), o, H, 0.125, [(k.to(DEV), vt_of(v, H).to(DEV), Tk, 0, 0)], kernel_sel=2)  # q not pre-scaled
+
+
+def test_asm_kernel_full_size_rows_sum_to_one(built_lib):
+    """BASELINE size (327 680 tokens would take a second per head; 2 heads x 65 536 keys here): V = const => O = const exactly up to the
+    rounding of l, for every query row -- a size-independent property that any dropped / duplicated tile or stale LDS slot breaks."""
+    dt = torch.float16
+    H, Tq, Tk = 2, 1024, 65536
+    qs, k = rnd((Tq, H * 64), dt, 40, 0.3), rnd((Tk, H * 64), dt, 41)
+    v = torch.full((Tk, H * 64), 0.75, dtype=dt)
+    o = run(qs, k, v, H)
+    assert_close(o.float(), torch.full((Tq, H * 64), 0.75), 2.0 ** -10, "rows sum to one")

@@ -1,0 +1,482 @@
+"""Lane-exact CPU emulator for the subset of gfx950 instructions the generators under fast3r_amd/csrc/asm/ emit.
+
+Test infrastructure (like oracle/): it executes the SAME instruction list that is printed for the assembler, one workgroup at a
+time, so register clashes, pipeline indexing, address arithmetic and missing waits are found without a GPU.  What it encodes about
+the hardware (MFMA operand layouts, LDS-DMA placement) is what the HIP kernels in fast3r_amd/csrc/ rely on and the GPU tests pin.
+
+Asynchrony is modelled pessimistically:
+  * a ds_read / global_load result reaches its registers only when an s_waitcnt retires it; until then the registers hold a poison
+    pattern (a NaN), so a consumer placed before the wait produces NaNs;
+  * LDS-DMA data lands in LDS only when the issuing wave's vmcnt wait retires it; other waves see it after that (waves of a
+    workgroup run one after the other between barriers, so a read that is not ordered by a barrier sees stale data for some wave).
+"""
+import numpy as np
+
+import sys
+import os
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fast3r_amd", "csrc", "asm"))
+from isa import Ins, Label, LabelRef, Lit, Neg, Reg, Special  # noqa: E402
+
+POISON = np.uint32(0x7FC0DEAD)
+MASK64 = (1 << 64) - 1
+
+
+def f32(u):
+    return u.view(np.float32)
+
+
+def u32(f):
+    return np.asarray(f, dtype=np.float32).view(np.uint32)
+
+
+def half_to_f32(h16, dtype):
+    h16 = h16.astype(np.uint16)
+    if dtype == "f16":
+        return h16.view(np.float16).astype(np.float32)
+    return (h16.astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_half(x, dtype):
+    x = np.asarray(x, dtype=np.float32)
+    if dtype == "f16":
+        with np.errstate(over="ignore"):
+            return x.astype(np.float16).view(np.uint16)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)  # round to nearest even
+    nan = np.isnan(x)
+    r[nan] = 0x7FC0
+    return r
+
+
+class Memory:
+    """flat global memory made of named numpy byte buffers at fake 64-bit addresses"""
+
+    def __init__(self):
+        self.bufs = []
+        self.next = 0x7F0000000000
+
+    def alloc(self, arr):
+        b = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+        base = self.next
+        self.next += (len(b) + 0xFFFF) & ~0xFFFF
+        self.bufs.append((base, b))
+        return base
+
+    def find(self, addr, n):
+        for base, b in self.bufs:
+            if base <= addr and addr + n <= base + len(b):
+                return b, addr - base
+        raise RuntimeError(f"global access out of bounds: 0x{addr:x} (+{n})")
+
+    def read(self, addr, n):
+        b, o = self.find(int(addr), n)
+        return b[o:o + n]
+
+    def write(self, addr, data):
+        b, o = self.find(int(addr), len(data))
+        b[o:o + len(data)] = data
+
+    def get(self, base, dtype, shape):
+        for bb, b in self.bufs:
+            if bb == base:
+                n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                return b[:n].view(dtype).reshape(shape)
+        raise KeyError(base)
+
+
+class Wave:
+    def __init__(self, wg, wid, items, labels, dtype):
+        self.wg, self.wid, self.items, self.labels, self.dtype = wg, wid, items, labels, dtype
+        self.v = np.zeros((256, 64), np.uint32)
+        self.a = np.zeros((256, 64), np.uint32)
+        self.s = np.zeros(128, np.uint32)
+        self.vcc = 0
+        self.scc = 0
+        self.m0 = 0
+        self.pc = 0
+        self.done = False
+        self.at_barrier = False
+        self.lgkm = []   # pending LDS / SMEM results: callables applied in order
+        self.vm = []     # pending VMEM operations
+        self.n_exec = 0
+
+    # ---- operand access
+    def rd(self, x):
+        if isinstance(x, Neg):
+            return self.rd(x.r) ^ np.uint32(0x80000000)
+        if isinstance(x, Reg):
+            assert x.n == 1, x
+            if x.kind == "v":
+                return self.v[x.idx]
+            if x.kind == "a":
+                return self.a[x.idx]
+            return np.full(64, self.s[x.idx], np.uint32)
+        if isinstance(x, Lit):
+            return np.full(64, x.bits & 0xFFFFFFFF, np.uint32)
+        if isinstance(x, Special):
+            if x.name == "m0":
+                return np.full(64, self.m0, np.uint32)
+            raise NotImplementedError(x.name)
+        if isinstance(x, float):
+            return np.full(64, np.float32(x).view(np.uint32), np.uint32)
+        if isinstance(x, int):
+            return np.full(64, x & 0xFFFFFFFF, np.uint32)
+        raise NotImplementedError(repr(x))
+
+    def rds(self, x):
+        """scalar read"""
+        if isinstance(x, Reg):
+            assert x.kind == "s" and x.n == 1
+            return int(self.s[x.idx])
+        if isinstance(x, Lit):
+            return x.bits & 0xFFFFFFFF
+        if isinstance(x, Special) and x.name == "m0":
+            return self.m0
+        if isinstance(x, int):
+            return x & 0xFFFFFFFF
+        if isinstance(x, float):
+            return int(np.float32(x).view(np.uint32))
+        raise NotImplementedError(repr(x))
+
+    def rds64(self, x):
+        if isinstance(x, Reg) and x.kind == "s" and x.n == 2:
+            return int(self.s[x.idx]) | (int(self.s[x.idx + 1]) << 32)
+        if isinstance(x, Special) and x.name == "vcc":
+            return self.vcc
+        if isinstance(x, int):
+            return x & MASK64
+        raise NotImplementedError(repr(x))
+
+    def wr(self, x, val):
+        val = np.asarray(val).astype(np.uint32, copy=False) if not (isinstance(val, np.ndarray) and val.dtype == np.uint32) else val
+        assert isinstance(x, Reg) and x.n == 1
+        if x.kind == "v":
+            self.v[x.idx] = val
+        elif x.kind == "a":
+            self.a[x.idx] = val
+        else:
+            raise AssertionError("vector write to an SGPR")
+
+    def wrs(self, x, val):
+        val &= 0xFFFFFFFF
+        if isinstance(x, Special) and x.name == "m0":
+            self.m0 = val
+            return
+        assert isinstance(x, Reg) and x.kind == "s" and x.n == 1, x
+        self.s[x.idx] = val
+
+    def file(self, kind):
+        return self.v if kind == "v" else self.a
+
+    def tuple_read(self, r):
+        return self.file(r.kind)[r.idx:r.idx + r.n]
+
+    def poison(self, r):
+        self.file(r.kind)[r.idx:r.idx + r.n] = POISON
+
+    # ---- MFMA (32x32 output, lane l: column l % 32; register r: row 8 (r / 4) + (r % 4) + 4 (l / 32))
+    def mfma(self, ins, kdim):
+        D, Aop, Bop, Cop = ins.args
+        per = kdim // 2                      # k elements per lane
+        nreg = per // 2
+        assert Aop.n == nreg and Bop.n == nreg and D.n == 16
+        lanes = np.arange(64)
+        g = lanes // 32
+        am = np.zeros((32, kdim), np.float32)
+        bm = np.zeros((kdim, 32), np.float32)
+        ar = self.tuple_read(Aop)
+        br = self.tuple_read(Bop)
+        for j in range(nreg):
+            for half in range(2):
+                kidx = per * g + 2 * j + half
+                av = half_to_f32((ar[j] >> (16 * half)) & 0xFFFF, self.dtype)
+                bv = half_to_f32((br[j] >> (16 * half)) & 0xFFFF, self.dtype)
+                am[lanes % 32, kidx] = av
+                bm[kidx, lanes % 32] = bv
+        prod = am.astype(np.float64) @ bm.astype(np.float64)
+        if isinstance(Cop, Reg):
+            c = f32(self.tuple_read(Cop).copy())
+        else:
+            assert Cop == 0
+            c = np.zeros((16, 64), np.float32)
+        out = np.zeros((16, 64), np.float32)
+        for r in range(16):
+            rows = 8 * (r // 4) + (r % 4) + 4 * g
+            out[r] = (prod[rows, lanes % 32] + c[r].astype(np.float64)).astype(np.float32)
+        self.file(D.kind)[D.idx:D.idx + 16] = out.view(np.uint32)
+
+    # ---- waits
+    def retire(self, queue, keep):
+        while len(queue) > keep:
+            queue.pop(0)()
+
+    def step(self):
+        it = self.items[self.pc]
+        self.pc += 1
+        if isinstance(it, Label):
+            return
+        self.n_exec += 1
+        op, a = it.op, it.args
+        lds = self.wg.lds
+        mem = self.wg.mem
+        if op.endswith("_e32") or op.endswith("_e64"):
+            op = op[:-4]
+        # ---------------- scalar
+        if op == "s_nop" or op == "s_setprio":
+            return
+        if op == "s_endpgm":
+            self.retire(self.vm, 0)
+            self.done = True
+            return
+        if op == "s_barrier":
+            self.at_barrier = True
+            return
+        if op == "s_waitcnt":
+            txt = a[0]
+            cnt = int(txt[txt.index("(") + 1:txt.index(")")])
+            if txt.startswith("vmcnt"):
+                self.retire(self.vm, cnt)
+            elif txt.startswith("lgkmcnt"):
+                self.retire(self.lgkm, cnt)
+            else:
+                raise NotImplementedError(txt)
+            return
+        if op in ("s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8"):
+            n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8}[op]
+            base = self.rds64(a[1]) + self.rds(a[2])
+            data = mem.read(base, 4 * n).view(np.uint32).copy()
+            dst = a[0]
+            self.s[dst.idx:dst.idx + n] = 0xDEADBEEF
+
+            def land(dst=dst, data=data, n=n):
+                self.s[dst.idx:dst.idx + n] = data
+            self.lgkm.append(land)
+            return
+        if op == "s_mov_b32":
+            self.wrs(a[0], self.rds(a[1]))
+            return
+        if op == "s_mov_b64":
+            v = self.rds64(a[1])
+            self.s[a[0].idx] = v & 0xFFFFFFFF
+            self.s[a[0].idx + 1] = v >> 32
+            return
+        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_add_i32", "s_sub_i32"):
+            x, y = self.rds(a[1]), self.rds(a[2])
+            if op == "s_add_u32" or op == "s_add_i32":
+                r = x + y
+                self.scc = int(r > 0xFFFFFFFF)
+            elif op == "s_addc_u32":
+                r = x + y + self.scc
+                self.scc = int(r > 0xFFFFFFFF)
+            else:
+                r = x - y
+                self.scc = int(y > x)
+            self.wrs(a[0], r & 0xFFFFFFFF)
+            return
+        if op == "s_mul_i32":
+            self.wrs(a[0], (self.rds(a[1]) * self.rds(a[2])) & 0xFFFFFFFF)
+            return
+        if op == "s_mul_hi_u32":
+            self.wrs(a[0], (self.rds(a[1]) * self.rds(a[2])) >> 32)
+            return
+        if op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
+            x, y = self.rds(a[1]), self.rds(a[2])
+            r = {"s_lshl_b32": (x << (y & 31)), "s_lshr_b32": x >> (y & 31), "s_and_b32": x & y, "s_or_b32": x | y}[op] & 0xFFFFFFFF
+            self.scc = int(r != 0)
+            self.wrs(a[0], r)
+            return
+        if op.startswith("s_cmp_"):
+            x, y = self.rds(a[0]), self.rds(a[1])
+            self.scc = int({"s_cmp_lt_u32": x < y, "s_cmp_eq_u32": x == y, "s_cmp_ge_u32": x >= y, "s_cmp_gt_u32": x > y,
+                            "s_cmp_le_u32": x <= y, "s_cmp_lg_u32": x != y}[op])
+            return
+        if op == "s_cselect_b32":
+            self.wrs(a[0], self.rds(a[1]) if self.scc else self.rds(a[2]))
+            return
+        if op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccnz", "s_cbranch_vccz"):
+            take = {"s_branch": True, "s_cbranch_scc0": self.scc == 0, "s_cbranch_scc1": self.scc == 1,
+                    "s_cbranch_vccnz": self.vcc != 0, "s_cbranch_vccz": self.vcc == 0}[op]
+            if take:
+                self.pc = self.labels[a[0].name]
+            return
+        # ---------------- vector ALU
+        if op.startswith("v_mfma_f32_32x32x16"):
+            self.mfma(it, 16)
+            return
+        if op.startswith("v_mfma_f32_32x32x8"):
+            self.mfma(it, 8)
+            return
+        if op == "v_mov_b32":
+            self.wr(a[0], self.rd(a[1]).copy())
+            return
+        if op == "v_readfirstlane_b32":
+            self.wrs(a[0], int(self.rd(a[1])[0]))
+            return
+        if op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32"):
+            self.wr(a[0], self.rd(a[1]).copy())
+            return
+        if op in ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_mul_lo_u32"):
+            x, y = self.rd(a[1]).astype(np.uint64), self.rd(a[2]).astype(np.uint64)
+            r = {"v_and_b32": x & y, "v_or_b32": x | y, "v_xor_b32": x ^ y, "v_add_u32": x + y, "v_sub_u32": x - y,
+                 "v_mul_lo_u32": x * y}[op]
+            self.wr(a[0], (r & 0xFFFFFFFF).astype(np.uint32))
+            return
+        if op in ("v_lshlrev_b32", "v_lshrrev_b32"):
+            sh, x = self.rd(a[1]) & 31, self.rd(a[2])
+            r = (x.astype(np.uint64) << sh.astype(np.uint64)) if op == "v_lshlrev_b32" else (x >> sh)
+            self.wr(a[0], (r & 0xFFFFFFFF).astype(np.uint32))
+            return
+        if op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32"):
+            x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
+            with np.errstate(all="ignore"):
+                r = {"v_add_f32": x + y, "v_sub_f32": x - y, "v_mul_f32": x * y, "v_max_f32": np.fmax(x, y)}[op]
+            self.wr(a[0], u32(r))
+            return
+        if op == "v_max3_f32":
+            x, y, z = f32(self.rd(a[1])), f32(self.rd(a[2])), f32(self.rd(a[3]))
+            self.wr(a[0], u32(np.fmax(np.fmax(x, y), z)))
+            return
+        if op == "v_exp_f32":
+            with np.errstate(all="ignore"):
+                self.wr(a[0], u32(np.exp2(f32(self.rd(a[1])).astype(np.float64)).astype(np.float32)))
+            return
+        if op == "v_rcp_f32":
+            with np.errstate(all="ignore"):
+                self.wr(a[0], u32((1.0 / f32(self.rd(a[1])).astype(np.float64)).astype(np.float32)))
+            return
+        if op in ("v_cvt_pk_f16_f32", "v_cvt_pk_bf16_f32"):
+            dt = "f16" if "f16" in op and "bf16" not in op else "bf16"
+            lo = f32_to_half(f32(self.rd(a[1])), dt).astype(np.uint32)
+            hi = f32_to_half(f32(self.rd(a[2])), dt).astype(np.uint32)
+            self.wr(a[0], lo | (hi << 16))
+            return
+        if op == "v_cvt_f16_f32":
+            self.wr(a[0], f32_to_half(f32(self.rd(a[1])), "f16").astype(np.uint32))
+            return
+        if op == "v_cvt_f32_f16":
+            self.wr(a[0], u32(half_to_f32(self.rd(a[1]) & 0xFFFF, "f16")))
+            return
+        if op == "v_pack_b32_f16":
+            self.wr(a[0], (self.rd(a[1]) & 0xFFFF) | ((self.rd(a[2]) & 0xFFFF) << 16))
+            return
+        if op in ("v_dot2c_f32_f16", "v_dot2c_f32_bf16"):
+            dt = "bf16" if "bf16" in op else "f16"
+            x, y = self.rd(a[1]), self.rd(a[2])
+            acc = f32(self.rd(a[0])).astype(np.float64)
+            for h in range(2):
+                acc = acc + half_to_f32((x >> (16 * h)) & 0xFFFF, dt).astype(np.float64) * half_to_f32((y >> (16 * h)) & 0xFFFF, dt).astype(np.float64)
+            with np.errstate(over="ignore"):
+                self.wr(a[0], u32(acc.astype(np.float32)))
+            return
+        if op in ("v_cmp_eq_u32", "v_cmp_le_f32", "v_cmp_ge_f32", "v_cmp_lt_u32"):
+            assert isinstance(a[0], Special) and a[0].name == "vcc"
+            if op.endswith("u32"):
+                x, y = self.rd(a[1]), self.rd(a[2])
+            else:
+                x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
+            with np.errstate(invalid="ignore"):
+                m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
+            self.vcc = int(sum(1 << i for i in range(64) if m[i]))
+            return
+        if op == "v_cndmask_b32":
+            mask = self.rds64(a[3])
+            sel = np.array([(mask >> i) & 1 for i in range(64)], bool)
+            self.wr(a[0], np.where(sel, self.rd(a[2]), self.rd(a[1])).astype(np.uint32))
+            return
+        # ---------------- LDS
+        if op == "ds_read_b128":
+            dst, addr = a[0], self.rd(a[1]).astype(np.int64) + int(it.mods.get("offset", 0) or 0)
+            assert dst.n == 4
+            assert np.all(addr % 16 == 0) and addr.max() + 16 <= len(lds), "ds_read_b128 address"
+            data = np.stack([lds[x:x + 16].view(np.uint32) for x in addr], axis=1).copy()  # [4][64]
+            self.poison(dst)
+
+            def land(dst=dst, data=data):
+                self.file(dst.kind)[dst.idx:dst.idx + 4] = data
+            self.lgkm.append(land)
+            return
+        if op == "ds_bpermute_b32":
+            idx = (self.rd(a[1]) >> 2) & 63
+            data = self.rd(a[2])[idx].copy()
+            dst = a[0]
+            self.poison(dst)
+
+            def land(dst=dst, data=data):
+                self.wr(dst, data)
+            self.lgkm.append(land)
+            return
+        # ---------------- global memory
+        if op == "global_load_dwordx4":
+            dst, voff, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            data = np.stack([mem.read(base + o, 16).view(np.uint32) for o in off], axis=1).copy()
+            self.poison(dst)
+
+            def land(dst=dst, data=data):
+                self.file(dst.kind)[dst.idx:dst.idx + 4] = data
+            self.vm.append(land)
+            return
+        if op == "global_load_lds_dwordx4":
+            voff, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            data = [mem.read(base + o, 16).copy() for o in off]
+            m0 = self.m0
+
+            def land(data=data, m0=m0):
+                for lane in range(64):
+                    lds[m0 + 16 * lane:m0 + 16 * lane + 16] = data[lane]
+            self.vm.append(land)
+            return
+        if op == "global_store_dwordx2":
+            voff, src, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            vals = self.tuple_read(src).copy()
+            for lane in range(64):
+                mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
+            self.vm.append(lambda: None)
+            return
+        raise NotImplementedError(it.text())
+
+
+class Workgroup:
+    def __init__(self, program, mem, kernarg_addr, wg_id, n_waves, lds_bytes, dtype):
+        self.mem = mem
+        self.lds = np.zeros(lds_bytes, np.uint8)
+        self.lds[:] = 0xA5  # garbage
+        items = program.items
+        labels = {it.name: i for i, it in enumerate(items) if isinstance(it, Label)}
+        self.waves = []
+        for w in range(n_waves):
+            wv = Wave(self, w, items, labels, dtype)
+            wv.s[0] = kernarg_addr & 0xFFFFFFFF
+            wv.s[1] = kernarg_addr >> 32
+            wv.s[2], wv.s[3], wv.s[4] = wg_id
+            wv.v[0] = np.arange(64, dtype=np.uint32) + 64 * w
+            self.waves.append(wv)
+
+    def run(self, max_steps=10_000_000):
+        steps = 0
+        flip = False
+        while True:
+            order = self.waves[::-1] if flip else self.waves
+            flip = not flip
+            progressed = False
+            for wv in order:
+                while not wv.done and not wv.at_barrier:
+                    wv.step()
+                    steps += 1
+                    progressed = True
+                    if steps > max_steps:
+                        raise RuntimeError("emulator step limit")
+            live = [w for w in self.waves if not w.done]
+            if not live:
+                return steps
+            if all(w.at_barrier for w in live):
+                for w in live:
+                    w.at_barrier = False
+            elif not progressed:
+                raise RuntimeError("deadlock")

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, GPU call A: first light of the hand-scheduled attention kernel (parity, then timing next to the HIP kernel, then generator variants)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+out=gpurun_out/r3a; mkdir -p $out
+timeout 900 python -m pytest tests/test_attn_asm_gpu.py -x -q > $out/pytest_asm.log 2>&1; echo "pytest rc $?" >> $out/pytest_asm.log
+tail -15 $out/pytest_asm.log
+timeout 400 python tools/kernel_bench.py --what attnsel --views 20,100,320 --attn-dtypes fp16,bf16 > $out/attnsel.jsonl 2>&1
+cat $out/attnsel.jsonl
+for v in g4 g6 add5 add6; do
+  echo "== $v" >> $out/attnsel_variants.jsonl
+  F3R_LAB_LIB=tools/lab/var/libf3r_$v.so timeout 200 python tools/kernel_bench.py --what attnsel --views 100,320 --attn-dtypes fp16 --sels 2 >> $out/attnsel_variants.jsonl 2>&1
+done
+cat $out/attnsel_variants.jsonl

@@ -104,6 +104,30 @@ def bench_attn_product(dt, views, H=16):
                       "tflops": round(4.0 * T * T * 64 * H / med / 1e9, 1)}), flush=True)
 
 
+def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2):
+    """The general HIP kernel (kernel_sel 1) next to the hand-scheduled one (kernel_sel 2) on the fusion shape, q pre-scaled."""
+    T = views * 1024
+    D = H * 64
+    q = (torch.randn((T, D), device=DEV) * (0.160192 * 1.4426950408889634)).to(dt)
+    k = torch.randn((T, D), device=DEV).to(dt)
+    vt = torch.randn((D, T), device=DEV).to(dt)
+    outs = {}
+    for sel in sels:
+        o = torch.empty((T, D), dtype=dt, device=DEV)
+
+        def f(sel=sel, o=o):
+            ops.attention(q, o, H, 0.160192, [(k, vt, T, 0, 0)], q_prescaled=True, kernel_sel=sel)
+        f()
+        med, mn = time_ms(f, rounds=rounds, inner=inner)
+        outs[sel] = o
+        print(json.dumps({"kernel": "attn_sel", "kernel_sel": sel, "dtype": str(dt).split(".")[-1], "views": views, "T": T, "ms": round(med, 3),
+                          "ms_min": round(mn, 3), "tflops": round(4.0 * T * T * 64 * H / med / 1e9, 1)}), flush=True)
+    if 1 in outs and 2 in outs:
+        a, b = outs[1].float(), outs[2].float()
+        print(json.dumps({"kernel": "attn_sel", "views": views, "dtype": str(dt).split(".")[-1],
+                          "rel_l2_asm_vs_hip": float((a - b).norm() / a.norm()), "nan": int(torch.isnan(b).sum())}), flush=True)
+
+
 def bench_attn_encoder(dt, views, variants, H=16):
     S, D = 1024, H * 64
     q = torch.randn((views * S, D), device=DEV).to(dt)
@@ -404,6 +428,7 @@ if __name__ == "__main__":
     ap.add_argument("--variants", default="24,72", help="attention variants; anything but 24 53 55 70 71 72 84 needs a -DF3R_ATTN_LAB build")
     ap.add_argument("--views", default="20,100")
     ap.add_argument("--attn-dtypes", default="bf16,fp16", help="attnproduct: which operand formats")
+    ap.add_argument("--sels", default="1,2", help="attnsel: f3r_attn_args.kernel_sel values to time")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
@@ -418,6 +443,11 @@ if __name__ == "__main__":
             for d in (args.attn_dtypes.split(",")):
                 bench_attn_product({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv)
         sys.exit(0)
+    if args.what == "attnsel":
+        for nv in [int(x) for x in args.views.split(",")]:
+            for d in (args.attn_dtypes.split(",")):
+                bench_attn_sel({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv, sels=tuple(int(x) for x in args.sels.split(",")))
+        return
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
             bench_attn(torch.bfloat16, nv, variants)
