@@ -112,6 +112,10 @@ class Label:
     name: str
 
 
+def base_op(op):
+    return op[:-4] if op.endswith("_e32") or op.endswith("_e64") else op
+
+
 def is_mfma(op):
     return op.startswith("v_mfma")
 
@@ -164,10 +168,15 @@ class Program:
                 problems += self._check_stream(window, f"[edge {it.text().strip()}] ", branch_resets=False)
         return problems
 
+    TRANS = ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32")
+
     def _check_stream(self, items, tag, branch_resets=True):
         last_mfma_write = {}   # (kind, idx) -> instruction index
         last_valu_write = {}
+        last_trans_write = {}  # VGPRs written by a transcendental: a non-transcendental VALU reader needs one wait state (gfx940 forwarding hazard)
+        last_valu_sgpr_write = {}  # SGPRs / VCC written by a VALU: a VALU reader needs two wait states
         last_m0_write = -10
+        last_dot_write = {}
         n = 0
         problems = []
         for it in items:
@@ -176,6 +185,7 @@ class Program:
             op = it.op
             if op in ("s_branch", "s_endpgm") and branch_resets:
                 last_mfma_write, last_valu_write, last_m0_write = {}, {}, -10
+                last_trans_write, last_valu_sgpr_write, last_dot_write = {}, {}, {}
                 continue
             slots = 1
             if op == "s_nop":
@@ -198,6 +208,38 @@ class Program:
                 for r in list(regs_r) + list(regs_w):
                     if r in last_mfma_write and n - last_mfma_write[r] < self.MFMA_RESULT_WAIT:
                         problems.append(f"{tag}{n}: {it.text()} touches MFMA result {r} after {n - last_mfma_write[r]} slots")
+                if is_valu(op):
+                    for r in list(regs_r) + list(regs_w):   # gfx940: a dot result may be consumed at once only by the same dot opcode as its accumulator
+                        if r in last_dot_write and n - last_dot_write[r][0] < 4 and not (base_op(op) == last_dot_write[r][1] and r in regs_w):
+                            problems.append(f"{tag}{n}: {it.text()} touches dot result {r} after {n - last_dot_write[r][0]} slots")
+                    if base_op(op).startswith("v_dot"):
+                        for r in regs_w:
+                            last_dot_write[r] = (n, base_op(op))
+                    if base_op(op) not in self.TRANS:
+                        for r in regs_r:
+                            if r in last_trans_write and n - last_trans_write[r] < 2:
+                                problems.append(f"{tag}{n}: {it.text()} reads transcendental result {r} with no wait state")
+                    if op.startswith("v_readfirstlane") or op.startswith("v_readlane") or op.startswith("v_permlane"):
+                        for r in regs_r:
+                            if r in last_valu_write and n - last_valu_write[r] < 2:
+                                problems.append(f"{tag}{n}: {it.text()} reads {r} written by the previous VALU instruction")
+                    sread = [a for a in it.args[1:] if (isinstance(a, Special) and a.name == "vcc")]
+                    sregs = [("vcc", 0)] if sread else []
+                    sregs += [r for r in regs_r if r[0] == "s"]
+                    for r in sregs:
+                        if r in last_valu_sgpr_write and n - last_valu_sgpr_write[r] < 3:
+                            problems.append(f"{tag}{n}: {it.text()} reads {r} written by a VALU {n - last_valu_sgpr_write[r]} slots earlier")
+                    if base_op(op) in self.TRANS:
+                        for r in regs_w:
+                            last_trans_write[r] = n
+                    else:
+                        for r in regs_w:
+                            last_trans_write.pop(r, None)
+                    if op.startswith("v_cmp") and it.args and isinstance(it.args[0], Special):
+                        last_valu_sgpr_write[("vcc", 0)] = n
+                    if op.startswith("v_readfirstlane") or op.startswith("v_readlane"):
+                        for r in regs_w:
+                            last_valu_sgpr_write[r] = n
                 if is_valu(op) or op.startswith("ds_read") or op.startswith("global_load_dword"):
                     for r in regs_w:
                         last_valu_write[r] = n

@@ -70,11 +70,14 @@ def check_if_same_size(imgs):
 
 
 _warned_fp32 = False
+_warned_exact_size = False
+EXACT_WARN_VIEWS = 48  # above this the fp32 attention of the "exact" mode (one FMA pipe, ~30 TFLOP/s, O(T^2)) takes longer than everything else together
 
 
-def _operand_format(precision, model):
-    """-> (compute_dtype, precision mode) for this call (see the module docstring)."""
-    global _warned_fp32
+def _operand_format(precision, model, n_views=0):
+    """-> (compute_dtype, precision mode) for this call (see the module docstring).  dtype="32" always runs fp16 hi + lo operand planes
+    (the model's compute_dtype is not consulted) with the attention core in fp32."""
+    global _warned_fp32, _warned_exact_size
     if precision in ("16-mixed", torch.float16):
         return torch.float16, model.precision
     if precision in ("bf16-mixed", "bf16-mixed-no-grad-scaling", torch.bfloat16):
@@ -83,6 +86,12 @@ def _operand_format(precision, model):
         from .fast3r import LlamaDecoder
         exact_ok = precision is not torch.float32 and model.sharding is None and not isinstance(model.decoder, LlamaDecoder)
         if exact_ok:
+            if n_views > EXACT_WARN_VIEWS and not _warned_exact_size:
+                warnings.warn(f"fast3r_amd.inference(dtype='32') on {n_views} views: the fp32-equivalent mode runs the attention core on the "
+                              "fp32 FMA pipe (~30 TFLOP/s, quadratic in the number of views: minutes per forward pass at hundreds of views); "
+                              "it is meant for validation.  Build the model with precision='high' and pass dtype='16-mixed' for the "
+                              "parity-green production format.", stacklevel=3)
+                _warned_exact_size = True
             return torch.float16, "exact"
         if not _warned_fp32:
             warnings.warn(f"fast3r_amd.inference(dtype={precision!r}): running fp16 operands with split hi + lo planes (precision='high': ~22-bit "
@@ -101,7 +110,7 @@ def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_bat
                 view[name] = view[name].to(device, non_blocking=True)
     net = getattr(model, "net", model)  # accept the MultiViewDUSt3RLitModule shim too
     saved = (net.compute_dtype, net.precision)
-    net.compute_dtype, net.precision = _operand_format(precision, net)
+    net.compute_dtype, net.precision = _operand_format(precision, net, n_views=len(batch))
     try:
         out = model(batch, profiling=profiling) if net is model else (net(batch, profiling=profiling))
     finally:

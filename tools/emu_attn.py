@@ -16,7 +16,7 @@ import attn_gen  # noqa: E402
 from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
 
 
-def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="dot2c", seed=0, batch=1, kv_shift=0, q_blocks=1,
+def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="add", seed=0, batch=1, kv_shift=0, q_blocks=1,
              gen_kwargs=None):
     rng = np.random.default_rng(seed)
     tq, tk = 512 * q_blocks, 64 * n_tiles
@@ -73,6 +73,7 @@ if __name__ == "__main__":
     ap.add_argument("--tiles", type=int, default=3)
     ap.add_argument("--heads", type=int, default=2)
     ap.add_argument("--spike", action="store_true")
-    ap.add_argument("--rowsum", default="dot2c")
+    ap.add_argument("--rowsum", default="add")
+    ap.add_argument("--cvt", default="rne")
     a = ap.parse_args()
-    run_case(a.dtype, a.tiles, a.heads, spike=a.spike, rowsum=a.rowsum)
+    run_case(a.dtype, a.tiles, a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt))

@@ -351,6 +351,37 @@ class Wave:
             hi = f32_to_half(f32(self.rd(a[2])), dt).astype(np.uint32)
             self.wr(a[0], lo | (hi << 16))
             return
+        if op == "v_cvt_pkrtz_f16_f32":
+            def rtz(x):
+                x = np.asarray(x, dtype=np.float32)
+                with np.errstate(over="ignore"):
+                    h = x.astype(np.float16)
+                    back = h.astype(np.float32)
+                up = (np.abs(back) > np.abs(x)) & np.isfinite(x)
+                hu = h.view(np.uint16).copy()
+                hu[up] -= 1  # one ulp toward zero (sign-magnitude encoding)
+                inf = np.isinf(back) & np.isfinite(x)
+                hu[inf] = (hu[inf] & 0x8000) | 0x7BFF
+                return hu
+            lo = rtz(f32(self.rd(a[1]))).astype(np.uint32)
+            hi = rtz(f32(self.rd(a[2]))).astype(np.uint32)
+            self.wr(a[0], lo | (hi << 16))
+            return
+        if op in ("v_pk_add_f16", "v_pk_max_f16"):
+            x, y = self.rd(a[1]), self.rd(a[2])
+            if "op_sel:[0,1] op_sel_hi:[1,0]" in it.mods.get("text", ""):
+                y = ((y >> 16) | (y << 16)) & 0xFFFFFFFF
+            else:
+                assert "text" not in it.mods
+            out = np.zeros(64, np.uint32)
+            for h in range(2):
+                xa = half_to_f32((x >> (16 * h)) & 0xFFFF, "f16")
+                ya = half_to_f32((y >> (16 * h)) & 0xFFFF, "f16")
+                with np.errstate(all="ignore"):
+                    r = xa + ya if op == "v_pk_add_f16" else np.fmax(xa, ya)
+                out |= f32_to_half(r, "f16").astype(np.uint32) << (16 * h)
+            self.wr(a[0], out)
+            return
         if op == "v_cvt_f16_f32":
             self.wr(a[0], f32_to_half(f32(self.rd(a[1])), "f16").astype(np.uint32))
             return
@@ -369,14 +400,14 @@ class Wave:
             with np.errstate(over="ignore"):
                 self.wr(a[0], u32(acc.astype(np.float32)))
             return
-        if op in ("v_cmp_eq_u32", "v_cmp_le_f32", "v_cmp_ge_f32", "v_cmp_lt_u32"):
+        if op in ("v_cmp_eq_u32", "v_cmp_le_f32", "v_cmp_ge_f32", "v_cmp_lt_u32", "v_cmp_le_u32"):
             assert isinstance(a[0], Special) and a[0].name == "vcc"
             if op.endswith("u32"):
                 x, y = self.rd(a[1]), self.rd(a[2])
             else:
                 x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
             with np.errstate(invalid="ignore"):
-                m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
+                m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_u32": x <= y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
             self.vcc = int(sum(1 << i for i in range(64) if m[i]))
             return
         if op == "v_cndmask_b32":

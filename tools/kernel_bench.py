@@ -447,7 +447,7 @@ if __name__ == "__main__":
         for nv in [int(x) for x in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):
                 bench_attn_sel({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv, sels=tuple(int(x) for x in args.sels.split(",")))
-        return
+        sys.exit(0)
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
             bench_attn(torch.bfloat16, nv, variants)
