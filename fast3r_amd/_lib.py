@@ -59,7 +59,7 @@ class AttnArgs(ctypes.Structure):
         ("scale", _c_f32), ("q_prescaled", _c_i32),
         ("st_o", _c_vp), ("st_ml", _c_vp), ("state_in", _c_i32), ("state_out", _c_i32),
         ("kv_group", _c_i32), ("causal", _c_i32), ("q_pos0", _c_i64), ("seg_pos0", _c_i64 * F3R_MAX_SEG),
-        ("kernel_sel", _c_i32), ("reserved0", _c_i32),
+        ("kernel_sel", _c_i32), ("head_dim", _c_i32),
     ]
 
 
@@ -89,7 +89,7 @@ SYMBOLS = {
     "f3r_silu_mul": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_rows_add_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_rope2d_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
-    "f3r_attn_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, _c_vp]),
+    "f3r_attn_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, _c_vp]),
 }

@@ -389,8 +389,10 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_attn_fwd: bad dtype %d", a.dtype);
   F3R_REQUIRE(a.n_heads > 0 && a.batch > 0 && a.tq >= 0, "f3r_attn_fwd: bad sizes");
   F3R_REQUIRE(a.n_seg >= 1 && a.n_seg <= F3R_MAX_SEG, "f3r_attn_fwd: n_seg %d out of range", a.n_seg);
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  F3R_REQUIRE(hd >= 16 && hd <= 128 && hd % 16 == 0, "f3r_attn_fwd: head_dim %d (a multiple of 16 up to 128)", a.head_dim);
   F3R_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "f3r_attn_fwd: ldq/ldk must be multiples of 8, ldo of 4");
-  F3R_REQUIRE(a.ldq >= a.n_heads * 64 && a.ldo >= a.n_heads * 64, "f3r_attn_fwd: row strides < heads*64");
+  F3R_REQUIRE(a.ldq >= a.n_heads * hd && a.ldo >= a.n_heads * hd, "f3r_attn_fwd: row strides < heads*head_dim");
   F3R_REQUIRE((((uintptr_t)a.q) & 15) == 0 && (((uintptr_t)a.o) & 7) == 0, "f3r_attn_fwd: q/o alignment");
   F3R_REQUIRE(a.q_batch_stride % 8 == 0 && a.o_batch_stride % 4 == 0, "f3r_attn_fwd: batch strides alignment");
   int64_t total = 0;
@@ -409,19 +411,22 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(total > 0, "f3r_attn_fwd: no keys");
   F3R_REQUIRE(a.kv_group >= 0 && (a.kv_group <= 1 || a.n_heads % a.kv_group == 0), "f3r_attn_fwd: kv_group %d does not divide n_heads %d", a.kv_group, a.n_heads);
   const int kv_heads = a.kv_group > 1 ? a.n_heads / a.kv_group : a.n_heads;
-  F3R_REQUIRE(a.ldk >= kv_heads * 64, "f3r_attn_fwd: ldk < kv heads * 64");
+  F3R_REQUIRE(a.ldk >= kv_heads * hd, "f3r_attn_fwd: ldk < kv heads * head_dim");
   if (a.state_in || a.state_out) {
     F3R_REQUIRE(a.st_o && a.st_ml && (((uintptr_t)a.st_o) & 15) == 0 && (((uintptr_t)a.st_ml) & 15) == 0, "f3r_attn_fwd: state buffers null/misaligned");
   }
   F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 2, "f3r_attn_fwd: kernel_sel %d", a.kernel_sel);
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (hd != 64) {
+    F3R_REQUIRE(a.kernel_sel != 2, "f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) is built for head_dim 64");
+    return f3r_attn_generic_launch(a, s);
+  }
   if (a.kernel_sel != 1) {  // the hand-scheduled one-wave-per-SIMD kernel where the launch allows it (include/f3r.h)
     const char* why = "";
-    const int seg = (a.n_heads < 65536 && a.batch < 65536) ? f3r_attn_asm_segment(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why) : -1;
-    if (seg >= 0) return f3r_attn_asm_launch(a, seg, s);
+    if (f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) return f3r_attn_asm_launch(a, s);
     if (a.kernel_sel == 2) {
-      f3r_set_error("f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) but the launch is not eligible: %s", why[0] ? why : "grid too large");
+      f3r_set_error("f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) but the launch is not eligible: %s", why);
       return F3R_ERR_UNSUPPORTED;
     }
   }

@@ -2,6 +2,8 @@
 // (obj/f3r_attn_asm_blob.cpp, written by build.sh), loaded once per device with hipModuleLoadData and launched with
 // hipModuleLaunchKernel on the caller's stream (capturable in a hipGraph like any other launch).  f3r_attn_fwd (f3r_attn.hip)
 // decides per call whether a launch goes here (f3r_attn_args.kernel_sel, include/f3r.h).
+#include <cstddef>
+#include <cstring>
 #include <mutex>
 
 #include "f3r_common.h"
@@ -12,17 +14,25 @@ extern "C" const unsigned int f3r_attn_asm_hsaco_len;
 namespace {
 
 // kernel argument block: the ARG_* offsets of csrc/asm/attn_gen.py
-struct f3r_attn_asm_args {
-  const void* q;
+struct f3r_attn_asm_seg {
   const void* k;
   const void* vt;
+  uint32_t tiles, pad;
+};
+struct f3r_attn_asm_args {
+  const void* q;
   void* o;
   uint32_t ldq_b, ldk_b, ldvt_b, ldo_b;  // row strides in bytes
-  uint32_t n_tiles, flags;
-  uint64_t q_bs, k_bs, vt_bs, o_bs;      // batch strides in bytes
-  uint32_t kv_shift, pad;
+  uint32_t n_tiles, n_seg;               // 64-key tiles over all segments, number of (non-empty) segments
+  uint64_t q_bs, o_bs;                   // batch strides in bytes
+  uint32_t kv_shift, flags;              // bit 0: state_in, bit 1: state_out
+  float* st_o;
+  float* st_ml;
+  uint64_t k_bs, vt_bs;
+  uint32_t st_o_ld_b, st_ml_ld_b, pad[2];
+  f3r_attn_asm_seg seg[8];
 };
-static_assert(sizeof(f3r_attn_asm_args) == 96, "must match ARG_SIZE of attn_gen.py");
+static_assert(sizeof(f3r_attn_asm_args) == 304 && offsetof(f3r_attn_asm_args, seg) == 112, "must match ARG_SIZE / ARG_SEG of attn_gen.py");
 
 constexpr int MAX_DEV = 16;
 struct DevKernels {
@@ -53,59 +63,74 @@ bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 }  // namespace
 
-// The one non-empty segment of an eligible launch (-1 if the launch is not eligible); *why names the first obstacle.
-int f3r_attn_asm_segment(const f3r_attn_args& a, int64_t min_keys, const char** why) {
+// Can the hand-scheduled kernel take this launch?  *why names the first obstacle.
+bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why) {
   static const char* none = "";
   *why = none;
-  if (a.causal) { *why = "causal mask"; return -1; }
-  if (a.state_in || a.state_out) { *why = "carried softmax state"; return -1; }
-  if (!a.q_prescaled) { *why = "q not pre-scaled"; return -1; }
-  if (a.tq <= 0 || a.tq % 512 != 0) { *why = "tq not a multiple of 512"; return -1; }
-  if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return -1; }
-  int seg = -1;
+  if (a.causal) { *why = "causal mask"; return false; }
+  if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
+  if (a.tq <= 0 || a.tq % 512 != 0) { *why = "tq not a multiple of 512"; return false; }
+  if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return false; }
+  if ((a.state_in || a.state_out) && a.batch != 1) { *why = "carried softmax state with batch > 1"; return false; }
+  int first = -1;
+  int64_t keys = 0;
   for (int s = 0; s < a.n_seg; ++s) {
     if (a.seg_len[s] == 0) continue;
-    if (seg >= 0) { *why = "more than one K/V segment"; return -1; }
-    seg = s;
+    if (a.seg_len[s] % 64 != 0) { *why = "a K/V segment is not a multiple of 64 keys"; return false; }
+    if (first < 0) first = s;
+    if (a.ldvt[s] != a.ldvt[first] || a.k_batch_stride[s] != a.k_batch_stride[first] || a.vt_batch_stride[s] != a.vt_batch_stride[first]) {
+      *why = "K/V segments with different ldvt / batch strides";
+      return false;
+    }
+    keys += a.seg_len[s];
   }
-  if (seg < 0) { *why = "no keys"; return -1; }
-  if (a.seg_len[seg] % 64 != 0) { *why = "keys not a multiple of 64"; return -1; }
-  if (a.seg_len[seg] < min_keys) { *why = "fewer keys than F3R_ATTN_ASM_MIN_KEYS"; return -1; }
-  if (a.seg_len[seg] / 64 >= (1ll << 31)) { *why = "too many keys"; return -1; }
+  if (first < 0) { *why = "no keys"; return false; }
+  if (keys < min_keys) { *why = "fewer keys than F3R_ATTN_ASM_MIN_KEYS"; return false; }
+  if (keys / 64 >= (1ll << 31)) { *why = "too many keys"; return false; }
   // 32-bit lane offsets: 128 query rows, 64 key rows, 64 V^T rows must span < 4 GiB
-  if (128 * a.ldq * 2 >= (1ll << 32) || 128 * a.ldo * 2 >= (1ll << 32) || 64 * a.ldk * 2 >= (1ll << 32) || 64 * a.ldvt[seg] * 2 >= (1ll << 32)) {
+  if (128 * a.ldq * 2 >= (1ll << 32) || 128 * a.ldo * 2 >= (1ll << 32) || 64 * a.ldk * 2 >= (1ll << 32) || 64 * a.ldvt[first] * 2 >= (1ll << 32) ||
+      (int64_t)128 * a.n_heads * 256 >= (1ll << 32)) {
     *why = "row strides too large for 32-bit lane offsets";
-    return -1;
+    return false;
   }
-  if (a.tq / 512 >= (1ll << 31)) { *why = "grid too large"; return -1; }
-  return seg;
+  if (a.tq / 512 >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
+  return true;
 }
 
-int f3r_attn_asm_launch(const f3r_attn_args& a, int seg, hipStream_t stream) {
+int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   hipFunction_t fn = get_fn(a.dtype);
   if (!fn) {
     f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");
     return F3R_ERR_LAUNCH;
   }
   f3r_attn_asm_args k;
+  memset(&k, 0, sizeof(k));
   k.q = a.q;
-  k.k = a.k_seg[seg];
-  k.vt = a.vt_seg[seg];
   k.o = a.o;
   k.ldq_b = (uint32_t)(a.ldq * 2);
   k.ldk_b = (uint32_t)(a.ldk * 2);
-  k.ldvt_b = (uint32_t)(a.ldvt[seg] * 2);
   k.ldo_b = (uint32_t)(a.ldo * 2);
-  k.n_tiles = (uint32_t)(a.seg_len[seg] / 64);
-  k.flags = 0;
   k.q_bs = (uint64_t)a.q_batch_stride * 2;
-  k.k_bs = (uint64_t)a.k_batch_stride[seg] * 2;
-  k.vt_bs = (uint64_t)a.vt_batch_stride[seg] * 2;
   k.o_bs = (uint64_t)a.o_batch_stride * 2;
   int sh = 0;
   for (int gsz = a.kv_group > 1 ? a.kv_group : 1; gsz > 1; gsz >>= 1) ++sh;
   k.kv_shift = (uint32_t)sh;
-  k.pad = 0;
+  k.flags = (a.state_in ? 1u : 0u) | (a.state_out ? 2u : 0u);
+  k.st_o = a.st_o;
+  k.st_ml = a.st_ml;
+  k.st_o_ld_b = (uint32_t)a.n_heads * 256u;
+  k.st_ml_ld_b = (uint32_t)a.n_heads * 16u;
+  for (int s = 0; s < a.n_seg; ++s) {
+    if (a.seg_len[s] == 0) continue;
+    f3r_attn_asm_seg& g = k.seg[k.n_seg++];
+    g.k = a.k_seg[s];
+    g.vt = a.vt_seg[s];
+    g.tiles = (uint32_t)(a.seg_len[s] / 64);
+    k.n_tiles += g.tiles;
+    k.ldvt_b = (uint32_t)(a.ldvt[s] * 2);
+    k.k_bs = (uint64_t)a.k_batch_stride[s] * 2;
+    k.vt_bs = (uint64_t)a.vt_batch_stride[s] * 2;
+  }
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.tq / 512), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);

@@ -97,8 +97,11 @@ int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger);
 int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_LAB builds only (tools/lab)
 
 // f3r_attn_asm.hip: the hand-scheduled attention kernel (csrc/asm/attn_gen.py) behind f3r_attn_fwd
-int f3r_attn_asm_segment(const f3r_attn_args& a, int64_t min_keys, const char** why);  // its K/V segment, or -1 (not eligible)
-int f3r_attn_asm_launch(const f3r_attn_args& a, int seg, hipStream_t stream);
+bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why);
+int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream);
+
+// f3r_attn_generic.hip: head_dim != 64
+int f3r_attn_generic_launch(const f3r_attn_args& a, hipStream_t stream);
 
 // host-side error plumbing (f3r_capi.cpp)
 void f3r_set_error(const char* fmt, ...);

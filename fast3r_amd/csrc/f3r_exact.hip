@@ -33,40 +33,38 @@ __global__ void rope2d_f32_kernel(float* __restrict__ qkv, int64_t rows, int64_t
 // softmax(q k^T * scale) v in fp32.  One thread = one query row of one head (q and the output row in registers), one 256-thread workgroup
 // = 256 consecutive queries of ONE sequence; 32-key tiles of K and V go through LDS (every lane reads the same address: broadcasts).
 constexpr int XQ = 256, XK = 32;
-template <class T>
+template <class T, int HD>
 __global__ __launch_bounds__(XQ) void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
                                                       uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo, float* __restrict__ o_f32, int64_t ldo,
                                                       int64_t seq_len, int qblocks, float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[XK][64];
-  __shared__ __attribute__((aligned(16))) float Vs[XK][64];
+  __shared__ __attribute__((aligned(16))) float Ks[XK][HD];
+  __shared__ __attribute__((aligned(16))) float Vs[XK][HD];
   const int head = blockIdx.y;
   const int64_t seq = blockIdx.x / qblocks;
   const int64_t qi = (int64_t)(blockIdx.x % qblocks) * XQ + threadIdx.x;  // query index inside the sequence
   const bool q_ok = qi < seq_len;
   const int64_t row0 = seq * seq_len;
-  float qr[64], o[64];
+  float qr[HD], o[HD];
   {
-    const float* src = q + (row0 + (q_ok ? qi : seq_len - 1)) * ld + head * 64;
+    const float* src = q + (row0 + (q_ok ? qi : seq_len - 1)) * ld + head * HD;
 #pragma unroll
-    for (int d = 0; d < 64; d += 4) {
+    for (int d = 0; d < HD; d += 4) {
       const float4v t = *(const float4v*)(src + d);
       qr[d] = t[0] * scale; qr[d + 1] = t[1] * scale; qr[d + 2] = t[2] * scale; qr[d + 3] = t[3] * scale;
     }
   }
 #pragma unroll
-  for (int d = 0; d < 64; ++d) o[d] = 0.f;
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
   float m = -INFINITY, l = 0.f;
   for (int64_t k0 = 0; k0 < seq_len; k0 += XK) {
     __syncthreads();  // the previous tile is consumed
     {
-      // 32 keys x 64 dims x 2 tensors = 1024 float4: 4 per thread
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int e = threadIdx.x + it * XQ;  // 0..511
-        const int kj = e >> 4, c4 = (e & 15) * 4;
+      // 32 keys x HD dims x 2 tensors as float4
+      for (int e = threadIdx.x; e < XK * (HD / 4); e += XQ) {
+        const int kj = e / (HD / 4), c4 = (e % (HD / 4)) * 4;
         const int64_t kr = k0 + kj < seq_len ? k0 + kj : seq_len - 1;
-        *(float4v*)&Ks[kj][c4] = *(const float4v*)(k + (row0 + kr) * ld + head * 64 + c4);
-        *(float4v*)&Vs[kj][c4] = *(const float4v*)(v + (row0 + kr) * ld + head * 64 + c4);
+        *(float4v*)&Ks[kj][c4] = *(const float4v*)(k + (row0 + kr) * ld + head * HD + c4);
+        *(float4v*)&Vs[kj][c4] = *(const float4v*)(v + (row0 + kr) * ld + head * HD + c4);
       }
     }
     __syncthreads();
@@ -77,7 +75,7 @@ __global__ __launch_bounds__(XQ) void attn_f32_kernel(const float* __restrict__ 
     for (int j = 0; j < XK; ++j) {
       float acc = 0.f;
 #pragma unroll
-      for (int d = 0; d < 64; d += 4) {
+      for (int d = 0; d < HD; d += 4) {
         const float4v kk = *(const float4v*)&Ks[j][d];
         acc = fmaf(qr[d], kk[0], acc); acc = fmaf(qr[d + 1], kk[1], acc); acc = fmaf(qr[d + 2], kk[2], acc); acc = fmaf(qr[d + 3], kk[3], acc);
       }
@@ -88,13 +86,13 @@ __global__ __launch_bounds__(XQ) void attn_f32_kernel(const float* __restrict__ 
     const float alpha = expf(m - m_new);  // exp(-inf) = 0 on the first tile
     l *= alpha;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] *= alpha;
+    for (int d = 0; d < HD; ++d) o[d] *= alpha;
 #pragma unroll
     for (int j = 0; j < XK; ++j) {
       const float p = expf(s[j] - m_new);  // 0 for the masked tail
       l += p;
 #pragma unroll
-      for (int d = 0; d < 64; d += 4) {
+      for (int d = 0; d < HD; d += 4) {
         const float4v vv = *(const float4v*)&Vs[j][d];
         o[d] = fmaf(p, vv[0], o[d]); o[d + 1] = fmaf(p, vv[1], o[d + 1]); o[d + 2] = fmaf(p, vv[2], o[d + 2]); o[d + 3] = fmaf(p, vv[3], o[d + 3]);
       }
@@ -103,9 +101,9 @@ __global__ __launch_bounds__(XQ) void attn_f32_kernel(const float* __restrict__ 
   }
   if (!q_ok) return;
   const float inv = 1.0f / l;
-  const int64_t orow = (row0 + qi) * ldo + head * 64;
+  const int64_t orow = (row0 + qi) * ldo + head * HD;
 #pragma unroll
-  for (int d = 0; d < 64; d += 4) {
+  for (int d = 0; d < HD; d += 4) {
     const float4v r = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
     if (o_f32) *(float4v*)(o_f32 + orow + d) = r;
     if (o_hi) {
@@ -142,22 +140,32 @@ extern "C" int f3r_rope2d_f32(float* qkv, int64_t rows, int64_t ld, int n_heads,
 }
 
 extern "C" int f3r_attn_f32(const float* q, const float* k, const float* v, int64_t ld, void* o_hi, void* o_lo, float* o_f32, int64_t ldo,
-                            int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, f3r_stream_t stream) {
+                            int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, int head_dim, f3r_stream_t stream) {
+  const int hd = head_dim == 0 ? 64 : head_dim;
+  F3R_REQUIRE(hd == 16 || hd == 32 || hd == 48 || hd == 64 || hd == 80 || hd == 96 || hd == 112 || hd == 128, "f3r_attn_f32: head_dim %d", head_dim);
   F3R_REQUIRE(q && k && v && (o_hi || o_f32), "f3r_attn_f32: null pointer");
   F3R_REQUIRE(dtype == F3R_F16 || dtype == F3R_BF16, "f3r_attn_f32: bad dtype %d", dtype);
   F3R_REQUIRE(al16(q) && al16(k) && al16(v) && ld % 4 == 0 && ldo % 4 == 0 && (!o_f32 || al16(o_f32)) && ((((uintptr_t)o_hi) | ((uintptr_t)o_lo)) & 7) == 0,
               "f3r_attn_f32: alignment (rows of q / k / v / o_f32 16-byte, o_hi / o_lo 8-byte, strides multiples of 4)");
   F3R_REQUIRE(!o_lo || o_hi, "f3r_attn_f32: a low plane needs its high plane");
-  F3R_REQUIRE(n_seq >= 0 && seq_len > 0 && n_heads > 0 && n_heads < 65536 && ld >= (int64_t)n_heads * 64 && ldo >= (int64_t)n_heads * 64, "f3r_attn_f32: bad sizes");
+  F3R_REQUIRE(n_seq >= 0 && seq_len > 0 && n_heads > 0 && n_heads < 65536 && ld >= (int64_t)n_heads * hd && ldo >= (int64_t)n_heads * hd, "f3r_attn_f32: bad sizes");
   if (n_seq == 0) return F3R_OK;
   const int64_t qblocks = (seq_len + XQ - 1) / XQ;
   F3R_REQUIRE(qblocks * n_seq < (1ll << 31), "f3r_attn_f32: grid too large");
   const dim3 grid((unsigned)(qblocks * n_seq), (unsigned)n_heads);
-  if (dtype == F3R_F16)
-    hipLaunchKernelGGL(attn_f32_kernel<F16>, grid, dim3(XQ), 0, (hipStream_t)stream, q, k, v, ld, (uint16_t*)o_hi, (uint16_t*)o_lo, o_f32, ldo, seq_len,
-                       (int)qblocks, scale);
-  else
-    hipLaunchKernelGGL(attn_f32_kernel<BF16>, grid, dim3(XQ), 0, (hipStream_t)stream, q, k, v, ld, (uint16_t*)o_hi, (uint16_t*)o_lo, o_f32, ldo, seq_len,
-                       (int)qblocks, scale);
+#define F3R_X(HDV)                                                                                                                              \
+  case HDV:                                                                                                                                     \
+    if (dtype == F3R_F16)                                                                                                                       \
+      hipLaunchKernelGGL((attn_f32_kernel<F16, HDV>), grid, dim3(XQ), 0, (hipStream_t)stream, q, k, v, ld, (uint16_t*)o_hi, (uint16_t*)o_lo, o_f32,   \
+                         ldo, seq_len, (int)qblocks, scale);                                                                                    \
+    else                                                                                                                                        \
+      hipLaunchKernelGGL((attn_f32_kernel<BF16, HDV>), grid, dim3(XQ), 0, (hipStream_t)stream, q, k, v, ld, (uint16_t*)o_hi, (uint16_t*)o_lo, o_f32,  \
+                         ldo, seq_len, (int)qblocks, scale);                                                                                    \
+    break;
+  switch (hd) {
+    F3R_X(16) F3R_X(32) F3R_X(48) F3R_X(64) F3R_X(80) F3R_X(96) F3R_X(112) F3R_X(128)
+    default: break;
+  }
+#undef F3R_X
   return f3r_check_launch("f3r_attn_f32");
 }

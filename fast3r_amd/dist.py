@@ -168,3 +168,92 @@ class ViewSharding:
             out.extend([{k: v.to(dev) for k, v in r.items()} for r in part])
         assert len(out) == n_total
         return out
+
+
+# ------------------------------------------------------------------------------------------------ one-GPU emulation of one rank
+class EmulatedKVExchange:
+    """KVExchange without a process group: ONE GPU plays rank `rank` of `world`.  The local shard is written by the QKV epilogue as in
+    the real exchange; the R-1 remote shards are either filled per layer by `kv_source(layer, r, k_out [T_r][D], vt_out [D][ld])`
+    (per-rank parity test: K / V^T captured from an unsharded forward) or left as they are (bench.py --emulate-rank: pre-filled once
+    with random operands -- the attention launches, their segment walk and the parked softmax state are exactly a rank's, only the
+    bytes that would have crossed xGMI are not real).  `comm_bytes_per_layer` = what the all-gather would move into this GPU."""
+
+    def __init__(self, world, rank, t_all, D, dtype, device, n_heads, q_dim, kv_source=None):
+        self.world, self.rank = world, rank
+        self.t_all, self.t_loc, self.D = list(t_all), t_all[rank], D
+        self.t_max = max(self.t_all)
+        self.ldvt = _round_up(self.t_max, 64)
+        self.k_loc = torch.zeros((self.t_max, D), dtype=dtype, device=device)
+        self.vt_loc = torch.zeros((1, D, self.ldvt), dtype=dtype, device=device)
+        self.k_all = torch.zeros((world, self.t_max, D), dtype=dtype, device=device)
+        self.vt_all = torch.zeros((world, D, self.ldvt), dtype=dtype, device=device)
+        self.kv_source = kv_source
+        if kv_source is None:  # timing only: operands of the model's own scale in the valid region, padding stays zero
+            g = torch.Generator(device=device).manual_seed(1234 + rank)
+            for r in range(world):
+                if r != rank and self.t_all[r] > 0:
+                    self.k_all[r, :self.t_all[r]] = torch.randn((self.t_all[r], D), generator=g, device=device).to(dtype)
+                    self.vt_all[r, :, :self.t_all[r]] = torch.randn((D, self.t_all[r]), generator=g, device=device).to(dtype)
+        self.has_remote = any(t > 0 for r, t in enumerate(self.t_all) if r != rank)
+        self.state = None
+        if self.has_remote and self.t_loc > 0:
+            self.state = (torch.empty((self.t_loc, q_dim), dtype=torch.float32, device=device),
+                          torch.empty((self.t_loc, n_heads, 4), dtype=torch.float32, device=device))
+        self.layer = 0
+        self.comm_bytes_per_layer = sum(2 * t * D * self.k_all.element_size() for r, t in enumerate(self.t_all) if r != rank)
+
+    positions = KVExchange.positions
+    remote_positions = KVExchange.remote_positions
+    local_segment = KVExchange.local_segment
+
+    def start(self):
+        if self.kv_source is not None:
+            for r in range(self.world):
+                if r != self.rank and self.t_all[r] > 0:
+                    self.kv_source(self.layer, r, self.k_all[r, :self.t_all[r]], self.vt_all[r, :, :self.t_all[r]])
+        self.layer += 1
+
+    def finish(self):
+        return [(self.k_all[r], self.vt_all[r], self.t_all[r], 0, 0) for r in range(self.world) if r != self.rank and self.t_all[r] > 0]
+
+
+class EmulatedSharding:
+    """Drop-in for ViewSharding on ONE GPU: the model runs the views, launches and buffers of rank `rank` of a `world`-rank job with no
+    collective (Fast3R.emulate_rank).  Views must have one size (the token count of the other ranks is derived from it)."""
+
+    def __init__(self, world, rank, kv_source=None):
+        if not (1 <= world <= 8 and 0 <= rank < world):
+            raise ValueError("emulated sharding: 1 <= world <= 8 (K/V segments of one MI355X node), 0 <= rank < world")
+        self.world, self.rank, self.kv_source = world, rank, kv_source
+        self.group, self.gather_outputs = None, False
+        self._n_total = None
+        self._kvx = None
+        self.last_exchange = None
+
+    def my_range(self, n_views):
+        self._n_total = n_views
+        return split_range(n_views, self.world, self.rank)
+
+    def broadcast_ids(self, ids, dev):
+        return ids
+
+    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None):
+        lo, hi = split_range(self._n_total, self.world, self.rank)
+        assert hi > lo and t_loc % (hi - lo) == 0, "emulated sharding needs views of one size"
+        per_view = t_loc // (hi - lo)
+        t_all = []
+        for r in range(self.world):
+            a, b = split_range(self._n_total, self.world, r)
+            t_all.append((b - a) * per_view)
+        q_dim = D if q_dim is None else q_dim
+        n_heads = q_dim // 64 if n_heads is None else n_heads
+        key = (tuple(t_all), D, dtype, str(dev), n_heads, q_dim)
+        if self._kvx is None or self._kvx[0] != key:
+            self._kvx = (key, EmulatedKVExchange(self.world, self.rank, t_all, D, dtype, dev, n_heads, q_dim, self.kv_source))
+        kvx = self._kvx[1]
+        kvx.layer = 0
+        self.last_exchange = kvx
+        return kvx
+
+    def gather_results(self, results, n_total, dev):
+        return results

@@ -160,8 +160,11 @@ class Fast3RDecoder(_Params):
         super().__init__()
         if attn_implementation not in ("pytorch_naive", "flash_attention", "pytorch_auto"):
             raise ValueError(f"Unknown attn_implementation: {attn_implementation}")
-        if embed_dim // num_heads != 64:
-            raise ValueError("fast3r_amd kernels are built for head_dim 64")
+        hd = embed_dim // num_heads
+        if embed_dim % num_heads != 0 or hd % 16 != 0 or not 16 <= hd <= 128:
+            # the reference takes any dim // num_heads (blocks.py:113-143); 64 runs the tuned attention kernels, the other multiples of
+            # 16 up to 128 (model_scaling_huge.yaml: 1280 / 16 = 80) the generic one (f3r_attn_generic.hip)
+            raise ValueError(f"fast3r_amd attention kernels are built for head_dim = a multiple of 16 up to 128 (got {embed_dim} / {num_heads})")
         self.embed_dim, self.num_heads, self.depth = embed_dim, num_heads, depth
         self.random_image_idx_embedding = random_image_idx_embedding
         self.attn_bias_for_inference_enabled = attn_bias_for_inference_enabled
@@ -335,10 +338,11 @@ class PixelwiseTaskWithDPT(_Params):
 # ======================================================================================= packed (device) weights
 class _PackedBlock:
     __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal")
+                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim")
 
     def __init__(self):
         self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
+        self.head_dim = 64  # the Fast3R fusion decoder may have another width (model_scaling_huge.yaml: 80)
         self.q_dim, self.kv_dim, self.kv_group, self.causal = 0, None, 1, False  # grouped-query / causal attention (LlamaDecoder only)
 
 
@@ -346,8 +350,9 @@ def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 
 
-def _pack_block(blk: _Block, lp, split=False):
+def _pack_block(blk: _Block, lp, split=False, head_dim=64):
     p = _PackedBlock()
+    p.head_dim = head_dim
     p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
     p.eps = blk.norm1.eps
     p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp, split), _f32(blk.attn.qkv.bias)
@@ -529,6 +534,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         self.precision = precision
         self.sharding = None  # set by shard_views(): view-sharded multi-GPU execution (fast3r_amd/dist.py)
         self.debug_taps = None  # set to a dict to capture the lowp DPT inputs (hooks 0, L/2, 3L/4, L) per sample
+        self.kv_tap = None  # callable(k, vt): sees every fusion layer's K [T][D] / V^T [D][ld] of an UNSHARDED forward (tests)
         self.use_graphs = False  # enable_graphs(): hipGraph replay of small scenes
         self._graphs = _GraphCache()
         self._packed = None
@@ -641,6 +647,15 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         self.sharding = ViewSharding(process_group)
         return self
 
+    def emulate_rank(self, rank, world, kv_source=None):
+        """ONE GPU runs exactly rank `rank`'s share of a `world`-rank view-sharded forward -- its views through the encoder, the fusion
+        layers as local launch (parking the softmax state) + remote launch over world - 1 K / V^T segments, its heads -- with no
+        collective (dist.EmulatedSharding).  kv_source fills the remote segments per layer (parity test); without it they hold random
+        operands (bench.py --emulate-rank: a per-rank step time, clearly not a multi-GPU measurement).  `emulate_rank(None, 0)` undoes it."""
+        from .dist import EmulatedSharding
+        self.sharding = None if rank is None else EmulatedSharding(world, rank, kv_source)
+        return self
+
     # ---------------------------------------------------------------- packed weights
     def load_state_dict(self, state_dict, strict=True, assign=False):
         self.invalidate_packed_weights()
@@ -713,7 +728,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
-            pk["dec"] = [_pack_block(b, lp, hp) for b in dec.dec_blocks]
+            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads) for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
         pk["head"] = _pack_head(self.downstream_head, lp, hp)
         pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None
@@ -732,7 +747,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         hidden = pb.fc1_w.shape[0]  # rows of the (possibly stacked [w1; w3]) up-projection
         return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=pb.kv_dim)
 
-    def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None):
+    def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None, kv_tap=None):
         """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
         with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single.
         ws: the pass's BlockWorkspace (made here when absent): no per-layer allocation."""
@@ -752,8 +767,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
         ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp, q_dim=pb.q_dim)
+        if kv_tap is not None and kv_exchange is None:
+            kv_tap(k, vt)  # the K / V^T of this fusion layer (capture for the per-rank emulation test)
         o = h  # LN output is dead: reuse as the attention output buffer
-        gqa = dict(kv_group=pb.kv_group, causal=pb.causal)
+        gqa = dict(kv_group=pb.kv_group, causal=pb.causal, head_dim=pb.head_dim)
         if kv_exchange is None:
             Dkv = k.shape[1]
             ops.attention(q, o, n_heads, scale, [(k, vt, seq_len, seq_len * Dkv, Dkv * ldvt)], tq=seq_len, batch=n_seq,
@@ -796,7 +813,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         qkv, _ = ops.gemm(h, pb.qkv_w, bias=pb.qkv_b, want_f32=True, split="x3", a_lo=hl)
         if rope is not None:
             ops.rope2d_f32(qkv, n_heads, seq_len, rope)
-        o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp)
+        o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, head_dim=pb.head_dim)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split="x3", a_lo=ol)
         _, hf = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, want_lp=False, want_f32=True, out_f32=hf)
         h, hl = self._pair(hf)
@@ -954,7 +971,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 taps[0] = planes(x)
             for li, pb in enumerate(pk["dec"]):
                 ops.rows_add(x, pk["view0"], view0_rows)
-                self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx, ws=ws)
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, rope, kvx, ws=ws, kv_tap=self.kv_tap)
                 if (li + 1) in hooks and (li + 1) != L:
                     taps[li + 1] = planes(x)
             if L in hooks:
@@ -976,7 +993,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     r0 += Ps[i]
             taps = {0: (enc_hi.float(), None) if f32_hooks else (enc_hi, enc_lo)}
             for li, pb in enumerate(pk["dec"]):
-                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx, ws=ws)
+                self._block(x, pb, dec.num_heads, scale, T_loc, 1, None, kvx, ws=ws, kv_tap=self.kv_tap)
                 if (li + 1) in hooks[1:3]:
                     taps[li + 1] = planes(x)
             w_, b_, eps = pk["dec_norm"]
@@ -988,10 +1005,11 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return [taps[hk] for hk in hooks]
 
     @torch.no_grad()
-    def decode_tokens(self, enc_tokens, tokens_per_view, image_ids, return_f32=False):
+    def decode_tokens(self, enc_tokens, tokens_per_view, image_ids, return_f32=False, enc_tokens_lo=None):
         """The fusion decoder alone (BASELINE configs[1]: "fusion transformer only, frozen random encoder"): enc_tokens lowp
         [sum(tokens_per_view)][enc_embed_dim] on the GPU, image_ids (N,) or (1, N) long -> the 4 hooked outputs [T][D], lowp as the
-        heads read them, or fp32 before that rounding with return_f32."""
+        heads read them, or fp32 before that rounding with return_f32.  enc_tokens_lo: optional low plane of the tokens (split-precision
+        modes: tokens = enc_tokens + enc_tokens_lo), default zero."""
         dev = enc_tokens.device
         if dev.type != "cuda":
             raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (tokens are on {dev}); there is no CPU fallback")
@@ -1002,7 +1020,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             emb_rows = self.decoder.image_idx_emb.to(dev)[ids]
             enc_lo = None
             if self._hp and not isinstance(self.decoder, LlamaDecoder):
-                enc_lo = torch.zeros_like(enc_tokens)
+                enc_lo = torch.zeros_like(enc_tokens) if enc_tokens_lo is None else enc_tokens_lo.contiguous()
             out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None, f32_hooks=return_f32)
             return [t[0] for t in out]
 

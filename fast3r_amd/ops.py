@@ -314,14 +314,14 @@ def convT(x, w, bias_tiled, s, cout, split=None, x_lo=None, want_lo=False, kerne
     return (out, out_lo) if want_lo else out
 
 
-def attention_state(tq_total: int, n_heads: int, device):
-    """Buffers for an online softmax carried across launches: (st_o fp32 [tq][heads*64], st_ml fp32 [tq][heads][4])."""
-    return (torch.empty((tq_total, n_heads * 64), dtype=torch.float32, device=device),
+def attention_state(tq_total: int, n_heads: int, device, head_dim: int = 64):
+    """Buffers for an online softmax carried across launches: (st_o fp32 [tq][heads*head_dim], st_ml fp32 [tq][heads][4])."""
+    return (torch.empty((tq_total, n_heads * head_dim), dtype=torch.float32, device=device),
             torch.empty((tq_total, n_heads, 4), dtype=torch.float32, device=device))
 
 
 def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
-              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0):
+              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0, head_dim=64):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][kv_heads*64][ldvt].  kv_group: query heads per K / V head (grouped-query attention).
     causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices).
@@ -345,6 +345,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     a.q_prescaled = int(q_prescaled)
     a.kv_group, a.causal, a.q_pos0 = int(kv_group), int(bool(causal)), int(q_pos0)
     a.kernel_sel = int(kernel_sel)
+    a.head_dim = int(head_dim)
     if causal:
         pos = [0] * len(segments)
         if seg_pos0 is None:  # consecutive segments of one sequence starting at position 0
@@ -366,7 +367,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     if ATTN_TIMER is not None:
         e1.record()
         t_k = sum(int(s[2]) for s in segments)
-        ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * 64 * n_heads * batch))
+        ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * head_dim * n_heads * batch, int(a.tq), int(t_k)))
     return out
 
 
@@ -432,19 +433,19 @@ def rope2d_f32(qkv, n_heads, seq_len, rope):
     return qkv
 
 
-def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False):
+def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_dim=64):
     """precision "exact": fp32 softmax attention over qkv[T][3D] fp32 (q | k | v column blocks, 64 per head) -> (o_hi, o_lo) lowp planes
     [T][D] (the A operand of the X3 projection) [, o fp32 with want_f32]."""
     require_gpu(qkv, "qkv")
     assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1
-    T, D = qkv.shape[0], n_heads * 64
+    T, D = qkv.shape[0], n_heads * head_dim
     assert qkv.shape[1] == 3 * D and T == n_seq * seq_len
     o_hi = torch.empty((T, D), dtype=lp, device=qkv.device)
     o_lo = torch.empty((T, D), dtype=lp, device=qkv.device)
     o32 = torch.empty((T, D), dtype=torch.float32, device=qkv.device) if want_f32 else None
     base = qkv.data_ptr()
     check(_lib.lib().f3r_attn_f32(base, base + D * 4, base + 2 * D * 4, qkv.stride(0), ptr(o_hi), ptr(o_lo), ptr(o32), D, n_seq, seq_len, n_heads,
-                                  float(scale), dtype_id(lp), stream_ptr()), "f3r_attn_f32")
+                                  float(scale), dtype_id(lp), int(head_dim), stream_ptr()), "f3r_attn_f32")
     return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 

@@ -35,13 +35,15 @@ def vit_large_args(img_size=512, attn_implementation="flash_attention", random_i
 def tiny_args(embed_dim=128, num_heads=2, enc_depth=2, dec_depth=12, img_size=64, with_local_head=True,
               random_image_idx_embedding=True, attn_implementation="pytorch_naive",
               attn_bias_for_inference_enabled=True, decoder_type="fast3r", llama_layers=12,
-              patch_embed_cls="PatchEmbedDust3R", landscape_only=False, llama_kv_heads=None, llama_causal=False):
-    """Small model of the same family (head_dim stays 64; decoder depth must be > 9, fast3r.py:137)."""
+              patch_embed_cls="PatchEmbedDust3R", landscape_only=False, llama_kv_heads=None, llama_causal=False,
+              dec_embed_dim=None, dec_num_heads=None):
+    """Small model of the same family (head_dim 64 unless dec_embed_dim / dec_num_heads give the fusion decoder another width, as in
+    configs/experiment/model_scaling/model_scaling_huge.yaml; decoder depth must be > 9, fast3r.py:137)."""
     encoder_args = dict(encoder_type="croco", img_size=img_size, patch_size=16, patch_embed_cls=patch_embed_cls,
                         embed_dim=embed_dim, num_heads=num_heads, depth=enc_depth, mlp_ratio=4, pos_embed="RoPE100",
                         attn_implementation=attn_implementation)
     decoder_args = dict(decoder_type="fast3r", random_image_idx_embedding=random_image_idx_embedding,
-                        enc_embed_dim=embed_dim, embed_dim=embed_dim, num_heads=num_heads, depth=dec_depth,
+                        enc_embed_dim=embed_dim, embed_dim=dec_embed_dim or embed_dim, num_heads=dec_num_heads or num_heads, depth=dec_depth,
                         mlp_ratio=4.0, qkv_bias=True, drop=0.0, attn_drop=0.0,
                         attn_implementation=attn_implementation,
                         attn_bias_for_inference_enabled=attn_bias_for_inference_enabled)

@@ -173,7 +173,7 @@ int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
 
 /* ---------------------------------------------------------------------------------------------
- * f3r_attn_fwd: O = softmax(scale * Q K^T) V, non-causal, head_dim 64, flash-style (never forms
+ * f3r_attn_fwd: O = softmax(scale * Q K^T) V, head_dim 64 (other widths: f3r_attn_args.head_dim), flash-style (never forms
  * the T x T matrix), fp32 online softmax.  Replaces the q@k^T -> softmax -> @v core of
  * Attention.forward (blocks.py:158-190; all three `attn_implementation`s compute this).
  * K/V arrive as up to F3R_MAX_SEG segments so that the view-sharded multi-GPU path can attend
@@ -225,10 +225,16 @@ typedef struct f3r_attn_args {
   /* Kernel choice (per call, like f3r_gemm_args.kernel_sel; no process-wide switch):
        0 = automatic: the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_gen.py: 512-query workgroups, 128 queries per
            wave) when the launch is eligible -- no causal mask, q_prescaled, tq a multiple of 512, every non-empty K/V segment a
-           multiple of 64 keys, at least F3R_ATTN_ASM_MIN_KEYS keys, kv_group a power of two -- and the general HIP kernel otherwise;
+           multiple of 64 keys with one ldvt and one pair of batch strides, at least F3R_ATTN_ASM_MIN_KEYS keys in total, kv_group a
+           power of two, batch 1 when the softmax state is carried (state_in / state_out; the state layout is the HIP kernel's, so
+           the two kernels can resume each other's launches) -- and the general HIP kernel otherwise;
        1 = the general HIP kernel;  2 = the hand-scheduled kernel (F3R_ERR_UNSUPPORTED if the launch is not eligible). */
   int32_t kernel_sel;
-  int32_t reserved0;
+  /* Width of a head: 0 or 64 = the tuned kernels; any other multiple of 16 up to 128 (the reference's Attention takes any dim //
+     num_heads, blocks.py:113-143; its model_scaling_huge.yaml fusion decoder has 80) runs the generic kernel (f3r_attn_generic.hip):
+     same layouts with head_dim columns per head (q / k / o rows, head_dim V^T planes per head, st_o rows of n_heads * head_dim),
+     no causal mask. */
+  int32_t head_dim;
 } f3r_attn_args;
 #define F3R_ATTN_ASM_MIN_KEYS 2048
 
@@ -349,13 +355,13 @@ int f3r_rows_add_f32(float* x, const float* vec, int64_t rows, int D, f3r_stream
  * f3r_rope2d_f32: RoPE-2D (pos_embed.py:162-183) in place on the q and k parts of qkv[rows][ld] (the first 2 * n_heads * 64 columns);
  *   tables as in f3r_gemm_args.rope_cos / rope_sin ([n_pos][16]), token t of a sequence sits at (t / rope_w, t % rope_w).
  * f3r_attn_f32: o[r][h*64 + d] = sum_j softmax_j(q[r] . k[j] * scale) v[j][d] over the keys of r's sequence (n_seq sequences of seq_len
- *   rows; q, k, v row stride ld floats, 64 floats per head).  Output as fp32 (o_f32) and / or as lowp hi [+ lo] planes ([rows][ldo]), the
+ *   rows; q, k, v row stride ld floats, head_dim floats per head: 0 or 64, or another multiple of 16 up to 128).  Output as fp32 (o_f32) and / or as lowp hi [+ lo] planes ([rows][ldo]), the
  *   A operand of the X3 projection that follows.
  */
 int f3r_rope2d_f32(float* qkv, int64_t rows, int64_t ld, int n_heads, int64_t seq_len, int rope_w, const float* rope_cos,
                    const float* rope_sin, f3r_stream_t stream);
 int f3r_attn_f32(const float* q, const float* k, const float* v, int64_t ld, void* o_hi, void* o_lo, float* o_f32, int64_t ldo,
-                 int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, f3r_stream_t stream);
+                 int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, int head_dim, f3r_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,14 @@ def test_emulated_kernel_batch_gqa_and_second_query_block():
     assert err < 6e-4
 
 
+@pytest.mark.parametrize("tiles,split", [((1, 2), False), ((2, 1, 3), False), ((1, 1, 1, 1, 1, 1, 1, 1), False), ((2, 3), True), ((1, 2, 1), True)])
+def test_emulated_kernel_walks_segments_and_carries_the_softmax_state(tiles, split):
+    """K/V as several segments (the view-sharded layout; a segment hop in the LDS-DMA stream) in one launch, or as two launches that
+    park / resume the online-softmax state (f3r_attn_args.state_out / state_in)"""
+    import emu_attn
+    assert emu_attn.run_case("f16", list(tiles), n_heads=2, wgs=((0, 1, 0),), spike=True, split_state=split) < 6e-4
+
+
 def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     import attn_gen
     gens = attn_gen.product_generators()

@@ -129,6 +129,39 @@ def test_asm_kernel_grouped_query_and_batch(built_lib, dt):
     assert_close(o.float(), ref, 2 * lp_tol(dt), "gqa + batch")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_asm_kernel_segments_and_carried_state(built_lib, dt):
+    """The view-sharded layout: K/V as segments (one launch over all of them == one launch over their concatenation), and the
+    two-launch form (local segment with state_out, remote segments with state_in) == one launch, bit for bit -- for the hand-scheduled
+    kernel alone and with the general HIP kernel taking either launch (one state layout for both)."""
+    H, Tq = 2, 1024
+    lens = [192, 64, 320, 128]
+    qs = rnd((Tq, H * 64), dt, 70, 0.125 * LOG2E * 1.5)
+    ks = [rnd((n, H * 64), dt, 71 + i, 1.5) for i, n in enumerate(lens)]
+    vs = [rnd((n, H * 64), dt, 81 + i) for i, n in enumerate(lens)]
+    ld = ops.vt_ld(max(lens))
+
+    def vt_pad(v):
+        vt = torch.zeros((H * 64, ld), dtype=dt)
+        vt[:, :v.shape[0]] = v.t()
+        return vt
+    segs = [(kk.to(DEV), vt_pad(vv).to(DEV), n, 0, 0) for kk, vv, n in zip(ks, vs, lens)]
+    ref = ref_prescaled(qs, torch.cat(ks), torch.cat(vs), H)
+    q = qs.to(DEV)
+    one = torch.full((Tq, H * 64), float("nan"), dtype=dt, device=DEV)
+    ops.attention(q, one, H, 1.0, segs, q_prescaled=True, kernel_sel=2)
+    assert_close(one.float(), ref, 2 * lp_tol(dt), "segments, one launch")
+    for sel_local, sel_remote in ((2, 2), (2, 1), (1, 2)):
+        two = torch.full((Tq, H * 64), float("nan"), dtype=dt, device=DEV)
+        state = ops.attention_state(Tq, H, DEV)
+        ops.attention(q, two, H, 1.0, segs[:1], q_prescaled=True, state=state, state_out=True, kernel_sel=sel_local)
+        assert torch.isnan(two.float()).all()  # the first launch must not write the output
+        ops.attention(q, two, H, 1.0, segs[1:], q_prescaled=True, state=state, state_in=True, kernel_sel=sel_remote)
+        if (sel_local, sel_remote) == (2, 2):
+            assert torch.equal(one, two)  # same tiles in the same order, state kept in fp32
+        assert_close(two.float(), ref, 2 * lp_tol(dt), f"state carry, kernels {sel_local} -> {sel_remote}")
+
+
 def test_asm_kernel_is_the_automatic_choice_and_refuses_what_it_cannot_do(built_lib):
     dt = torch.float16
     H, Tq, Tk = 1, 512, 2048

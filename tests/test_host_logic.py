@@ -83,6 +83,21 @@ def test_constructor_errors_match_reference_types():
         Fast3R(dict(enc, attn_implementation="nope"), dec, head)  # blocks.py:192
 
 
+def test_the_scaling_ablation_decoder_builds():
+    """configs/experiment/model_scaling/model_scaling_huge.yaml:13-15: fusion decoder 1280 wide, 16 heads (head_dim 80), depth 32 -- the
+    reference's Attention takes any dim // num_heads (blocks.py:113-143); widths that are not a multiple of 16 are refused by name."""
+    from fast3r_amd.fast3r import Fast3RDecoder
+    dec = Fast3RDecoder(True, 1024, embed_dim=1280, num_heads=16, depth=2)  # (depth 32 in the config: the layer count is free)
+    assert dec.embed_dim // dec.num_heads == 80 and abs(dec.attention_scale(True) - 80 ** -0.5) < 1e-12
+    sd = dec.state_dict()
+    assert sd["dec_blocks.0.attn.qkv.weight"].shape == (3 * 1280, 1280) and sd["decoder_embed.weight"].shape == (1280, 1024)
+    enc, decargs, head = tiny_args(dec_embed_dim=160)
+    m = Fast3R(enc, decargs, head)
+    assert m.decoder.embed_dim // m.decoder.num_heads == 80
+    with pytest.raises(ValueError, match="multiple of 16"):
+        Fast3RDecoder(True, 128, embed_dim=200, num_heads=2, depth=12)
+
+
 def test_no_cpu_fallback():
     m = Fast3R(*tiny_args()).eval()
     with pytest.raises(F3RError):

@@ -425,6 +425,72 @@ def test_attention_state_carried_across_launches(built_lib, dt):
     assert_close(two.float(), _attn_ref(q, torch.cat(ks), torch.cat(vs), H, 0.125), 2 * lp_tol(dt), "state carry")
 
 
+# ------------------------------------------------------------------------------------------------ head_dim != 64 (f3r_attn_generic.hip)
+def _attn_ref_hd(q, k, v, H, Hkv, hd, scale):
+    Tq = q.shape[0]
+    qh = q.double().reshape(Tq, H, hd).transpose(0, 1)
+    kh = k.double().reshape(-1, Hkv, hd).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    vh = v.double().reshape(-1, Hkv, hd).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    return (((qh @ kh.transpose(1, 2)) * scale).softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * hd)
+
+
+def _vt_hd(v, ld=None):
+    T = v.shape[0]
+    vt = torch.zeros((v.shape[1], ops.vt_ld(T) if ld is None else ld), dtype=v.dtype)
+    vt[:, :T] = v.t()
+    return vt
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd,T,H,Hkv", [(80, 200, 2, 2), (80, 1024, 3, 3), (128, 333, 2, 1), (32, 130, 4, 4), (96, 64, 1, 1), (16, 77, 2, 2)])
+def test_attention_generic_head_dim(built_lib, dt, hd, T, H, Hkv):
+    """The reference's Attention takes any dim // num_heads (blocks.py:113-143; model_scaling_huge.yaml: 80): the generic kernel vs fp64,
+    incl. partial key tiles, ragged query blocks and grouped-query heads."""
+    scale = hd ** -0.5
+    q, k, v = rnd((T, H * hd), dt, 120), rnd((T, Hkv * hd), dt, 121), rnd((T, Hkv * hd), dt, 122)
+    o = torch.full((T, H * hd), float("nan"), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), o, H, scale, [(k.to(DEV), _vt_hd(v).to(DEV), T, 0, 0)], head_dim=hd, kv_group=H // Hkv)
+    assert_close(o.float(), _attn_ref_hd(q, k, v, H, Hkv, hd, scale), 2 * lp_tol(dt), f"attn head_dim {hd}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_generic_head_dim_segments_state_batch(built_lib, dt):
+    """head_dim 80: K/V segments (incl. an empty one) == their concatenation; two launches carrying (m, l, O) == one; batched sequences."""
+    hd, H, Tq = 80, 2, 300
+    lens = [130, 0, 64, 257]
+    scale = hd ** -0.5
+    q = rnd((Tq, H * hd), dt, 130)
+    ks = [rnd((max(n, 1), H * hd), dt, 131 + i) for i, n in enumerate(lens)]
+    vs = [rnd((max(n, 1), H * hd), dt, 141 + i) for i, n in enumerate(lens)]
+    segs = [(kk.to(DEV), _vt_hd(vv[:max(n, 1)] * (1 if n else 0)).to(DEV), n, 0, 0) for kk, vv, n in zip(ks, vs, lens)]
+    kcat = torch.cat([kk[:n] for kk, n in zip(ks, lens)])
+    vcat = torch.cat([vv[:n] for vv, n in zip(vs, lens)])
+    ref = _attn_ref_hd(q, kcat, vcat, H, H, hd, scale)
+    one = torch.empty((Tq, H * hd), dtype=dt, device=DEV)
+    ops.attention(q.to(DEV), one, H, scale, segs, head_dim=hd)
+    assert_close(one.float(), ref, 2 * lp_tol(dt), "segments")
+    two = torch.full((Tq, H * hd), float("nan"), dtype=dt, device=DEV)
+    state = ops.attention_state(Tq, H, DEV, head_dim=hd)
+    ops.attention(q.to(DEV), two, H, scale, segs[:1], state=state, state_out=True, head_dim=hd)
+    assert torch.isnan(two.float()).all()
+    ops.attention(q.to(DEV), two, H, scale, segs[1:], state=state, state_in=True, head_dim=hd)
+    assert torch.equal(one, two)
+    nb, S = 3, 90
+    D = H * hd
+    qb, kb, vb = rnd((nb * S, D), dt, 150), rnd((nb * S, D), dt, 151), rnd((nb * S, D), dt, 152)
+    ld = ops.vt_ld(S)
+    vt = torch.zeros((nb, D, ld), dtype=dt)
+    for b in range(nb):
+        vt[b, :, :S] = vb[b * S:(b + 1) * S].t()
+    o = torch.empty((nb * S, D), dtype=dt, device=DEV)
+    ops.attention(qb.to(DEV), o, H, scale, [(kb.to(DEV), vt.to(DEV), S, S * D, D * ld)], tq=S, batch=nb, q_batch_stride=S * D, o_batch_stride=S * D,
+                  head_dim=hd)
+    refb = torch.cat([_attn_ref_hd(qb[b * S:(b + 1) * S], kb[b * S:(b + 1) * S], vb[b * S:(b + 1) * S], H, H, hd, scale) for b in range(nb)])
+    assert_close(o.float(), refb, 2 * lp_tol(dt), "batched head_dim 80")
+    with pytest.raises(ValueError, match="causal"):
+        ops.attention(q.to(DEV), one, H, scale, segs, head_dim=hd, causal=True)
+
+
 # ------------------------------------------------------------------------------------------------ grouped-query / causal attention
 def _attn_ref_general(q, k, v, H, Hkv, scale, causal=False, q_pos0=0, k_pos=None):
     """q (Tq, H*64), k / v (Tk, Hkv*64) -> fp64 softmax(q k^T scale [+ causal mask]) v with repeat_kv (llama.py:125-134)."""

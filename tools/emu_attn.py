@@ -1,6 +1,8 @@
 """Run the generated attention kernel (fast3r_amd/csrc/asm/attn_gen.py) in the CPU emulator against a float64 softmax reference.
 
-python tools/emu_attn.py [--dtype f16|bf16] [--tiles N] [--heads H] [--spike] [--rowsum dot2c|add]
+python tools/emu_attn.py [--dtype f16|bf16] [--tiles N[,N..]] [--heads H] [--spike] [--rowsum pkadd|add|dot2c] [--split-state]
+  --tiles a,b,c   K/V arrive as segments of a, b, c tiles (the view-sharded layout)
+  --split-state   two launches: segment 0 with state_out, the remaining segments with state_in (the multi-GPU two-launch form)
 """
 import argparse
 import os
@@ -16,10 +18,24 @@ import attn_gen  # noqa: E402
 from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
 
 
-def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="add", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None):
+def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0):
+    """segs: [(k address, vt address, tiles)] -> the kernel argument block (byte strides)"""
+    nt = sum(t for _, _, t in segs)
+    b = struct.pack("<QQIIIIIIQQIIQQQQIIQ", q, o, ldq, ldk, ldvt, ldo, nt, len(segs), q_bs, o_bs, kv_shift, flags, st_o, st_ml, k_bs, vt_bs,
+                    st_o_ld, st_ml_ld, 0)
+    assert len(b) == attn_gen.ARG_SEG
+    for i in range(8):
+        k, vt, t = segs[i] if i < len(segs) else (0, 0, 0)
+        b += struct.pack("<QQII", k, vt, t, 0)
+    assert len(b) == attn_gen.ARG_SIZE
+    return b
+
+
+def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
+             gen_kwargs=None, split_state=False):
     rng = np.random.default_rng(seed)
-    tq, tk = 512 * q_blocks, 64 * n_tiles
+    seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
+    tq, tk = 512 * q_blocks, 64 * sum(seg_tiles)
     D = n_heads * 64
     kv_heads = n_heads >> kv_shift
     Dk = kv_heads * 64
@@ -32,31 +48,50 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         k[:, tk - 40, :] = q[:, 7, :Dk] * 3.0 if kv_shift == 0 else k[:, tk - 40, :] * 6.0
     qh = f32_to_half(q * (scale * LOG2E), dtype)            # pre-scaled, as the QKV epilogue writes it
     kh = f32_to_half(k, dtype)
-    ldvt = tk
-    vth = np.zeros((batch, Dk, ldvt), np.uint16)
-    vth[:, :, :tk] = f32_to_half(np.transpose(v, (0, 2, 1)), dtype)
+    ldvt = 64 * max(seg_tiles)
     mem = Memory()
-    a_q, a_k, a_vt = mem.alloc(qh), mem.alloc(kh), mem.alloc(vth)
+    a_q = mem.alloc(qh)
+    segs, key0 = [], 0
+    vth_all = f32_to_half(np.transpose(v, (0, 2, 1)), dtype)   # [batch][Dk][tk]
+    for t in seg_tiles:
+        n = 64 * t
+        ks = np.ascontiguousarray(kh[:, key0:key0 + n])
+        vts = np.zeros((batch, Dk, ldvt), np.uint16)
+        vts[:, :, :n] = vth_all[:, :, key0:key0 + n]
+        segs.append((mem.alloc(ks), mem.alloc(vts), t, n))
+        key0 += n
+    if batch > 1:
+        assert len(segs) == 1
     o = np.full((batch, tq, D), 0x7E00, np.uint16)
     a_o = mem.alloc(o)
-    karg = struct.pack("<QQQQIIIIIIQQQQII", a_q, a_k, a_vt, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, n_tiles, 0,
-                       tq * D * 2, tk * Dk * 2, Dk * ldvt * 2, tq * D * 2, kv_shift, 0)
-    assert len(karg) == attn_gen.ARG_SIZE
-    a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
+    st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
+    st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
+    common = dict(q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
+                  st_o_ld=D * 4, st_ml_ld=n_heads * 16)
+    launches = []
+    if split_state:
+        assert len(segs) >= 2 and batch == 1
+        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[:1]], flags=attn_gen.FLAG_STATE_OUT, **common))
+        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
+    else:
+        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
     g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
     worst = 0.0
     for wg in wgs:
-        w = Workgroup(prog, mem, a_arg, wg, 4, attn_gen.LDS_BYTES, dtype)
-        steps = w.run()
+        steps = 0
+        for karg in launches:
+            a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
+            w = Workgroup(prog, mem, a_arg, wg, 4, attn_gen.LDS_BYTES, dtype)
+            steps += w.run()
         og = mem.get(a_o, np.uint16, (batch, tq, D))
         x, head, b = wg
         kvh = head >> kv_shift
         qf = half_to_f32(qh[b, x * 512:(x + 1) * 512, head * 64:(head + 1) * 64], dtype).astype(np.float64)
         kf = half_to_f32(kh[b, :, kvh * 64:(kvh + 1) * 64], dtype).astype(np.float64)
-        vf = half_to_f32(vth[b, kvh * 64:(kvh + 1) * 64, :tk], dtype).astype(np.float64).T
+        vf = half_to_f32(vth_all[b, kvh * 64:(kvh + 1) * 64, :], dtype).astype(np.float64).T
         s = qf @ kf.T
         p = np.exp2(s - s.max(axis=1, keepdims=True))
         ref = (p @ vf) / p.sum(axis=1, keepdims=True)
@@ -70,10 +105,12 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f16")
-    ap.add_argument("--tiles", type=int, default=3)
+    ap.add_argument("--tiles", default="3")
     ap.add_argument("--heads", type=int, default=2)
     ap.add_argument("--spike", action="store_true")
-    ap.add_argument("--rowsum", default="add")
+    ap.add_argument("--rowsum", default="pkadd")
     ap.add_argument("--cvt", default="rne")
+    ap.add_argument("--split-state", action="store_true")
     a = ap.parse_args()
-    run_case(a.dtype, a.tiles, a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt))
+    tiles = [int(x) for x in a.tiles.split(",")]
+    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state)

@@ -242,8 +242,8 @@ class Wave:
             else:
                 raise NotImplementedError(txt)
             return
-        if op in ("s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8"):
-            n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8}[op]
+        if op in ("s_load_dword", "s_load_dwordx2", "s_load_dwordx4", "s_load_dwordx8", "s_load_dwordx16"):
+            n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8, "s_load_dwordx16": 16}[op]
             base = self.rds64(a[1]) + self.rds(a[2])
             data = mem.read(base, 4 * n).view(np.uint32).copy()
             dst = a[0]
@@ -438,15 +438,16 @@ class Wave:
             self.lgkm.append(land)
             return
         # ---------------- global memory
-        if op == "global_load_dwordx4":
+        if op in ("global_load_dwordx4", "global_load_dword"):
+            nd = 4 if op.endswith("x4") else 1
             dst, voff, sbase = a
             base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
             off = self.rd(voff).astype(np.int64)
-            data = np.stack([mem.read(base + o, 16).view(np.uint32) for o in off], axis=1).copy()
+            data = np.stack([mem.read(base + o, 4 * nd).view(np.uint32) for o in off], axis=1).copy()
             self.poison(dst)
 
-            def land(dst=dst, data=data):
-                self.file(dst.kind)[dst.idx:dst.idx + 4] = data
+            def land(dst=dst, data=data, nd=nd):
+                self.file(dst.kind)[dst.idx:dst.idx + nd] = data
             self.vm.append(land)
             return
         if op == "global_load_lds_dwordx4":
@@ -460,6 +461,15 @@ class Wave:
                 for lane in range(64):
                     lds[m0 + 16 * lane:m0 + 16 * lane + 16] = data[lane]
             self.vm.append(land)
+            return
+        if op in ("global_store_dwordx4", "global_store_dword"):
+            voff, src, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            vals = self.tuple_read(src).copy()
+            for lane in range(64):
+                mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
+            self.vm.append(lambda: None)
             return
         if op == "global_store_dwordx2":
             voff, src, sbase = a
