@@ -91,7 +91,7 @@ SYMBOLS = {
     "f3r_rope2d_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
     "f3r_attn_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
-                                          _c_f32, ctypes.c_int, _c_vp]),
+                                          _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libf3r_hip.so")

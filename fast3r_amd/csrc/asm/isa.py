@@ -277,6 +277,8 @@ def operand_rw(it):
     r = []
     for a in args[1:]:
         r += regs_of(a)
+    if op == "v_fma_mix_f32":
+        pass  # the accumulator is an explicit source
     if op.startswith("v_dot2c") or op in ("v_fmac_f32",):
         r += w
     if op == "v_permlane32_swap_b32":

@@ -166,7 +166,7 @@ __device__ __forceinline__ double grid_focal(int k, int S, int n) {  // np.geoms
 
 __global__ __launch_bounds__(PT) void pnp_kernel(const float* __restrict__ pts, const float* __restrict__ conf, const float* __restrict__ focal_in,
                                                  float* __restrict__ focal_out, float* __restrict__ pose_out, int* __restrict__ inliers_out,
-                                                 int H, int W, float conf_thr, float ppx, float ppy, int n_focals) {
+                                                 int H, int W, float conf_thr, float ppx, float ppy, int n_focals, int n_hyp) {
   __shared__ double red[NW_][48];
   __shared__ double sums[48];
   __shared__ Pose hyp[N_HYP];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(PT) void pnp_kernel(const float* __restrict__ pts, 
     Pose P;
     P.ok = 0;
     P.f = 0;
-    if (n_mask >= SAMPLE) {
+    if (n_mask >= SAMPLE && tid < n_hyp) {  // n_hyp = the caller's RANSAC iteration count (niter_PnP), at most N_HYP
       double m[40];
       for (int k = 0; k < 40; ++k) m[k] = 0.0;
       for (int j = 0; j < SAMPLE; ++j) {
@@ -420,13 +420,15 @@ __global__ __launch_bounds__(PT) void pnp_kernel(const float* __restrict__ pts, 
 }  // namespace
 
 extern "C" int f3r_estimate_poses(const float* pts3d, const float* conf, const float* focal_in, float* focal_out, float* cam_to_world,
-                                  int* inliers, int n_views, int H, int W, float conf_thr, float ppx, float ppy, int n_focals,
+                                  int* inliers, int n_views, int H, int W, float conf_thr, float ppx, float ppy, int n_focals, int n_iter,
                                   f3r_stream_t stream) {
   F3R_REQUIRE(pts3d && conf && focal_out && cam_to_world && inliers, "f3r_estimate_poses: null pointer");
   F3R_REQUIRE(n_views >= 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "f3r_estimate_poses: bad sizes");
   F3R_REQUIRE(n_focals >= 1 && n_focals <= 4096, "f3r_estimate_poses: n_focals %d", n_focals);
+  F3R_REQUIRE(n_iter >= 1, "f3r_estimate_poses: n_iter %d (the RANSAC iteration count: at least 1)", n_iter);
+  const int n_hyp = n_iter < N_HYP ? n_iter : N_HYP;
   if (n_views == 0) return F3R_OK;
   hipLaunchKernelGGL(pnp_kernel, dim3(n_views), dim3(PT), 0, (hipStream_t)stream, pts3d, conf, focal_in, focal_out, cam_to_world, inliers, H, W,
-                     conf_thr, ppx, ppy, n_focals);
+                     conf_thr, ppx, ppy, n_focals, n_hyp);
   return f3r_check_launch("f3r_estimate_poses");
 }

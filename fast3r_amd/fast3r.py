@@ -165,6 +165,8 @@ class Fast3RDecoder(_Params):
             # the reference takes any dim // num_heads (blocks.py:113-143); 64 runs the tuned attention kernels, the other multiples of
             # 16 up to 128 (model_scaling_huge.yaml: 1280 / 16 = 80) the generic one (f3r_attn_generic.hip)
             raise ValueError(f"fast3r_amd attention kernels are built for head_dim = a multiple of 16 up to 128 (got {embed_dim} / {num_heads})")
+        if embed_dim % 64 != 0:
+            raise ValueError(f"fast3r_amd: the fused QKV epilogue splits q / k / v on 64-column groups: embed_dim must be a multiple of 64 (got {embed_dim})")
         self.embed_dim, self.num_heads, self.depth = embed_dim, num_heads, depth
         self.random_image_idx_embedding = random_image_idx_embedding
         self.attn_bias_for_inference_enabled = attn_bias_for_inference_enabled

@@ -20,10 +20,14 @@ N_GUESSED_FOCALS = 100  # init_im_poses.py:300
 CONF_THR = 1.0          # multiview_dust3r_module.py:1045
 
 
-def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals=N_GUESSED_FOCALS):
+N_ITER_MAX = 32         # hypotheses the kernel scores per view (f3r_pnp.hip N_HYP); niter_PnP above it is clamped
+
+
+def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals=N_GUESSED_FOCALS, n_iter=N_ITER_MAX):
     """pts3d (n, H, W, 3), conf (n, H, W), focal None / float / (n,) tensor ->
     (cam_to_world (n, 4, 4) fp32, focal (n,) fp32 with NaN where the solve failed, inliers (n,) int32) on pts3d's device (CPU inputs
-    are uploaded to the current ROCm device for the kernels)."""
+    are uploaded to the current ROCm device for the kernels).  n_iter: the RANSAC iteration count of the reference's call
+    (cv2.solvePnPRansac(iterationsCount=niter_PnP)) = the number of sampled hypotheses scored per view, at most 32."""
     if pts3d.dim() != 4 or pts3d.shape[-1] != 3 or tuple(conf.shape) != tuple(pts3d.shape[:3]):
         raise ValueError(f"pts3d must be (n, H, W, 3) and conf (n, H, W); got {tuple(pts3d.shape)} and {tuple(conf.shape)}")
     n, H, W, _ = pts3d.shape
@@ -41,33 +45,39 @@ def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals
     inl = torch.empty((n,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         check(_lib.lib().f3r_estimate_poses(ptr(pts3d), ptr(conf), ptr(fin), ptr(fout), ptr(poses), ptr(inl), n, H, W, float(conf_thr),
-                                            float(ppx), float(ppy), int(n_focals), stream_ptr()), "f3r_estimate_poses")
+                                            float(ppx), float(ppy), int(n_focals), max(1, int(n_iter)), stream_ptr()), "f3r_estimate_poses")
     return poses.to(home), fout.to(home), inl.to(home)
 
 
 def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimation_method="individual"):
-    """multiview_dust3r_module.py:807-869.  preds: list over views of dicts with 'pts3d_in_other_view' (B,H,W,3) and 'conf' (B,H,W) on the
-    GPU.  `niter_PnP` (OpenCV's RANSAC iteration count) has no counterpart in the deterministic solver and is accepted for compatibility."""
+    """multiview_dust3r_module.py:807-869.  preds: list over views of dicts with 'pts3d_in_other_view' (B,H,W,3) and 'conf' (B,H,W).
+    `niter_PnP` is the RANSAC iteration count (init_im_poses.py:335): min(niter_PnP, 32) sampled hypotheses per view here.  Views of
+    different resolutions are solved per resolution group (the reference loops over views, :1038-1078)."""
     if focal_length_estimation_method not in ("individual", "first_view_from_global_head", "first_view_from_local_head"):
         raise ValueError(f"Unknown focal_length_estimation_method: {focal_length_estimation_method}")  # :843
     n_views = len(preds)
     B = len(preds[0]["pts3d_in_other_view"])  # :811
-    H, W = preds[0]["pts3d_in_other_view"].shape[1:3]
-    if any(tuple(p["pts3d_in_other_view"].shape[1:3]) != (H, W) for p in preds):
-        raise NotImplementedError("estimate_camera_poses: views of different resolutions -- call estimate_poses per resolution group")
-    pts = torch.stack([p["pts3d_in_other_view"] for p in preds], dim=1).reshape(B * n_views, H, W, 3)  # sample-major
-    conf = torch.stack([p["conf"] for p in preds], dim=1).reshape(B * n_views, H, W)
-    focal = None
+    f_b = None
     if focal_length_estimation_method != "individual":  # :826-848: one focal per sample, from view 0, 10th percentile
         if focal_length_estimation_method == "first_view_from_global_head":
             p0, c0 = preds[0]["pts3d_in_other_view"], preds[0]["conf"]
         else:
             p0, c0 = preds[0]["pts3d_local_aligned_to_global"], preds[0]["conf_local"]
         f_b = estimate_focals(p0, c0.reshape(p0.shape[:3]), min_conf_thr_percentile=10)  # (B,)
-        focal = f_b.repeat_interleave(n_views)
-    poses, fout, _ = estimate_poses(pts, conf, focal)
-    poses = poses.view(B, n_views, 4, 4).cpu().numpy().astype(np.float64)
-    fout = fout.view(B, n_views).cpu().tolist()
-    poses_all = [[poses[b, v] for v in range(n_views)] for b in range(B)]
-    focals_all = [[(None if math.isnan(f) else f) for f in fout[b]] for b in range(B)]
+    groups = {}  # (H, W) -> view indices, in view order
+    for v, p in enumerate(preds):
+        groups.setdefault(tuple(p["pts3d_in_other_view"].shape[1:3]), []).append(v)
+    poses_all = [[None] * n_views for _ in range(B)]
+    focals_all = [[None] * n_views for _ in range(B)]
+    for (H, W), vs in groups.items():
+        pts = torch.stack([preds[v]["pts3d_in_other_view"] for v in vs], dim=1).reshape(B * len(vs), H, W, 3)  # sample-major
+        conf = torch.stack([preds[v]["conf"] for v in vs], dim=1).reshape(B * len(vs), H, W)
+        focal = None if f_b is None else f_b.repeat_interleave(len(vs))
+        poses, fout, _ = estimate_poses(pts, conf, focal, n_iter=niter_PnP)
+        poses = poses.view(B, len(vs), 4, 4).cpu().numpy().astype(np.float64)
+        fout = fout.view(B, len(vs)).cpu().tolist()
+        for b in range(B):
+            for j, v in enumerate(vs):
+                poses_all[b][v] = poses[b, j]
+                focals_all[b][v] = None if math.isnan(fout[b][j]) else fout[b][j]
     return poses_all, focals_all

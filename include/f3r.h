@@ -317,14 +317,15 @@ int f3r_estimate_focal(const float* pts3d, const float* conf, float* focal, floa
  * estimate_cam_pose_one_sample :1038-1078) = fast_pnp (fast3r/dust3r/cloud_opt/init_im_poses.py:300-350): mask = conf > conf_thr
  * (:1045 uses 1.0); fewer than 4 masked points -> failure (:302-303); focal_in[v] > 0 is used as is, otherwise the focal is searched
  * on np.geomspace(max(H,W)/2, 3 max(H,W), n_focals) (:312-316; the reference uses 100) by inlier count at 5 px (:335,:342);
- * result = inverse of the world-to-camera [R|T] (:349-350).  The reference solves with cv2.solvePnPRansac(SQPNP); this library uses
- * sampled closed-form DLT hypotheses + inlier DLT + gated Gauss-Newton (f3r_pnp.hip) -- same contract, different solver.
+ * result = inverse of the world-to-camera [R|T] (:349-350).  The reference solves with cv2.solvePnPRansac(iterationsCount = niter_PnP,
+ * SQPNP); this library uses min(n_iter, 32) sampled closed-form DLT hypotheses + inlier DLT + gated Gauss-Newton (f3r_pnp.hip) -- same
+ * contract (n_iter = the RANSAC iteration count), different solver.
  *   pts3d [n_views][H][W][3] fp32 (world frame), conf [n_views][H][W] fp32, focal_in [n_views] fp32 or NULL,
  *   focal_out [n_views] fp32 (NaN on failure), cam_to_world [n_views][4][4] fp32 row-major (identity on failure, :1062-1064),
  *   inliers [n_views] int32 (0 on failure).
  */
 int f3r_estimate_poses(const float* pts3d, const float* conf, const float* focal_in, float* focal_out, float* cam_to_world, int* inliers,
-                       int n_views, int H, int W, float conf_thr, float ppx, float ppy, int n_focals, f3r_stream_t stream);
+                       int n_views, int H, int W, float conf_thr, float ppx, float ppy, int n_focals, int n_iter, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_resample_u8 / f3r_imgnorm_u8: the device side of the input pipeline `load_images` (fast3r/dust3r/utils/image.py:76-159).

@@ -42,8 +42,9 @@ CASES = {
     # enc_embed_dim features and its DPT heads at patch size 14 (Interpolate 14/8) run for real; the inside of the backbone stays unpinned
     "tiny_dino_portrait_b2": (dict(patch_embed_cls="dino", enc_depth=2, landscape_only=True), [(56, 70)] * 3, 2, 8, 3, "default"),
     # a fusion decoder whose heads are not 64 wide (configs/experiment/model_scaling/model_scaling_huge.yaml:13-15: 1280 / 16 = 80):
-    # encoder 128 / 2 heads, decoder 160 / 2 heads
-    "tiny_hd80_3x64": (dict(enc_depth=1, dec_embed_dim=160), [(64, 64), (48, 64), (64, 64)], 1, 9, 21, "default"),
+    # encoder 128 / 2 heads, decoder 320 / 4 heads (the QKV epilogue splits q / k / v on 64-column groups: widths are multiples of 64,
+    # as 1280 is)
+    "tiny_hd80_3x64": (dict(enc_depth=1, dec_embed_dim=320, dec_num_heads=4), [(64, 64), (48, 64), (64, 64)], 1, 9, 21, "default"),
 }
 TRUE_SHAPES = {"tiny_portrait_b2": [[[48, 64], [48, 64]], [[64, 48], [64, 48]], [[64, 48], [48, 64]]],
                "tiny_dino_portrait_b2": [[[56, 70], [56, 70]], [[70, 56], [70, 56]], [[70, 56], [56, 70]]]}

@@ -132,8 +132,8 @@ def test_asm_kernel_grouped_query_and_batch(built_lib, dt):
 @pytest.mark.parametrize("dt", DTYPES)
 def test_asm_kernel_segments_and_carried_state(built_lib, dt):
     """The view-sharded layout: K/V as segments (one launch over all of them == one launch over their concatenation), and the
-    two-launch form (local segment with state_out, remote segments with state_in) == one launch, bit for bit -- for the hand-scheduled
-    kernel alone and with the general HIP kernel taking either launch (one state layout for both)."""
+    two-launch form (local segment with state_out, remote segments with state_in) == one launch -- for the hand-scheduled kernel alone
+    and with the general HIP kernel taking either launch (one state layout for both)."""
     H, Tq = 2, 1024
     lens = [192, 64, 320, 128]
     qs = rnd((Tq, H * 64), dt, 70, 0.125 * LOG2E * 1.5)
@@ -158,7 +158,9 @@ def test_asm_kernel_segments_and_carried_state(built_lib, dt):
         assert torch.isnan(two.float()).all()  # the first launch must not write the output
         ops.attention(q, two, H, 1.0, segs[1:], q_prescaled=True, state=state, state_in=True, kernel_sel=sel_remote)
         if (sel_local, sel_remote) == (2, 2):
-            assert torch.equal(one, two)  # same tiles in the same order, state kept in fp32
+            # same tiles in the same order, state kept in fp32; the resumed launch takes its first half tile through the re-base path,
+            # whose row sum is an fp32 dot instead of the packed partial sums of the steady state: equal up to that rounding
+            assert_close(two.float(), one.float().cpu(), lp_tol(dt) / 2, "two launches vs one")
         assert_close(two.float(), ref, 2 * lp_tol(dt), f"state carry, kernels {sel_local} -> {sel_remote}")
 
 

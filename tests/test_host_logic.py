@@ -91,7 +91,7 @@ def test_the_scaling_ablation_decoder_builds():
     assert dec.embed_dim // dec.num_heads == 80 and abs(dec.attention_scale(True) - 80 ** -0.5) < 1e-12
     sd = dec.state_dict()
     assert sd["dec_blocks.0.attn.qkv.weight"].shape == (3 * 1280, 1280) and sd["decoder_embed.weight"].shape == (1280, 1024)
-    enc, decargs, head = tiny_args(dec_embed_dim=160)
+    enc, decargs, head = tiny_args(dec_embed_dim=320, dec_num_heads=4)
     m = Fast3R(enc, decargs, head)
     assert m.decoder.embed_dim // m.decoder.num_heads == 80
     with pytest.raises(ValueError, match="multiple of 16"):

@@ -1,9 +1,9 @@
 """Camera poses (second half; reference multiview_dust3r_module.py:807-869,1038-1078 + fast_pnp,
-dust3r/cloud_opt/init_im_poses.py:300-350).  The reference's solver is cv2.solvePnPRansac (OpenCV is not in this image and its RANSAC is
-randomised), so the SOLVER is unpinned: it is anchored on ground truth -- known cameras are recovered from synthetic pointmaps with noise
-and gross outliers -- and on HIP == the independent torch restatement of the same algorithm.  The reference's WRAPPER around the solver is
-pinned: it runs for real with a stand-in for OpenCV (oracle/cv2_stub.py, oracle/make_golden_pose.py -> tests/golden/pose_cases.pt), last
-section of this file."""
+dust3r/cloud_opt/init_im_poses.py:300-350).  The reference's solver is cv2.solvePnPRansac(flags=SOLVEPNP_SQPNP); OpenCV is not in this
+image, so the named dependency's PUBLISHED algorithm is restated in fp64 (oracle/sqpnp.py: SQPnP, Terzakis & Lourakis 2020, inside
+OpenCV's RANSAC structure, oracle/cv2_stub.py) and checked for what defines its result (global minimum of its cost: first section).  The
+reference's WRAPPER around the solver runs for real on top of it (oracle/make_golden_pose.py -> tests/golden/pose_cases.pt) and the HIP
+path -- a different algorithm with the same contract -- is compared with what it returns at tolerances stated per scene (last section)."""
 
 import numpy as np
 import pytest
@@ -38,6 +38,70 @@ def make_scene(seed, H, W, f, noise, n_out, anchor=False):
     T[:3, 3] = -R.t() @ t
     conf = 1.0 + torch.rand(H, W, generator=g) * 4 + 1e-3
     return Xw.float(), conf, T
+
+
+# ------------------------------------------------------------------------------------------------ CPU: SQPnP restatement
+def _rand_problem(rng, n, noise):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    t = rng.standard_normal(3) + np.array([0.0, 0.0, 6.0])
+    M = rng.standard_normal((n, 3)) * 1.5
+    Xc = M @ q.T + t
+    return M, Xc[:, :2] / Xc[:, 2:3] + noise * rng.standard_normal((n, 2)), q, t
+
+
+def test_sqpnp_recovers_exact_cameras():
+    """noise-free correspondences (4 .. 40 points): the restated solver returns the camera to fp64 accuracy"""
+    from oracle import sqpnp
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        M, xy, R, t = _rand_problem(rng, int(rng.integers(4, 40)), 0.0)
+        Rs, ts, err = sqpnp.solve(M, xy)
+        assert np.abs(Rs - R).max() < 1e-9 and np.abs(ts - t).max() < 1e-9 and err < 1e-10
+
+
+def test_sqpnp_result_is_the_minimum_of_its_cost():
+    """what pins an SQPnP implementation is its optimum: no rotation near the result, and none of 20 000 random rotations, has a lower
+    r^T Omega r (t eliminated in closed form), and the result is a proper rotation that keeps the points in front of the camera"""
+    from oracle import sqpnp
+    rng = np.random.default_rng(1)
+    for _ in range(6):
+        M, xy, R, t = _rand_problem(rng, 30, 0.01)
+        Rs, ts, err = sqpnp.solve(M, xy)
+        assert abs(np.linalg.det(Rs) - 1) < 1e-12 and np.abs(Rs @ Rs.T - np.eye(3)).max() < 1e-12
+        assert ((M @ Rs.T + ts)[:, 2] > 0).all()
+        Om, P, _ = sqpnp.omega_matrix(M, xy)
+        for scale in (1e-3, 2e-2, 0.3):
+            for _k in range(500):
+                w = rng.standard_normal(3) * scale
+                th = np.linalg.norm(w)
+                K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+                r = ((np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K) @ Rs).reshape(9)
+                assert r @ Om @ r >= err - 1e-12
+        q = rng.standard_normal((20000, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        a, b, c, d = q.T
+        Rr = np.stack([1 - 2 * (c * c + d * d), 2 * (b * c - a * d), 2 * (b * d + a * c), 2 * (b * c + a * d), 1 - 2 * (b * b + d * d), 2 * (c * d - a * b),
+                       2 * (b * d - a * c), 2 * (c * d + a * b), 1 - 2 * (b * b + c * c)], 1)
+        assert (np.einsum("ni,ij,nj->n", Rr, Om, Rr) >= err - 1e-12).all()
+
+
+def test_cv2_stand_in_follows_opencvs_ransac_contract():
+    """solvePnPRansac of the stand-in: (ok, rvec (3,1), tvec (3,1), inliers (n,1) int32), gross outliers excluded from the inlier list, the
+    final pose = SQPnP on the consensus set; fewer than 4 correspondences raise cv2.error"""
+    from oracle import cv2_stub as cv2
+    rng = np.random.default_rng(2)
+    M, xy, R, t = _rand_problem(rng, 200, 0.0)
+    K = np.array([[80.0, 0, 32], [0, 80.0, 24], [0, 0, 1]])
+    uv = xy * 80.0 + np.array([32.0, 24.0])
+    uv[:40] += rng.standard_normal((40, 2)) * 60  # gross outliers
+    ok, rvec, tvec, inl = cv2.solvePnPRansac(M, uv, K, None, iterationsCount=100, reprojectionError=5, flags=cv2.SOLVEPNP_SQPNP)
+    assert ok and rvec.shape == (3, 1) and tvec.shape == (3, 1) and inl.dtype == np.int32 and inl.shape[1] == 1
+    assert (inl[:, 0] >= 40).sum() == 160 and (inl[:, 0] < 40).sum() <= 4
+    assert np.abs(cv2.Rodrigues(rvec)[0] - R).max() < 1e-6 and np.abs(tvec[:, 0] - t).max() < 1e-6
+    with pytest.raises(cv2.error):
+        cv2.solvePnPRansac(M[:3], uv[:3], K, None)
 
 
 SCENES = [(0, 48, 64, 70.0, 0.002, 300), (1, 64, 64, 55.0, 0.0, 0), (2, 40, 56, 120.0, 0.01, 500), (3, 96, 128, 100.0, 0.003, 2000)]
@@ -114,7 +178,8 @@ def test_hip_estimate_camera_poses_api(built_lib):
 # ------------------------------------------------------------------------------------------------ the reference's wrapper, run for real
 # tests/golden/pose_cases.pt (oracle/make_golden_pose.py): the reference's MultiViewDUSt3RLitModule.estimate_camera_poses ->
 # estimate_cam_pose_one_sample -> fast_pnp and its estimate_focal, imported from the reference checkout and run unmodified, with OpenCV (not
-# installable here) replaced by oracle/cv2_stub.py -- an independent numpy RANSAC-PnP, NOT the product's algorithm.
+# installable here) replaced by oracle/cv2_stub.py -- OpenCV's RANSAC structure around an fp64 restatement of SQPnP (oracle/sqpnp.py), NOT
+# the product's algorithm.
 def _pose_cases():
     import os
     return torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_cases.pt"), weights_only=False)["cases"]
@@ -137,8 +202,10 @@ def test_reference_wrapper_fixture_recovers_the_known_cameras():
 @pytest.mark.gpu
 def test_hip_matches_the_reference_wrapper(built_lib):
     """README flow (focal_length_estimation_method='first_view_from_global_head'): same return structure, the shared focal equal to the
-    reference's (its estimate_focal is the pinned Weiszfeld row), every pose within 1e-2 of what the reference's wrapper returned -- two
-    different solvers on noisy pointmaps with gross outliers, both a few 1e-3 from the ground truth.
+    reference's (its estimate_focal is the pinned Weiszfeld row), every pose within the scene's stated tolerance of what the reference's
+    wrapper returned around the restated SQPnP -- two different solvers (SQPnP minimises its object-space cost on the RANSAC consensus
+    set, the product the reprojection error) on noisy pointmaps with gross outliers, both a few 1e-3 from the ground truth; the
+    tolerance is the pointmap noise x a few (noise-free scene: 1e-4).
     'individual' mode is NOT compared value by value: there the reference keeps the FIRST of its 100 focal candidates that reaches the
     maximum inlier count (`score > best[0]`, init_im_poses.py:341-342), i.e. the low end of a plateau that is wide at 5 px on small images
     (fixture: 55 for a true 70), while the product breaks ties by reprojection cost; only structure and failure
@@ -155,7 +222,8 @@ def test_hip_matches_the_reference_wrapper(built_lib):
                 assert isinstance(poses[b][v], np.ndarray) and poses[b][v].shape == (4, 4)
                 assert abs(focals[b][v] - ref["focals"][b][v]) <= 1e-4 * ref["focals"][b][v], (focals[b][v], ref["focals"][b][v])
                 d = float(np.abs(poses[b][v] - ref["poses"][b][v]).max())
-                assert d < 1e-2, (c["scene"], b, v, d)
+                tol = 1e-4 if c["scene"][6] == 0.0 else max(4.0 * c["scene"][6], 1e-2)  # scene[6] = pointmap noise (world units)
+                assert d < tol, (c["scene"], b, v, d, tol)
         poses_i, focals_i = MultiViewDUSt3RLitModule.estimate_camera_poses(preds, niter_PnP=100, focal_length_estimation_method="individual")
         ref_i = c["reference"]["individual"]
         assert len(poses_i) == len(ref_i["poses"]) and all(len(a) == len(b_) for a, b_ in zip(poses_i, ref_i["poses"]))

@@ -42,9 +42,11 @@ def _build(dt, precision):
 def test_vit_large_n100_matches_the_fp32_equivalent_path(built_lib):
     """BASELINE configs[2] at its real size: 100 views of 512^2 end to end."""
     views = views_to(make_views(100, 512, 512), DEV)
+    m = _build(torch.float16, "exact")
     with torch.no_grad():
-        torch.manual_seed(4321)
-        ref = [{k: v.cpu() for k, v in o.items()} for o in _build(torch.float16, "exact")(views)]
+        torch.manual_seed(4321)  # (after the model is built: parameter initialisation draws from the same generator as the image ids)
+        ref = [{k: v.cpu() for k, v in o.items()} for o in m(views)]
+    del m
     torch.cuda.empty_cache()
     report = {}
     for dt, precision in ((torch.float16, "high"), (torch.bfloat16, "fast")):
@@ -83,6 +85,7 @@ def test_rank_of_eight_at_n320_reproduces_the_unsharded_forward(built_lib):
 
     def kv_source(layer, r, k_out, vt_out):
         k, vt = taps[layer]
+        vt = vt.view(vt.shape[-2], vt.shape[-1])  # [1][D][ld] of the one decoder sample
         k_out.copy_(k[r * per:(r + 1) * per])
         vt_out.copy_(vt[:, r * per:(r + 1) * per])
     m.emulate_rank(rank, world, kv_source)

@@ -84,7 +84,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         steps = 0
         for karg in launches:
             a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
-            w = Workgroup(prog, mem, a_arg, wg, 4, attn_gen.LDS_BYTES, dtype)
+            w = Workgroup(prog, mem, a_arg, wg, 4, g.lds_bytes, dtype)
             steps += w.run()
         og = mem.get(a_o, np.uint16, (batch, tq, D))
         x, head, b = wg

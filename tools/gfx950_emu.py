@@ -382,6 +382,14 @@ class Wave:
                 out |= f32_to_half(r, "f16").astype(np.uint32) << (16 * h)
             self.wr(a[0], out)
             return
+        if op == "v_fma_mix_f32":
+            txt = it.mods.get("text", "")
+            assert "op_sel_hi:[1,0,0]" in txt
+            x = self.rd(a[1])
+            xh = half_to_f32((x >> 16) & 0xFFFF if "op_sel:[1,0,0]" in txt else x & 0xFFFF, "f16")
+            r = xh.astype(np.float64) * f32(self.rd(a[2])).astype(np.float64) + f32(self.rd(a[3])).astype(np.float64)
+            self.wr(a[0], u32(r.astype(np.float32)))
+            return
         if op == "v_cvt_f16_f32":
             self.wr(a[0], f32_to_half(f32(self.rd(a[1])), "f16").astype(np.uint32))
             return
