@@ -32,7 +32,7 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False):
+             gen_kwargs=None, split_state=False, layout=1):
     rng = np.random.default_rng(seed)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
     tq, tk = 512 * q_blocks, 64 * sum(seg_tiles)
@@ -75,7 +75,11 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
     else:
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
-    g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))
+    if layout == 2:
+        import attn_gen2
+        g = attn_gen2.AttnGen2(dtype, rowsum=rowsum, **(gen_kwargs or {}))
+    else:
+        g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
@@ -111,6 +115,7 @@ if __name__ == "__main__":
     ap.add_argument("--rowsum", default="pkadd")
     ap.add_argument("--cvt", default="rne")
     ap.add_argument("--split-state", action="store_true")
+    ap.add_argument("--layout", type=int, default=1)
     a = ap.parse_args()
     tiles = [int(x) for x in a.tiles.split(",")]
-    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state)
+    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout)

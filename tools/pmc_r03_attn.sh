@@ -36,7 +36,7 @@ for V in ("fp16", "bf16"):
          "effective_clock_ghz": cyc / dur, "valu_insts_per_mfma": avg["SQ_INSTS_VALU"] / avg["SQ_INSTS_MFMA"],
          "lds_insts_per_mfma": avg.get("SQ_INSTS_LDS", 0) / avg["SQ_INSTS_MFMA"], "counters_per_dispatch": avg}
     T = $VIEWS * 1024
-    big = 4.0 * T * T * 64 * 16 / (2 * 32 * 32 * 16) / 64   # wave-level 32x32x16 MFMA instructions of the algorithm
+    big = 4.0 * T * T * 64 * 16 / (2 * 32 * 32 * 16)   # wave-level 32x32x16 MFMA instructions of the algorithm
     e["mfma_util_useful_cycles"] = big * 32 / (cyc * 1024)
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in avg and avg.get("SQ_WAVE_CYCLES"):
