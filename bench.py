@@ -65,6 +65,9 @@ def parse(argv=None):
                     help="EMULATION, not a multi-GPU measurement: this one GPU runs exactly the work of rank R of --of W view-sharded ranks (its "
                          "views, local + remote attention launches over pre-filled K/V segments, parked softmax state) with no collective")
     ap.add_argument("--of", type=int, default=8, help="world size of the emulated job (--emulate-rank)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "p2p"],
+                    help="K/V exchange of the view-sharded path: one all-gather per tensor and layer + ONE remote attention launch, or pairwise "
+                         "rounds + one remote launch per arrived shard")
     return ap.parse_args(argv)
 
 
@@ -198,9 +201,9 @@ def main():
         model.load_state_dict(sd, strict=True)
         model = model.to(dev)
         if distributed:
-            model.shard_views()
+            model.shard_views(exchange=args.exchange)
         if emu:
-            model.emulate_rank(args.emulate_rank, args.of)
+            model.emulate_rank(args.emulate_rank, args.of, exchange=args.exchange)
         if args.fusion_only:
             step_fn = make_fusion_only_step(model, V, lp, dev)
         else:
@@ -224,7 +227,7 @@ def main():
             # two launches per fusion layer: queries = the rank's tokens, keys = its own shard (local) / the other ranks' shards (remote)
             t_loc = (hi - lo) * 1024
             pair = [(a.elapsed_time(b), fl) for a, b, fl, tq, tk in timer if tq == t_loc and tk >= t_loc]
-            n_layers = len(pair) // 2
+            n_layers = int(dec["depth"]) * steps
             big = sum(fl for _, fl in pair) / n_layers
             avg_ms = sum(ms for ms, _ in pair) / n_layers
             fus = pair
@@ -241,8 +244,8 @@ def main():
             res_emu = {"comm_bytes_per_layer_into_this_gpu": kvx.comm_bytes_per_layer, "fusion_layers": int(dec["depth"]),
                        "xgmi_link_budget": "7 links x ~153 GB/s per GPU (MI355X_MICROARCH / SURVEY section 5)",
                        "allgather_ms_per_layer_all_links": kvx.comm_bytes_per_layer / (7 * 153e9) * 1e3,
-                       "local_launch_ms": sum(ms for ms, fl in fus[0::2]) / max(1, len(fus) // 2),
-                       "remote_launch_ms": sum(ms for ms, fl in fus[1::2]) / max(1, len(fus) // 2)}
+                       "exchange": args.exchange, "attention_launches_per_layer": len(fus) // max(1, n_layers),
+                       "attention_ms_per_layer": avg_ms}
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
                "roofline": {"bound": "mfma", "kernel": "attn_kernel (fusion self-attention, one launch per fusion layer per rank)",
@@ -270,7 +273,7 @@ def main():
                "ms_per_step": main_res["ms_per_step"], "per_rank_step_ms": main_res["ms_per_step"],
                "projected_views_per_s_if_comm_is_hidden": V / (main_res["ms_per_step"] * 1e-3),
                "dtype": main_res["dtype"], "precision": main_res["precision"], "data": "synthetic",
-               "config": {"workload": workload, "views": V, "views_of_this_rank": hi - lo, "rank": args.emulate_rank, "world": args.of},
+               "config": {"workload": workload, "views": V, "views_of_this_rank": hi - lo, "rank": args.emulate_rank, "world": args.of, "exchange": args.exchange},
                "roofline": main_res["roofline"], "exchange": main_res["emulation"]}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         return

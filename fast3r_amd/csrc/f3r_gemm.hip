@@ -315,7 +315,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;
   F3R_REQUIRE(a.split != F3R_SPLIT_X3 || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 split needs A_lo (16-byte aligned) and no a_relu");
-  F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 4) || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
+  F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 5) || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
   F3R_REQUIRE(a.N % 4 == 0, "f3r_gemm: N %d must be a multiple of 4", a.N);
   F3R_REQUIRE(al16(a.A) && al16(a.W), "f3r_gemm: A/W must be 16-byte aligned");
   F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_gemm: bad dtype %d", a.dtype);

@@ -46,6 +46,16 @@ template <int NH> struct TileCfg {
   static constexpr int LDS_BYTES = NBUF * BUF * 2;   // 131072 / 147456
 };
 
+inline int f3r_num_cus() {  // CUs of the current device, rounded down to a multiple of 8 (XCDs)
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+    n = cu / 8 * 8;
+  }
+  return n;
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -65,8 +75,14 @@ struct IC {
 //   128 s_memtime stamps of wave 0 (entry, main loop start, main loop end, epilogue issued, stores retired) -> (uint64*)p.rope_cos [wg][5]
 // (1, 2, 4, 8 compute garbage by construction: timing only)
 template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0>
-__device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, int64_t m0, int n0) {
+__device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, const int64_t m0_tile, const int n0_tile, const bool first = true,
+                                             const bool has_next = false, const int64_t m0_next = 0, const int n0_next = 0) {
+  // PERSISTENT form (gemm256_kernel walks several output tiles per workgroup): `first` = this workgroup's first tile (its opening loads
+  // are issued here); otherwise the previous call issued them, between its main loop and its epilogue, so that their latency hides
+  // behind the epilogue's stores.  `has_next`: do the same for (m0_next, n0_next) before this tile's epilogue.
   constexpr int BUF = TileCfg<NH>::BUF;
+  int64_t m0 = m0_tile;  // the tile the staging lambdas address (switched to the next tile before the epilogue)
+  int n0 = n0_tile;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,7 +119,11 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   uint32_t a_msk[2][2];               // CONV: bit tap = the tap of this lane's pixel lies inside the image
   const char* const Ab = (const char*)p.A;
   const char* const Alo = (const char*)p.A_lo;
-  const char* const Wb = (const char*)p.W + (int64_t)n0 * p.Kpad * 2;
+  const char* Wb = nullptr;
+  auto setup_tile = [&](int64_t tm0, int tn0) {
+  m0 = tm0;
+  n0 = tn0;
+  Wb = (const char*)p.W + (int64_t)n0 * p.Kpad * 2;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -135,10 +155,13 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
         a_msk[h][i] = msk;
       }
     }
+  };
+  setup_tile(m0_tile, n0_tile);
 
   // cursors: which K-tile the NEXT A / W half-tile pair is loaded for (wave-uniform; clamped at the last tile, see the loop tail)
   int a_seg = 0, a_kk = 0, a_tap = 0, a_ct = 0, a_t = 0;
   int w_seg = 0, w_kk = 0, w_t = 0;
+  bool dry = false;  // advance the cursors without issuing (the loads were issued by the previous tile of this workgroup)
   auto a_advance = [&]() {
     if (a_t + 1 < nk) {
       ++a_t; ++a_kk; ++a_ct;
@@ -154,6 +177,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   };
   bool in_loop = false;  // LAB only
   auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
+    if (dry) return;
     if ((LAB & 1) && in_loop) return;
     const char* plane = (a_seg == 2) ? Alo : Ab;
     uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
@@ -181,6 +205,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     }
   };
   auto issue_w = [&](int h, int buf) {
+    if (dry) return;
     if ((LAB & 1) && in_loop) return;
     const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
     uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
@@ -303,31 +328,41 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   // The bias and the additive epilogue terms (fp32 / lowp residuals, image-id rows) are loaded FIRST, straight into the accumulators:
   // they land under the latency of the first tiles (f3r_gemm_epi.h); the compiler's own wait covers their first use.
   typedef GemmFragLayout<2 * NH, 8, 2, 4, PAIRED> Frag;  // 2 fragments from each W half, 4 fragments from each A half
-  const int64_t m_base = m0 + wm * 64;
-  const int n_base = n0 + wn * 32;
+  const int64_t m_base = m0_tile + wm * 64;
+  const int n_base = n0_tile + wn * 32;
+  auto opening_loads = [&]() {
+    a_seg = a_kk = a_tap = a_ct = a_t = 0;
+    w_seg = w_kk = w_t = 0;
+    if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
+      issue_a(0, 0);
+      issue_w(0, 0);
+      issue_a(1, 0);
+      a_advance();
+      issue_w(1, 0);
+      w_advance();
+      issue_a(0, 1);
+      issue_w(0, 1);
+    } else {                  // tiles 0 and 1
+      issue_a(0, 0);
+      issue_w(0, 0);
+      w_advance();
+      issue_a(1, 0);
+      a_advance();
+      issue_a(0, 1);
+      issue_w(0, 1);
+      w_advance();
+      issue_a(1, 1);
+      a_advance();
+    }
+  };
+  dry = !first;
+  opening_loads();
+  dry = false;
   gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
-  if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
-    issue_a(0, 0);
-    issue_w(0, 0);
-    issue_a(1, 0);
-    a_advance();
-    issue_w(1, 0);
-    w_advance();
-    issue_a(0, 1);
-    issue_w(0, 1);
-    F3R_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed; the four younger half tiles stay in flight
-  } else {                  // tiles 0 and 1
-    issue_a(0, 0);
-    issue_w(0, 0);
-    w_advance();
-    issue_a(1, 0);
-    a_advance();
-    issue_a(0, 1);
-    issue_w(0, 1);
-    w_advance();
-    issue_a(1, 1);
-    a_advance();
-    F3R_VMCNT(8);  // A half 0 and W of tile 0 have landed
+  if (first) {
+    F3R_VMCNT(8);  // A half 0 and W half 0 (NH == 1: W) of tile 0 have landed; the four younger half tiles stay in flight
+  } else {
+    F3R_VMCNT(0);  // the previous tile's epilogue stores are in the queue behind the opening loads: counted waits resume once it is empty
   }
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
@@ -355,6 +390,10 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   F3R_VMCNT(0);
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
   if (LAB & 128) stamp[2] = __builtin_amdgcn_s_memtime();
+  if (has_next) {  // every wave is past its last LDS read and the queue is empty: stage the next tile's opening half tiles under the epilogue
+    setup_tile(m0_next, n0_next);
+    opening_loads();
+  }
 
   // ------------------------------------------------------------------ epilogue
   if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
@@ -381,29 +420,43 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   const int n_tiles_n = (p.N + BN - 1) / BN;
   const int64_t n_tiles_m = (p.M + BM - 1) / BM;
   const int64_t n_wg = n_tiles_m * n_tiles_n;
-  int64_t wg = blockIdx.x;
-  {
-    const int64_t q = n_wg / 8, r = n_wg % 8;
-    const int64_t xcd = wg % 8, idx = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GM = 8;
-  const int64_t per_group = (int64_t)GM * n_tiles_n;
-  const int64_t grp = wg / per_group;
-  const int64_t first_m = grp * GM;
-  const int gm = (int)((n_tiles_m - first_m) < GM ? (n_tiles_m - first_m) : GM);
-  const int64_t rem_ = wg - grp * per_group;
-  const int tn = (int)(rem_ / gm);
-  const int64_t tm = first_m + rem_ % gm;
-  const int64_t m0 = tm * BM;
-  const int n0 = tn * BN;
-  if constexpr (EPI == F3R_EPI_QKV) {
-    if (n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3))) {  // the V part: swapped operand roles, V^T epilogue
-      gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0);
-      return;
+  auto tile_of = [&](int64_t wg, int64_t& m0, int& n0) {
+    {
+      const int64_t q = n_wg / 8, r = n_wg % 8;
+      const int64_t xcd = wg % 8, idx = wg / 8;
+      wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    constexpr int GM = 8;
+    const int64_t per_group = (int64_t)GM * n_tiles_n;
+    const int64_t grp = wg / per_group;
+    const int64_t first_m = grp * GM;
+    const int gm = (int)((n_tiles_m - first_m) < GM ? (n_tiles_m - first_m) : GM);
+    const int64_t rem_ = wg - grp * per_group;
+    const int tn = (int)(rem_ / gm);
+    const int64_t tm = first_m + rem_ % gm;
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  // PERSISTENT: gridDim.x = min(tiles, CUs) workgroups (a multiple of 8 whenever there is more than one round, so a workgroup's tiles
+  // stay on its XCD's contiguous run); workgroup b computes tiles b, b + gridDim.x, ...; between two of them the next tile's opening
+  // LDS-DMA loads are issued before the finished tile's epilogue stores (gemm256_body).
+  int64_t m0, m0n = 0;
+  int n0, n0n = 0;
+  bool first = true;
+  for (int64_t v = blockIdx.x; v < n_wg; v += gridDim.x) {
+    tile_of(v, m0, n0);
+    const bool has_next = v + gridDim.x < n_wg;
+    if (has_next) tile_of(v + gridDim.x, m0n, n0n);
+    bool done = false;
+    if constexpr (EPI == F3R_EPI_QKV) {
+      if (n0 >= (p.qkv_dq ? p.qkv_dq + (p.N - p.qkv_dq) / 2 : 2 * (p.N / 3))) {  // the V part: swapped operand roles, V^T epilogue
+        gemm256_body<T, A_MODE, EPI, true, STAGGER, F3R_ADD_NONE, NH>(p, smem, m0, n0, first, has_next, m0n, n0n);
+        done = true;
+      }
+    }
+    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0, first, has_next, m0n, n0n);
+    first = false;
   }
-  gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0);
 }
 
 template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
@@ -416,7 +469,10 @@ int launch256(const f3r_gemm_args& a, hipStream_t stream) {
     attr_set = true;
   }
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS_BYTES, stream, a);
+  // one resident workgroup per CU (128 / 144 KiB of LDS): a persistent grid of at most that many workgroups; kernel_sel 5 asks for the
+  // one-tile-per-workgroup form (measurements)
+  const int64_t grid = (a.kernel_sel == 5 || tiles <= f3r_num_cus()) ? tiles : f3r_num_cus();
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS_BYTES, stream, a);
   return f3r_check_launch("f3r_gemm(256)");
 }
 
@@ -438,7 +494,7 @@ inline float score_128(const f3r_gemm_args& a) { return tile_score(((a.M + 127) 
 inline int tile_halves(const f3r_gemm_args& a) {
   if (a.epi == F3R_EPI_QKV) return 2;
   if (a.N % 256 != 0 || a.kernel_sel == 4) return 1;
-  if (a.kernel_sel == 2 || a.kernel_sel == 3) return 2;
+  if (a.kernel_sel == 2 || a.kernel_sel == 3 || a.kernel_sel == 5) return 2;
   return score_256(a, 1) > score_256(a, 2) ? 1 : 2;
 }
 

@@ -35,9 +35,14 @@ def _round_up(x, m):
 class KVExchange:
     """Per-forward send/receive buffers for the per-layer K / V^T all-gather (allocated once, reused by all layers)."""
 
-    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device, n_heads=None, q_dim=None):
+    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device, n_heads=None, q_dim=None, mode="allgather"):
         """D = width of the K rows / number of V^T planes x 64 (= the model width, or n_kv_heads * 64 with grouped-query attention);
-        q_dim = width of the parked O state (the model width)."""
+        q_dim = width of the parked O state (the model width).  mode: "allgather" (one collective per tensor, the remote shards are
+        attended in ONE launch when all have landed) or "p2p" (W-1 rounds of pairwise send / receive in ring-distance order, one remote
+        launch per ARRIVED shard: the attention over shard d hides the transfer of shard d+1 whatever algorithm RCCL would have picked
+        for the collective; costs one round trip of the parked softmax state per extra launch)."""
+        assert mode in ("allgather", "p2p")
+        self.mode = mode
         self.group, self.world, self.rank = group, world, rank
         self.t_loc, self.t_all, self.D = t_loc, list(t_all), D
         q_dim = D if q_dim is None else q_dim
@@ -90,10 +95,69 @@ class KVExchange:
     def local_segment(self):
         return (self.k_loc, self.vt_loc.view(self.D, self.ldvt), self.t_loc, 0, 0)
 
+    def _peer_order(self):
+        """peers in the order their shards arrive in p2p mode: round d receives from rank - d (and sends to rank + d)"""
+        return [((self.rank - d) % self.world, (self.rank + d) % self.world) for d in range(1, self.world)]
+
+    def _start_p2p(self):
+        """post every round now (asynchronously where the backend allows it); each round is its own group, so that it completes -- and
+        its shard can be attended -- while later rounds are still moving"""
+        self._rounds = []
+        nccl = self.k_all.is_cuda and dist.get_backend(self.group) == "nccl"
+        glob = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+        for src, dst in self._peer_order():
+            ops, stage = [], []
+            if self.t_loc > 0:
+                ks, vs = (self.k_loc, self.vt_loc.view(self.D, self.ldvt)) if nccl or not self.k_loc.is_cuda else (self.k_loc.cpu(), self.vt_loc.view(self.D, self.ldvt).cpu())
+                ops += [dist.P2POp(dist.isend, ks, glob(dst), self.group), dist.P2POp(dist.isend, vs, glob(dst), self.group)]
+            if self.t_all[src] > 0:
+                if nccl or not self.k_all.is_cuda:
+                    kr, vr = self.k_all[src], self.vt_all[src]
+                else:  # gloo with device buffers (the 2-process single-GPU test): receive on the host, copy at wait()
+                    kr, vr = torch.empty(self.k_all[src].shape, dtype=self.k_all.dtype), torch.empty(self.vt_all[src].shape, dtype=self.vt_all.dtype)
+                    stage = [(self.k_all[src], kr), (self.vt_all[src], vr)]
+                ops += [dist.P2POp(dist.irecv, kr, glob(src), self.group), dist.P2POp(dist.irecv, vr, glob(src), self.group)]
+            works = dist.batch_isend_irecv(ops) if ops else []
+            self._rounds.append([src, works, stage])
+
+    def remote_groups(self):
+        """[(wait, segments)] in arrival order: `wait()` makes the current stream wait for that group's transfer.  allgather mode: one
+        group with every remote shard; p2p mode: one group per peer."""
+        if self.mode == "allgather":
+            return [(lambda: None, self.finish())] if self.has_remote else []
+        out = []
+        for rnd in self._rounds:
+            src, works, stage = rnd[:3]
+
+            def wait(rnd=rnd):
+                if len(rnd) > 3:   # already waited for (a second wait on a completed gloo request blocks)
+                    return
+                for w in rnd[1]:
+                    w.wait()
+                for dst_t, src_t in rnd[2]:
+                    dst_t.copy_(src_t)
+                rnd.append(True)
+            if self.t_all[src] > 0:
+                out.append((wait, [(self.k_all[src], self.vt_all[src], self.t_all[src], 0, 0)]))
+            else:
+                out.append((wait, []))
+        return out
+
+    def remote_position_of(self, seg):
+        """global token index of the first row of a remote segment (causal attention): seg = an entry of remote_groups()"""
+        pos = self.positions()
+        for r in range(self.world):
+            if seg[0].data_ptr() == self.k_all[r].data_ptr():
+                return pos[r]
+        raise ValueError("not a segment of this exchange")
+
     def start(self):
         """Launch both all-gathers.  With RCCL they are asynchronous (their own stream, ordered after the QKV GEMM that
         produced k_loc / vt_loc on the current stream); other backends gather synchronously through the host."""
         self._works = []
+        if self.mode == "p2p":
+            self._start_p2p()
+            return
         if self.k_all.is_cuda and dist.get_backend(self.group) == "nccl":
             self._works.append(dist.all_gather_into_tensor(self.k_all.view(self.world * self.t_max, self.D), self.k_loc,
                                                            group=self.group, async_op=True))
@@ -105,6 +169,9 @@ class KVExchange:
 
     def finish(self):
         """Make the current stream wait for the gathers; returns the segments of the OTHER ranks, in rank order."""
+        if self.mode == "p2p":  # (a rank without tokens, or a caller that wants everything at once)
+            for wait, _ in self.remote_groups():
+                wait()
         for w in getattr(self, "_works", []):
             w.wait()
         self._works = []
@@ -113,13 +180,14 @@ class KVExchange:
 
 
 class ViewSharding:
-    def __init__(self, process_group=None, gather_outputs=False):
+    def __init__(self, process_group=None, gather_outputs=False, exchange="allgather"):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("ViewSharding needs an initialised torch.distributed process group (RCCL: backend 'nccl')")
         self.group = process_group
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
         self.gather_outputs = gather_outputs
+        self.exchange = exchange  # "allgather" | "p2p" (KVExchange.mode)
         self._kvx_cache = {}  # geometry -> KVExchange (make_kv_exchange)
         if self.world > 8:
             raise ValueError("the attention kernel takes at most 8 K/V segments (one MI355X node)")
@@ -149,11 +217,11 @@ class ViewSharding:
         of the same geometry instead of being rebuilt: the local K / V^T rows are fully rewritten by every layer's QKV epilogue and
         the padding stays zero."""
         t_all = self.all_token_counts(t_loc, dev)
-        key = (t_loc, tuple(t_all), D, dtype, str(dev), n_heads, q_dim)
+        key = (t_loc, tuple(t_all), D, dtype, str(dev), n_heads, q_dim, self.exchange)
         cache = self._kvx_cache
         if key not in cache:
             cache.clear()  # one geometry at a time: a different scene releases the previous buffers
-            cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim)
+            cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim, mode=self.exchange)
         return cache[key]
 
     def gather_results(self, results, n_total, dev):
@@ -178,8 +246,8 @@ class EmulatedKVExchange:
     with random operands -- the attention launches, their segment walk and the parked softmax state are exactly a rank's, only the
     bytes that would have crossed xGMI are not real).  `comm_bytes_per_layer` = what the all-gather would move into this GPU."""
 
-    def __init__(self, world, rank, t_all, D, dtype, device, n_heads, q_dim, kv_source=None):
-        self.world, self.rank = world, rank
+    def __init__(self, world, rank, t_all, D, dtype, device, n_heads, q_dim, kv_source=None, mode="allgather"):
+        self.world, self.rank, self.mode = world, rank, mode
         self.t_all, self.t_loc, self.D = list(t_all), t_all[rank], D
         self.t_max = max(self.t_all)
         self.ldvt = _round_up(self.t_max, 64)
@@ -205,6 +273,14 @@ class EmulatedKVExchange:
     positions = KVExchange.positions
     remote_positions = KVExchange.remote_positions
     local_segment = KVExchange.local_segment
+    remote_position_of = KVExchange.remote_position_of
+    _peer_order = KVExchange._peer_order
+
+    def remote_groups(self):
+        if self.mode == "allgather":
+            return [(lambda: None, self.finish())] if self.has_remote else []
+        return [(lambda: None, [(self.k_all[src], self.vt_all[src], self.t_all[src], 0, 0)] if self.t_all[src] > 0 else [])
+                for src, _ in self._peer_order()]
 
     def start(self):
         if self.kv_source is not None:
@@ -221,7 +297,8 @@ class EmulatedSharding:
     """Drop-in for ViewSharding on ONE GPU: the model runs the views, launches and buffers of rank `rank` of a `world`-rank job with no
     collective (Fast3R.emulate_rank).  Views must have one size (the token count of the other ranks is derived from it)."""
 
-    def __init__(self, world, rank, kv_source=None):
+    def __init__(self, world, rank, kv_source=None, exchange="allgather"):
+        self.exchange = exchange
         if not (1 <= world <= 8 and 0 <= rank < world):
             raise ValueError("emulated sharding: 1 <= world <= 8 (K/V segments of one MI355X node), 0 <= rank < world")
         self.world, self.rank, self.kv_source = world, rank, kv_source
@@ -247,9 +324,9 @@ class EmulatedSharding:
             t_all.append((b - a) * per_view)
         q_dim = D if q_dim is None else q_dim
         n_heads = q_dim // 64 if n_heads is None else n_heads
-        key = (tuple(t_all), D, dtype, str(dev), n_heads, q_dim)
+        key = (tuple(t_all), D, dtype, str(dev), n_heads, q_dim, self.exchange)
         if self._kvx is None or self._kvx[0] != key:
-            self._kvx = (key, EmulatedKVExchange(self.world, self.rank, t_all, D, dtype, dev, n_heads, q_dim, self.kv_source))
+            self._kvx = (key, EmulatedKVExchange(self.world, self.rank, t_all, D, dtype, dev, n_heads, q_dim, self.kv_source, mode=self.exchange))
         kvx = self._kvx[1]
         kvx.layer = 0
         self.last_exchange = kvx

@@ -643,19 +643,20 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def set_max_parallel_views_for_head(self, n):
         self.max_parallel_views_for_head = n
 
-    def shard_views(self, process_group=None):
+    def shard_views(self, process_group=None, exchange="allgather"):
         """Enable the view-sharded multi-GPU path: this rank encodes / decodes / regresses only its contiguous range of
-        views and exchanges K / V^T per fusion layer with an RCCL all-gather (fast3r_amd/dist.py)."""
-        self.sharding = ViewSharding(process_group)
+        views and exchanges K / V^T per fusion layer over RCCL (fast3r_amd/dist.py).  exchange: "allgather" (one collective per tensor
+        and layer, one remote attention launch) or "p2p" (pairwise rounds, one remote launch per arrived shard)."""
+        self.sharding = ViewSharding(process_group, exchange=exchange)
         return self
 
-    def emulate_rank(self, rank, world, kv_source=None):
+    def emulate_rank(self, rank, world, kv_source=None, exchange="allgather"):
         """ONE GPU runs exactly rank `rank`'s share of a `world`-rank view-sharded forward -- its views through the encoder, the fusion
         layers as local launch (parking the softmax state) + remote launch over world - 1 K / V^T segments, its heads -- with no
         collective (dist.EmulatedSharding).  kv_source fills the remote segments per layer (parity test); without it they hold random
         operands (bench.py --emulate-rank: a per-rank step time, clearly not a multi-GPU measurement).  `emulate_rank(None, 0)` undoes it."""
         from .dist import EmulatedSharding
-        self.sharding = None if rank is None else EmulatedSharding(world, rank, kv_source)
+        self.sharding = None if rank is None else EmulatedSharding(world, rank, kv_source, exchange=exchange)
         return self
 
     # ---------------------------------------------------------------- packed weights
@@ -787,9 +788,16 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 pos = kv_exchange.positions()  # global token index of the first row of every rank's shard (causal attention only)
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True,
                               state=kv_exchange.state, state_out=True, q_pos0=pos[kv_exchange.rank], seg_pos0=[pos[kv_exchange.rank]], **gqa)
-                remote = kv_exchange.finish()
-                ops.attention(q, o, n_heads, scale, remote, tq=seq_len, q_prescaled=True, state=kv_exchange.state, state_in=True,
-                              q_pos0=pos[kv_exchange.rank], seg_pos0=kv_exchange.remote_positions(), **gqa)
+                # the remote shards, as ONE group once the all-gathers have landed or ("p2p" exchange) shard by shard in arrival order
+                groups = [(w, sg) for w, sg in kv_exchange.remote_groups()]
+                live = [i for i, (_, sg) in enumerate(groups) if sg]
+                for i, (wait, segs) in enumerate(groups):
+                    wait()
+                    if not segs:
+                        continue
+                    ops.attention(q, o, n_heads, scale, segs, tq=seq_len, q_prescaled=True, state=kv_exchange.state, state_in=True,
+                                  state_out=(i != live[-1]), q_pos0=pos[kv_exchange.rank],
+                                  seg_pos0=[kv_exchange.remote_position_of(sg) for sg in segs], **gqa)
             else:
                 kv_exchange.finish()
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True, **gqa)

@@ -138,7 +138,8 @@ typedef struct f3r_gemm_args {
      the row stride, K the real depth of ONE plane) and, for X3, A_lo is the low plane of A (same layout / strides as A). */
   int32_t split;     /* f3r_split */
   int32_t kernel_sel; /* 0 = pick the kernel by shape; 1 = 128x128-tile kernel; 2 / 3 = 256x256-tile kernel with / without staggered wave rows;
-                         4 = its 256x128 tile form (measurement only: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
+                         4 = its 256x128 tile form; 5 = 256x256 with one tile per workgroup instead of the persistent grid (2 - 5 are for
+                         measurement: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
   const void* A_lo;
   /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
      their high planes.  Same leading dimensions as the high planes. */

@@ -85,3 +85,56 @@ def test_view_sharding_gloo_world2():
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _worker_p2p(rank, world, port, ret):
+    """the per-peer form: pairwise rounds in ring-distance order, the remote shards handed out one by one in ARRIVAL order"""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fast3r_amd.dist import ViewSharding
+        sh = ViewSharding(exchange="p2p")
+        n_views, P, D = 7, 24, 128  # uneven: 3 + 2 + 2 views
+        lo, hi = sh.my_range(n_views)
+        t_loc = (hi - lo) * P
+        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"))
+        assert kvx.mode == "p2p" and kvx.t_all == [3 * P, 2 * P, 2 * P]
+        g = torch.Generator().manual_seed(0)
+        T = n_views * P
+        qf, kf, vf = (torch.randn(T, D, generator=g) for _ in range(3))
+        r0 = lo * P
+        for layer in range(2):
+            kvx.k_loc[:t_loc] = kf[r0:r0 + t_loc] + layer
+            kvx.vt_loc[0, :, :t_loc] = (vf[r0:r0 + t_loc] + layer).t()
+            kvx.start()
+            groups = kvx.remote_groups()
+            assert len(groups) == world - 1
+            arrived, order = [kvx.local_segment()], []
+            for wait, segs in groups:
+                wait()
+                assert len(segs) == 1
+                order.append(kvx.remote_position_of(segs[0]))
+                arrived += segs
+            pos = kvx.positions()
+            assert order == [pos[(rank - d) % world] for d in range(1, world)]  # round d brings the shard of rank - d
+            out = _segment_attention(qf[r0:r0 + t_loc], arrived, 0.16)  # softmax is order independent
+            full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
+            assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
+            assert [s[2] for s in kvx.finish()] == [t for r, t in enumerate(kvx.t_all) if r != rank]  # everything at once still works
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_sharding_per_peer_exchange_gloo_world3():
+    mp.set_start_method("spawn", force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [mp.Process(target=_worker_p2p, args=(r, 3, port, ret)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: "ok", 1: "ok", 2: "ok"}

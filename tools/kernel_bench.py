@@ -146,7 +146,7 @@ def bench_attn_encoder(dt, views, variants, H=16):
     lab_lib().f3r_attn_set_variant(-1)
 
 
-SEL_NAME = {1: "128-tile", 2: "256-tile staggered", 3: "256-tile lock-step", 4: "256x128-tile"}
+SEL_NAME = {1: "128-tile", 2: "256-tile persistent", 3: "256-tile lock-step", 4: "256x128-tile", 5: "256-tile one tile per workgroup"}
 
 
 def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
@@ -442,6 +442,19 @@ if __name__ == "__main__":
         for nv in [int(v) for v in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):
                 bench_attn_product({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv)
+        sys.exit(0)
+    if args.what == "gemmpersist":  # persistent grid (kernel_sel 2) next to one tile per workgroup (5) on the model's shapes
+        for dt in (torch.bfloat16, torch.float16):
+            for M in (40960, 102400, 327680):
+                bench_gemm(dt, M, 1024, 1024, f"proj+res M={M}", res=True, sels=(2, 5))
+                bench_gemm(dt, M, 4096, 1024, f"fc1+gelu M={M}", act="gelu", out="lp", sels=(2, 5))
+                bench_gemm(dt, M, 1024, 4096, f"fc2+res M={M}", res=True, sels=(2, 5))
+                bench_qkv(dt, M, 1024, M, sels=(2, 5))
+            bench_conv(dt, 8, 128, 128, 256, 256, "refinenet1 rcu", sels=(2, 5))
+            bench_conv(dt, 8, 256, 256, 256, 128, "head0", sels=(4,))
+            bench_conv(dt, 8, 512, 512, 128, 128, "head2", sels=(4,))
+        bench_gemm(torch.float16, 102400, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2", sels=(2, 5))
+        bench_conv(torch.float16, 8, 128, 128, 256, 256, "refinenet1 rcu x3", split="x3", sels=(2, 5))
         sys.exit(0)
     if args.what == "attnsel":
         for nv in [int(x) for x in args.views.split(",")]:
