@@ -226,15 +226,17 @@ def main():
         if emu:
             # two launches per fusion layer: queries = the rank's tokens, keys = its own shard (local) / the other ranks' shards (remote)
             t_loc = (hi - lo) * 1024
-            pair = [(a.elapsed_time(b), fl) for a, b, fl, tq, tk in timer if tq == t_loc and tk >= t_loc]
+            pair = [(a.elapsed_time(b), fl) for a, b, fl, tq, tk, _ in timer if tq == t_loc and tk >= t_loc]
+            kname = sorted(set(nm for _, _, _, tq, tk, nm in timer if tq == t_loc and tk >= t_loc))
             n_layers = int(dec["depth"]) * steps
             big = sum(fl for _, fl in pair) / n_layers
             avg_ms = sum(ms for ms, _ in pair) / n_layers
             fus = pair
         else:
-            fus = [(a.elapsed_time(b), fl) for a, b, fl, _, _ in timer]
-            big = max(fl for _, fl in fus)
-            fus = [(ms, fl) for ms, fl in fus if fl == big]
+            fus = [(a.elapsed_time(b), fl, nm) for a, b, fl, _, _, nm in timer]
+            big = max(fl for _, fl, _ in fus)
+            kname = sorted(set(nm for _, fl, nm in fus if fl == big))
+            fus = [(ms, fl) for ms, fl, _ in fus if fl == big]
             avg_ms = sum(ms for ms, _ in fus) / len(fus)
         achieved = big / (avg_ms * 1e-3) / 1e12
         prec = "" if precision == "fast" else "; split-precision GEMM operands (weights hi+lo in the transformer, both operands hi+lo in the heads)"
@@ -248,7 +250,7 @@ def main():
                        "attention_ms_per_layer": avg_ms}
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
-               "roofline": {"bound": "mfma", "kernel": "attn_kernel (fusion self-attention, one launch per fusion layer per rank)",
+               "roofline": {"bound": "mfma", "kernel": " / ".join(kname) + " -- the fusion self-attention launches of f3r_attn_fwd",
                             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                             "flops_per_launch": big, "avg_launch_ms": avg_ms, "launches_timed": len(fus),
                             "e2e": None if e2e is None else {"flops_per_forward": flops_forward(V), "achieved_per_gpu": e2e, "frac": e2e / MFMA_PEAK_TFLOPS}}}

@@ -73,6 +73,7 @@ SYMBOLS = {
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
+    "f3r_attn_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(AttnArgs)]),
     "f3r_block_workspace_bytes": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)]),
     "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -382,6 +382,18 @@ int attn_launch(const f3r_attn_args& a, hipStream_t s) {
 
 }  // namespace
 
+// Which kernel f3r_attn_fwd takes for these arguments (reporting only: bench.py names the roofline kernel with it).
+extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
+  if (!args) return "";
+  const f3r_attn_args& a = *args;
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  if (hd != 64) return "attn_generic_kernel (f3r_attn_generic.hip)";
+  const char* why = "";
+  if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why))
+    return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen2.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen2.py)";
+  return a.causal ? "attn_kernel<causal> (f3r_attn.hip)" : (a.batch > 1 ? "attn_kernel<batched> (f3r_attn.hip)" : "attn_kernel (f3r_attn.hip)");
+}
+
 extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(args != nullptr, "f3r_attn_fwd: null args");
   const f3r_attn_args& a = *args;

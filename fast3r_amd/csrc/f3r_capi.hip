@@ -37,7 +37,7 @@ extern "C" size_t f3r_sizeof(int what) {
 }
 
 extern "C" size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]) {
-  if (tokens < 0 || D <= 0 || kv_dim <= 0 || hidden <= 0 || n_seq <= 0 || seq_len < 0 || n_seq * seq_len != tokens || !offsets) return 0;
+  if (tokens < 0 || D <= 0 || kv_dim < 0 || hidden <= 0 || n_seq <= 0 || seq_len < 0 || n_seq * seq_len != tokens || !offsets) return 0;
   const size_t al = 256;
   const size_t ldvt = (size_t)((seq_len + 63) / 64 * 64);
   const size_t sizes[5] = {(size_t)tokens * D * 2, (size_t)tokens * D * 2, (size_t)tokens * kv_dim * 2, (size_t)n_seq * kv_dim * ldvt * 2,

@@ -244,7 +244,7 @@ class LlamaDecoder(_Params):
     """fast3r.py:810-968 (the `llama_dec` experiment, configs/experiment/llama_dec/llama_dec.yaml): pre-norm RMSNorm blocks with SwiGLU,
     bias-free projections, rotary embedding of q / k by the IMAGE id of a token's view (all patches of a view share one angle set), a
     learnable embedding added to the tokens of view 0 before every layer, final RMSNorm.  Bidirectional (the released config) or
-    causal attention; grouped-query attention with an even n_kv_heads; head_dim must be 64."""
+    causal attention; grouped-query attention with any n_kv_heads that divides n_heads (incl. 1: multi-query); head_dim must be 64."""
 
     def __init__(self, random_image_idx_embedding, enc_embed_dim, embed_dim=4096, n_layers=32, n_heads=32, n_kv_heads=None,
                  multiple_of=256, ffn_dim_multiplier=None, norm_eps=1e-5, rope_theta=10000, max_seq_len=1000, is_causal=False,
@@ -255,9 +255,6 @@ class LlamaDecoder(_Params):
         n_kv_heads = n_heads if n_kv_heads is None else int(n_kv_heads)
         if n_heads % n_kv_heads != 0:
             raise ValueError(f"n_heads ({n_heads}) must be a multiple of n_kv_heads ({n_kv_heads})")  # repeat_kv, llama.py:125-134,196
-        if n_kv_heads % 2 != 0 and n_kv_heads != n_heads:
-            # the k and the v part of the fused QKV projection must each be whole 128-column blocks (f3r_gemm QKV epilogue)
-            raise NotImplementedError("fast3r_amd LlamaDecoder: grouped-query attention needs an even n_kv_heads")
         self.embed_dim, self.num_heads, self.depth = embed_dim, n_heads, n_layers
         self.n_kv_heads, self.is_causal = n_kv_heads, bool(is_causal)
         self.random_image_idx_embedding = random_image_idx_embedding
@@ -745,10 +742,11 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return self._rope_cache[key]
 
     # ---------------------------------------------------------------- transformer block on the HIP kernels
-    def _block_ws(self, pb, T, D, n_seq, seq_len, dev):
-        """Workspace of the blocks of one encoder pass / decoder sample: ONE allocation shared by all of its layers."""
+    def _block_ws(self, pb, T, D, n_seq, seq_len, dev, external_kv=False):
+        """Workspace of the blocks of one encoder pass / decoder sample: ONE allocation shared by all of its layers.  external_kv: K / V^T
+        are written into the buffers of a KVExchange (view-sharded path), the workspace keeps no room for them."""
         hidden = pb.fc1_w.shape[0]  # rows of the (possibly stacked [w1; w3]) up-projection
-        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=pb.kv_dim)
+        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=0 if external_kv else pb.kv_dim)
 
     def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None, kv_tap=None):
         """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
@@ -960,7 +958,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         D = dec.embed_dim
         T_loc, n_loc = sum(Ps), len(Ps)
         x = torch.empty((T_loc, D), dtype=torch.float32, device=dev)
-        ws = self._block_ws(pk["dec"][0], T_loc, D, 1, T_loc, dev)  # one allocation for the intermediates of all L blocks
+        ws = self._block_ws(pk["dec"][0], T_loc, D, 1, T_loc, dev, external_kv=kvx is not None)  # one allocation for all L blocks
         planes = (lambda t: (t.clone(), None)) if f32_hooks else self._planes
         want_f32_norm = f32_hooks or self._hp
         if llama and self.precision == "exact":

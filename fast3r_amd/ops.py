@@ -186,7 +186,7 @@ class BlockWorkspace:
             return self.buf[offs[i]:offs[i] + 2 * n].view(lp).view(shape)
         self.h, self.q, self.k = view(0, (tokens, D)), view(1, (tokens, D)), view(2, (tokens, kv_dim))
         self.vt, self.hid = view(3, (n_seq, kv_dim, ld)), view(4, (tokens, hidden))
-        if ld != seq_len:
+        if ld != seq_len and kv_dim:
             self.vt.zero_()  # the pad columns are read by the last key tile and never written by the QKV epilogue
         self.key = (tokens, D, hidden, n_seq, seq_len, lp, str(device))
 
@@ -367,7 +367,8 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     if ATTN_TIMER is not None:
         e1.record()
         t_k = sum(int(s[2]) for s in segments)
-        ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * head_dim * n_heads * batch, int(a.tq), int(t_k)))
+        ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * head_dim * n_heads * batch, int(a.tq), int(t_k),
+                           _lib.lib().f3r_attn_kernel_name(ctypes.byref(a)).decode()))
     return out
 
 

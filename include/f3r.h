@@ -168,7 +168,8 @@ int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
  * per encoder pass / decoder sample and every block of that pass reuses it (the intermediates of a block are dead when it ends).
  * offsets[0..4] (bytes, 256-byte aligned) = { LN output / attention output (lowp [tokens][D]),  q (lowp [tokens][D]),
  * k (lowp [tokens][kv_dim]),  V^T (lowp [n_seq][kv_dim][ldvt], ldvt = seq_len rounded up to 64: pad columns are never written, zero
- * them once; kv_dim = D, or n_kv_heads * 64 with grouped-query attention),
+ * them once; kv_dim = D, or n_kv_heads * 64 with grouped-query attention, or 0 when K / V^T live elsewhere -- the view-sharded path
+ * writes them into the exchange buffers -- and the two regions are empty),
  * MLP hidden (lowp [tokens][hidden]) }.  Returns 0 on bad arguments.
  */
 size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
@@ -240,6 +241,8 @@ typedef struct f3r_attn_args {
 #define F3R_ATTN_ASM_MIN_KEYS 2048
 
 int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream);
+/* which kernel f3r_attn_fwd takes for `args` (a static string; reporting only) */
+const char* f3r_attn_kernel_name(const f3r_attn_args* args);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_upsample2x: bilinear x2, align_corners=True, NHWC lowp -> NHWC lowp.

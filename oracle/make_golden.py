@@ -34,6 +34,8 @@ CASES = {
     # grouped-query (4 query heads on 2 K/V heads) + causal LlamaDecoder (components/llama.py:195-198,229-239): not the released config
     "tiny_llama_gqa_causal": (dict(decoder_type="llama", embed_dim=256, num_heads=4, llama_kv_heads=2, llama_causal=True, enc_depth=1,
                                    llama_layers=12), [(48, 64)] * 3, 1, 7, 17, "default"),
+    # multi-query attention: 4 query heads on ONE K/V head (repeat_kv accepts any divisor, components/llama.py:125-134)
+    "tiny_llama_mqa": (dict(decoder_type="llama", embed_dim=256, num_heads=4, llama_kv_heads=1, enc_depth=1, llama_layers=12), [(48, 64)] * 3, 1, 10, 23, "default"),
     # the training-config pair ManyAR_PatchEmbed + landscape_only=True (configs/model/fast3r.yaml:55,77): images are STORED landscape
     # (48 x 64) and `true_shape` says which samples are portrait pictures: view 0 all landscape, view 1 all portrait, view 2 mixed
     "tiny_portrait_b2": (dict(enc_depth=1, patch_embed_cls="ManyAR_PatchEmbed", landscape_only=True), [(48, 64)] * 3, 2, 6, 11, "default"),

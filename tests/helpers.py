@@ -8,7 +8,7 @@ from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = ["tiny_3x64", "tiny_mixed", "tiny_b2_seqids", "tiny_oddgrid", "tiny_hot_3x64", "tiny_llama_3x64", "tiny_llama_seqids_b2",
-                "tiny_portrait_b2", "tiny_llama_gqa_causal", "tiny_dino_portrait_b2", "tiny_hd80_3x64"]
+                "tiny_portrait_b2", "tiny_llama_gqa_causal", "tiny_dino_portrait_b2", "tiny_hd80_3x64", "tiny_llama_mqa"]
 
 
 def load_golden(name):
