@@ -14,7 +14,7 @@ done
 python - <<PY
 import csv, glob, json, collections
 out = "$out"
-res = {"_doc": "rocprofv3 --kernel-trace --pmc (tools/pmc_r03_attn.sh) over tools/kernel_bench.py --what attnsel --sels $SEL at T = %d (N = $VIEWS): the fusion-attention kernel f3r_attn_fwd takes for that shape (kernel_sel $SEL).  mfma_util_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); useful = without the bias steps (4 v_mfma_f32_32x32x8 per 32 v_mfma_f32_32x32x16, same 32 pipe cycles each); effective clock = GRBM_GUI_ACTIVE/8/duration.  Profiled runs clock a few per cent below plain ones." % ($VIEWS * 1024), "formats": {}}
+res = {"_doc": "rocprofv3 --kernel-trace --pmc (tools/pmc_r03_attn.sh) over tools/kernel_bench.py --what attnsel --sels $SEL at T = %d (N = $VIEWS): the fusion-attention kernel f3r_attn_fwd takes for that shape (kernel_sel $SEL).  mfma_util_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); mfma_util_useful_cycles = the algorithm's 32x32x16 MFMA instructions x 32 pipe cycles over the same denominator (layout 2 of the hand-scheduled kernel issues no other MFMA, so the two agree; layout 1 and the HIP kernel spend extra pipe cycles on bias steps); effective clock = GRBM_GUI_ACTIVE/8/duration.  Profiled runs clock a few per cent below plain ones." % ($VIEWS * 1024), "formats": {}}
 traffic = {}
 for V in ("fp16", "bf16"):
     def counters(tag):
