@@ -367,7 +367,7 @@ def load_traffic(V, world):
 
 def load_pmc(dtype_name="fp16"):
     """Matrix-pipe utilisation in cycles + effective clock of the same kernel from the newest committed rocprofv3 PMC pass
-    (profiles/r*_attn_mfma_util.json, tools/pmc_mfma_util.sh): `frac` above is this times clock / 2.4 GHz."""
+    (profiles/r*_attn_mfma_util.json, tools/pmc_r03_attn.sh): `frac` above is this times clock / 2.4 GHz."""
     try:
         import glob
         cands = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_attn_mfma_util.json")))
