@@ -63,6 +63,16 @@ class AttnArgs(ctypes.Structure):
     ]
 
 
+class AttnF32Args(ctypes.Structure):
+    """struct f3r_attn_f32_args (include/f3r.h)."""
+    _fields_ = [
+        ("q", _c_vp), ("k", _c_vp), ("v", _c_vp), ("ldq", _c_i64), ("ldkv", _c_i64),
+        ("o_hi", _c_vp), ("o_lo", _c_vp), ("o_f32", _c_vp), ("ldo", _c_i64),
+        ("n_seq", _c_i64), ("tq", _c_i64), ("tk", _c_i64), ("q_pos0", _c_i64), ("k_pos0", _c_i64),
+        ("n_heads", _c_i32), ("kv_group", _c_i32), ("causal", _c_i32), ("dtype", _c_i32), ("head_dim", _c_i32), ("scale", _c_f32),
+    ]
+
+
 # every symbol include/f3r.h declares: (name, restype, argtypes)
 SYMBOLS = {
     "f3r_version": (ctypes.c_int, []),
@@ -91,6 +101,9 @@ SYMBOLS = {
     "f3r_rows_add_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_rope2d_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
     "f3r_attn_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_rope_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
+    "f3r_silu_mul_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_attn_f32_ex": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
 }
@@ -120,7 +133,7 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the .so does not export what the header declares
             fn.restype = res
             fn.argtypes = args
-        if l.f3r_sizeof(0) != ctypes.sizeof(GemmArgs) or l.f3r_sizeof(1) != ctypes.sizeof(AttnArgs):
+        if l.f3r_sizeof(0) != ctypes.sizeof(GemmArgs) or l.f3r_sizeof(1) != ctypes.sizeof(AttnArgs) or l.f3r_sizeof(2) != ctypes.sizeof(AttnF32Args):
             raise F3RError("fast3r_amd/_lib.py struct layout does not match include/f3r.h "
                            f"(gemm {l.f3r_sizeof(0)} vs {ctypes.sizeof(GemmArgs)}, attn {l.f3r_sizeof(1)} vs {ctypes.sizeof(AttnArgs)})")
         if l.f3r_version() < ABI_VERSION:

@@ -32,6 +32,7 @@ extern "C" size_t f3r_sizeof(int what) {
   switch (what) {
     case 0: return sizeof(f3r_gemm_args);
     case 1: return sizeof(f3r_attn_args);
+    case 2: return sizeof(f3r_attn_f32_args);
     default: return 0;
   }
 }

@@ -32,6 +32,17 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def _all_gather_into(out, inp, group):
+    """all_gather_into_tensor; RCCL moves device buffers directly, any other backend (gloo: CPU tests, and the 2-process single-GPU test)
+    goes through host staging -- a transport detail."""
+    if out.is_cuda and dist.get_backend(group) != "nccl":
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class KVExchange:
     """Per-forward send/receive buffers for the per-layer K / V^T all-gather (allocated once, reused by all layers)."""
 
@@ -63,14 +74,22 @@ class KVExchange:
                           torch.empty((t_loc, n_heads, 4), dtype=torch.float32, device=device))
 
     def _all_gather(self, out2d, in2d):
-        """RCCL moves device buffers directly.  Any other backend (gloo: CPU tests, and the 2-process single-GPU
-        test) goes through host staging -- a transport detail, the segments handed to the kernel are the same."""
-        if out2d.is_cuda and dist.get_backend(self.group) != "nccl":
-            o, i = torch.empty(out2d.shape, dtype=out2d.dtype), in2d.cpu()
-            dist.all_gather_into_tensor(o, i, group=self.group)
-            out2d.copy_(o)
-        else:
-            dist.all_gather_into_tensor(out2d, in2d, group=self.group)
+        _all_gather_into(out2d, in2d, self.group)
+
+    def gather_rows_f32(self, k_rows, v_rows):
+        """precision "exact": all-gather the fp32 K and V rows [T_r][D] of every rank (blocking) -> (K, V) fp32 [sum T_r][D] in rank
+        order, i.e. in global token order.  Two collectives of padded [T_max][D] blocks; the validation mode trades the overlap of the
+        16-bit path for simplicity."""
+        outs = []
+        for rows in (k_rows, v_rows):
+            D = rows.shape[1]
+            send = torch.zeros((self.t_max, D), dtype=torch.float32, device=rows.device)
+            send[:self.t_loc].copy_(rows)
+            recv = torch.empty((self.world * self.t_max, D), dtype=torch.float32, device=rows.device)
+            self._all_gather(recv, send)
+            recv = recv.view(self.world, self.t_max, D)
+            outs.append(torch.cat([recv[r, :self.t_all[r]] for r in range(self.world)], dim=0).contiguous())
+        return outs[0], outs[1]
 
     def exchange(self):
         """All-gather this layer's K and V^T (blocking); returns the attention segments of ALL ranks in rank order:
@@ -211,12 +230,13 @@ class ViewSharding:
         dist.all_gather_into_tensor(out, mine, group=self.group)
         return [int(v) for v in out.cpu().tolist()]
 
-    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None):
-        """The exchange of one forward pass.  The (tiny) token-count all-gather runs every time -- it is what tells a rank that another
-        rank's shard changed -- but the buffers (2 x world x T_max x D operands + the parked softmax state) are kept between forwards
-        of the same geometry instead of being rebuilt: the local K / V^T rows are fully rewritten by every layer's QKV epilogue and
-        the padding stays zero."""
-        t_all = self.all_token_counts(t_loc, dev)
+    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None, t_all=None):
+        """The exchange of one forward pass.  t_all = the token count of every rank's shard: the model passes it (every rank holds the
+        same list of views, so it is known without communication); without it a tiny all-gather asks.  The buffers (2 x world x T_max
+        x D operands + the parked softmax state) are kept between forwards of the same geometry instead of being rebuilt: the local
+        K / V^T rows are fully rewritten by every layer's QKV epilogue and the padding stays zero."""
+        t_all = self.all_token_counts(t_loc, dev) if t_all is None else [int(t) for t in t_all]
+        assert len(t_all) == self.world and t_all[self.rank] == t_loc
         key = (t_loc, tuple(t_all), D, dtype, str(dev), n_heads, q_dim, self.exchange)
         cache = self._kvx_cache
         if key not in cache:
@@ -225,15 +245,38 @@ class ViewSharding:
         return cache[key]
 
     def gather_results(self, results, n_total, dev):
-        """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with
-        gather_outputs=True every rank receives all N dicts (N x 8.4 MB of fp32 at 512^2)."""
+        """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with gather_outputs=True every rank
+        receives all N dicts (N x 8.4 MB of fp32 at 512^2).  The tensors travel as ONE flat device buffer per rank through
+        all_gather_into_tensor (RCCL: device to device); only their names and shapes (a few hundred bytes) are exchanged as objects."""
         if not self.gather_outputs:
             return results
-        gathered = [None] * self.world
-        dist.all_gather_object(gathered, [{k: v.cpu() for k, v in r.items()} for r in results], group=self.group)
+        meta = [[(k, tuple(v.shape), v.dtype) for k, v in r.items()] for r in results]
+        metas = [None] * self.world
+        dist.all_gather_object(metas, meta, group=self.group)
+
+        def numel(shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return n
+        sizes = [sum(numel(shp) for view in m for _, shp, _ in view) for m in metas]
+        n_max = max(sizes + [1])
+        send = torch.zeros((n_max,), dtype=torch.float32, device=dev)
+        if results:
+            flat = torch.cat([v.reshape(-1).to(device=dev, dtype=torch.float32) for r in results for v in r.values()])
+            send[:flat.numel()].copy_(flat)
+        recv = torch.empty((self.world * n_max,), dtype=torch.float32, device=dev)
+        _all_gather_into(recv, send, self.group)
         out = []
-        for part in gathered:
-            out.extend([{k: v.to(dev) for k, v in r.items()} for r in part])
+        for r, m in enumerate(metas):
+            off = r * n_max
+            for view in m:
+                d = {}
+                for k, shp, dt in view:
+                    n = numel(shp)
+                    d[k] = recv[off:off + n].view(shp).to(dt).clone()
+                    off += n
+                out.append(d)
         assert len(out) == n_total
         return out
 
@@ -269,6 +312,9 @@ class EmulatedKVExchange:
                           torch.empty((self.t_loc, n_heads, 4), dtype=torch.float32, device=device))
         self.layer = 0
         self.comm_bytes_per_layer = sum(2 * t * D * self.k_all.element_size() for r, t in enumerate(self.t_all) if r != rank)
+
+    def gather_rows_f32(self, k_rows, v_rows):
+        raise NotImplementedError("precision='exact' is not available under the one-GPU rank emulation (there is no fp32 K / V of the other ranks)")
 
     positions = KVExchange.positions
     remote_positions = KVExchange.remote_positions
@@ -314,7 +360,7 @@ class EmulatedSharding:
     def broadcast_ids(self, ids, dev):
         return ids
 
-    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None):
+    def make_kv_exchange(self, t_loc, D, dtype, dev, n_heads=None, q_dim=None, t_all=None):
         lo, hi = split_range(self._n_total, self.world, self.rank)
         assert hi > lo and t_loc % (hi - lo) == 0, "emulated sharding needs views of one size"
         per_view = t_loc // (hi - lo)

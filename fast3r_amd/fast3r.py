@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import F3RError
-from .dist import ViewSharding
+from .dist import ViewSharding, split_range
 
 
 # ======================================================================================= parameter containers
@@ -810,22 +810,37 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return x
 
     def _block_exact(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange):
-        """precision "exact": the same block with every operand as hi + lo planes and fp32 attention.  LayerNorm -> fp32 -> planes; QKV
-        through the generic epilogue into an fp32 [T][3D] buffer (+ RoPE-2D in place); f3r_attn_f32 -> planes; proj / fc1 (+GELU, planes
-        out) / fc2 as X3 GEMMs with the fp32 residual epilogue."""
-        if kv_exchange is not None or pb.rms or pb.swiglu_hidden or pb.kv_group > 1 or pb.causal:
-            raise NotImplementedError("precision='exact' covers the CroCo / DINOv2 encoders and the Fast3R decoder on one GPU")
+        """precision "exact": the same block with every operand as hi + lo planes and fp32 attention.  LayerNorm / RMSNorm -> fp32 -> planes;
+        QKV through the generic epilogue into an fp32 [T][Dq + 2 Dkv] buffer (+ rotary embedding in place, 2-D or per-view); f3r_attn_f32_ex
+        (grouped-query heads, causal by absolute position) -> planes; proj / fc1 (+GELU | SwiGLU gate, planes out) / fc2 as X3 GEMMs with the
+        fp32 residual epilogue.  View-sharded: the fp32 K and V rows of all ranks are all-gathered (blocking: this is the validation mode)
+        and the rank's queries attend over them in one launch."""
         lp = self.compute_dtype
-        _, hf = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, want_lp=False, want_f32=True)
+        T = x.shape[0]
+        _, hf = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, want_lp=False, want_f32=True, rms=pb.rms)
         h, hl = self._pair(hf)
         qkv, _ = ops.gemm(h, pb.qkv_w, bias=pb.qkv_b, want_f32=True, split="x3", a_lo=hl)
-        if rope is not None:
-            ops.rope2d_f32(qkv, n_heads, seq_len, rope)
-        o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, head_dim=pb.head_dim)
+        n_kv = n_heads // pb.kv_group
+        if rope is not None and T:
+            ops.rope_f32(qkv, n_heads + n_kv, max(1, seq_len), rope, pb.rope_mode)
+        gqa = dict(head_dim=pb.head_dim, kv_group=pb.kv_group, causal=pb.causal)
+        if kv_exchange is None:
+            o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, **gqa)
+        else:
+            Dq, Dkv = n_heads * pb.head_dim, n_kv * pb.head_dim
+            k_all, v_all = kv_exchange.gather_rows_f32(qkv[:, Dq:Dq + Dkv], qkv[:, Dq + Dkv:])
+            if T:
+                o, ol = ops.attention_f32(qkv, n_heads, 1, seq_len, scale, lp, kv=(k_all, v_all), q_pos0=kv_exchange.positions()[kv_exchange.rank], **gqa)
+            else:
+                o = ol = torch.empty((0, Dq), dtype=lp, device=x.device)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split="x3", a_lo=ol)
-        _, hf = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, want_lp=False, want_f32=True, out_f32=hf)
+        _, hf = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, want_lp=False, want_f32=True, out_f32=hf, rms=pb.rms)
         h, hl = self._pair(hf)
-        _, hid, hid_lo = ops.gemm(h, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, want_lo=True, split="x3", a_lo=hl)
+        if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
+            ab, _ = ops.gemm(h, pb.fc1_w, want_f32=True, split="x3", a_lo=hl)
+            hid, hid_lo = ops.silu_mul_f32(ab, pb.swiglu_hidden, lp)
+        else:
+            _, hid, hid_lo = ops.gemm(h, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, want_lo=True, split="x3", a_lo=hl)
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split="x3", a_lo=hid_lo)
         return x
 
@@ -961,12 +976,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         ws = self._block_ws(pk["dec"][0], T_loc, D, 1, T_loc, dev, external_kv=kvx is not None)  # one allocation for all L blocks
         planes = (lambda t: (t.clone(), None)) if f32_hooks else self._planes
         want_f32_norm = f32_hooks or self._hp
-        if llama and self.precision == "exact":
-            raise NotImplementedError("precision='exact' covers the CroCo / DINOv2 encoders and the Fast3R decoder on one GPU")
         if llama:
             # embed; per layer add view0_embed to the tokens of view 0, then the block with the rotary angles of each token's view;
             # outputs[0] = embedded tokens, outputs[n_layers] = final RMSNorm
-            ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], out_f32=x, split=sp)
+            ops.gemm(enc_hi, pk["de_w"], bias=pk["de_b"], out_f32=x, split=sp, a_lo=a_lo)
             rows = emb_rows[v_lo:v_lo + n_loc]                              # (n_loc, 64) = [cos (32) | sin (32)] of each view's id
             if len(set(Ps)) == 1:
                 rope = (rows[:, :32].contiguous(), rows[:, 32:].contiguous(), Ps[0])
@@ -1254,7 +1267,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             if feats[0][b][1] is not None:
                 enc_lo = (torch.cat([feats[i][b][1] for i in range(n_loc)], dim=0) if n_loc > 1 else feats[0][b][1]).contiguous()
             kv_dim = getattr(pk["dec"][0], "kv_dim", None) or D
-            kvx = None if sh is None else sh.make_kv_exchange(T_loc, kv_dim, lp, dev, n_heads=dec.num_heads, q_dim=D)
+            kvx = None
+            if sh is not None:
+                # every rank holds the same list of views, so it knows every rank's token count without asking (no per-forward collective)
+                tok = [(v["img"].shape[-2] // ps) * (v["img"].shape[-1] // ps) for v in views]
+                t_all = [sum(tok[slice(*split_range(N_total, sh.world, r))]) for r in range(sh.world)]
+                assert t_all[sh.rank] == T_loc
+                kvx = sh.make_kv_exchange(T_loc, kv_dim, lp, dev, n_heads=dec.num_heads, q_dim=D, t_all=t_all)
             hook_toks.append(self._decode_sample(pk, enc_hi, enc_lo, Ps, emb_rows[b], v_lo, kvx))
             if self.debug_taps is not None:
                 self.debug_taps.setdefault("hooks", []).append([t[0].float().cpu() for t in hook_toks[-1]])

@@ -10,8 +10,8 @@ selects the operand format of the HIP kernels:
     "32" / 32                                                      precision="exact": both operands of every GEMM / conv as fp16
                                                                    hi + lo planes (~22 significand bits), attention in plain fp32 --
                                                                    ~1e-6 of the reference's fp32 path, a validation mode (slow: no
-                                                                   16-bit attention).  Models it does not cover (LlamaDecoder, view
-                                                                   sharding) run precision="high" instead, with a warning
+                                                                   16-bit attention); every model this package builds, view-sharded
+                                                                   ones included (one-GPU rank emulation excepted)
     torch.float32                                                  (in the reference: NOT fp32 but the default autocast dtype, SURVEY.md
                                                                    section 0.3) fp16 operands with precision="high" (split weights,
                                                                    split head operands, fp16 attention); a
@@ -83,9 +83,7 @@ def _operand_format(precision, model, n_views=0):
     if precision in ("bf16-mixed", "bf16-mixed-no-grad-scaling", torch.bfloat16):
         return torch.bfloat16, model.precision
     if precision in ("32", 32, torch.float32):
-        from .fast3r import LlamaDecoder
-        exact_ok = precision is not torch.float32 and model.sharding is None and not isinstance(model.decoder, LlamaDecoder)
-        if exact_ok:
+        if precision is not torch.float32:
             if n_views > EXACT_WARN_VIEWS and not _warned_exact_size:
                 warnings.warn(f"fast3r_amd.inference(dtype='32') on {n_views} views: the fp32-equivalent mode runs the attention core on the "
                               "fp32 FMA pipe (~30 TFLOP/s, quadratic in the number of views: minutes per forward pass at hundreds of views); "
@@ -96,7 +94,7 @@ def _operand_format(precision, model, n_views=0):
         if not _warned_fp32:
             warnings.warn(f"fast3r_amd.inference(dtype={precision!r}): running fp16 operands with split hi + lo planes (precision='high': ~22-bit "
                           "weights and head activations, fp16 attention operands, fp32 accumulation); the fp32-equivalent mode is "
-                          "dtype='32' on an unsharded Fast3R-decoder model (precision='exact').", stacklevel=3)
+                          "dtype='32' (precision='exact').", stacklevel=3)
             _warned_fp32 = True
         return torch.float16, "high"
     return model.compute_dtype, model.precision

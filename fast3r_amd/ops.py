@@ -424,29 +424,58 @@ def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.
     return pts, conf
 
 
-def rope2d_f32(qkv, n_heads, seq_len, rope):
-    """precision "exact": RoPE-2D in place on the q and k parts (first 2 * n_heads * 64 columns) of the fp32 qkv[T][3D] buffer;
-    rope = (cos, sin, tokens_per_row) as for gemm_qkv."""
+def rope_f32(qkv, n_rot_heads, seq_len, rope, rope_mode=0):
+    """precision "exact": rotary embedding in place on the first n_rot_heads 64-wide column groups (q heads, then k heads) of the fp32
+    qkv[T][...] buffer; rope = (cos, sin, tokens_per_row | rows per group) and rope_mode as for gemm_qkv."""
     require_gpu(qkv, "qkv")
     assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1
-    check(_lib.lib().f3r_rope2d_f32(ptr(qkv), qkv.shape[0], qkv.stride(0), n_heads, seq_len, int(rope[2]), ptr(rope[0]), ptr(rope[1]), stream_ptr()),
-          "f3r_rope2d_f32")
+    check(_lib.lib().f3r_rope_f32(ptr(qkv), qkv.shape[0], qkv.stride(0), int(n_rot_heads), seq_len, int(rope[2]), int(rope_mode), ptr(rope[0]),
+                                  ptr(rope[1]), stream_ptr()), "f3r_rope_f32")
     return qkv
 
 
-def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_dim=64):
-    """precision "exact": fp32 softmax attention over qkv[T][3D] fp32 (q | k | v column blocks, 64 per head) -> (o_hi, o_lo) lowp planes
-    [T][D] (the A operand of the X3 projection) [, o fp32 with want_f32]."""
+def rope2d_f32(qkv, n_heads, seq_len, rope):
+    """RoPE-2D on the q and k parts (first 2 * n_heads * 64 columns) of the fp32 qkv[T][3D] buffer."""
+    return rope_f32(qkv, 2 * n_heads, seq_len, rope, 0)
+
+
+def silu_mul_f32(ab, hidden, lp):
+    """precision "exact": SwiGLU gate on fp32 ab[rows][2*hidden] -> (hi, lo) lowp planes [rows][hidden] (llama.py:284)."""
+    require_gpu(ab, "ab")
+    assert ab.dtype == torch.float32 and ab.dim() == 2 and ab.shape[1] == 2 * hidden and ab.is_contiguous()
+    hi = torch.empty((ab.shape[0], hidden), dtype=lp, device=ab.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().f3r_silu_mul_f32(ptr(ab), ptr(hi), ptr(lo), ab.shape[0], int(hidden), dtype_id(lp), stream_ptr()), "f3r_silu_mul_f32")
+    return hi, lo
+
+
+def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_dim=64, kv_group=1, causal=False, kv=None, q_pos0=0, k_pos0=0):
+    """precision "exact": fp32 softmax attention -> (o_hi, o_lo) lowp planes [T][D] (the A operand of the X3 projection) [, o fp32 with
+    want_f32].  qkv fp32 [T][Dq + 2 Dkv] = q | k | v column blocks (head_dim per head; Dkv = Dq / kv_group: grouped-query heads);
+    kv = (k, v) fp32 [n_seq * tk][Dkv] replaces the k / v columns of qkv (a view-sharded rank attending over the gathered keys of all
+    ranks); causal masks by absolute position (q_pos0 / k_pos0 = position of the first query / key)."""
     require_gpu(qkv, "qkv")
     assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1
     T, D = qkv.shape[0], n_heads * head_dim
-    assert qkv.shape[1] == 3 * D and T == n_seq * seq_len
+    Dkv = D // max(1, kv_group)
+    assert qkv.shape[1] == D + 2 * Dkv and T == n_seq * seq_len
     o_hi = torch.empty((T, D), dtype=lp, device=qkv.device)
     o_lo = torch.empty((T, D), dtype=lp, device=qkv.device)
     o32 = torch.empty((T, D), dtype=torch.float32, device=qkv.device) if want_f32 else None
+    a = _lib.AttnF32Args()
     base = qkv.data_ptr()
-    check(_lib.lib().f3r_attn_f32(base, base + D * 4, base + 2 * D * 4, qkv.stride(0), ptr(o_hi), ptr(o_lo), ptr(o32), D, n_seq, seq_len, n_heads,
-                                  float(scale), dtype_id(lp), int(head_dim), stream_ptr()), "f3r_attn_f32")
+    a.q, a.ldq = base, qkv.stride(0)
+    if kv is None:
+        a.k, a.v, a.ldkv, a.tk = base + D * 4, base + (D + Dkv) * 4, qkv.stride(0), seq_len
+    else:
+        k, v = kv
+        assert k.dtype == v.dtype == torch.float32 and k.shape == v.shape and k.shape[1] == Dkv and k.is_contiguous() and v.is_contiguous()
+        assert k.shape[0] % max(1, n_seq) == 0
+        a.k, a.v, a.ldkv, a.tk = k.data_ptr(), v.data_ptr(), Dkv, k.shape[0] // max(1, n_seq)
+    a.o_hi, a.o_lo, a.o_f32, a.ldo = ptr(o_hi), ptr(o_lo), ptr(o32), D
+    a.n_seq, a.tq, a.q_pos0, a.k_pos0 = n_seq, seq_len, int(q_pos0), int(k_pos0)
+    a.n_heads, a.kv_group, a.causal, a.dtype, a.head_dim, a.scale = n_heads, max(1, int(kv_group)), int(bool(causal)), dtype_id(lp), int(head_dim), float(scale)
+    check(_lib.lib().f3r_attn_f32_ex(ctypes.byref(a), stream_ptr()), "f3r_attn_f32_ex")
     return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 

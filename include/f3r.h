@@ -48,7 +48,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
 int f3r_version(void);  /* 300 = 0.3.0, the round-3 ABI (f3r_attn_args.kernel_sel, head_dim field); 200 = round 2 */
 const char* f3r_last_error_string(void);
-/* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1): lets a foreign-language binding
+/* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
 size_t f3r_sizeof(int what);
 
@@ -367,6 +367,36 @@ int f3r_rope2d_f32(float* qkv, int64_t rows, int64_t ld, int n_heads, int64_t se
                    const float* rope_sin, f3r_stream_t stream);
 int f3r_attn_f32(const float* q, const float* k, const float* v, int64_t ld, void* o_hi, void* o_lo, float* o_f32, int64_t ldo,
                  int64_t n_seq, int64_t seq_len, int n_heads, float scale, int dtype, int head_dim, f3r_stream_t stream);
+
+/* The general forms (LlamaDecoder and view-sharded models in precision "exact"):
+ * f3r_rope_f32: rotary embedding in place on the first n_rot_heads 64-wide column groups of qkv (q heads, then k heads); rope_mode as in
+ *   f3r_gemm_args.rope_mode (0: RoPE-2D tables [n_pos][16]; 1: one [32]-angle row per group of rope_w rows, llama.py:96-122).
+ * f3r_silu_mul_f32: SwiGLU gate (llama.py:284) on fp32 ab[rows][2*hidden] -> hi + lo planes [rows][hidden].
+ * f3r_attn_f32_ex: fp32 attention with separate query / key counts (tq, tk per sequence), grouped-query heads (query head h reads K / V
+ *   head h / kv_group: repeat_kv, llama.py:195-198) and an optional causal mask on absolute positions (key j visible to query i iff
+ *   k_pos0 + j <= q_pos0 + i), so a rank of a view-sharded model can attend its queries over the gathered keys of all ranks. */
+typedef struct f3r_attn_f32_args {
+  const float* q;    /* [n_seq * tq][ldq], head h at columns [h * head_dim, (h + 1) * head_dim) */
+  const float* k;    /* [n_seq * tk][ldkv], K / V head g at columns [g * head_dim, ...) */
+  const float* v;
+  int64_t ldq, ldkv;
+  void* o_hi;        /* lowp planes [n_seq * tq][ldo] (o_lo optional), and / or */
+  void* o_lo;
+  float* o_f32;      /* fp32 [n_seq * tq][ldo] */
+  int64_t ldo;
+  int64_t n_seq, tq, tk;
+  int64_t q_pos0, k_pos0; /* causal only */
+  int32_t n_heads;   /* query heads */
+  int32_t kv_group;  /* query heads per K / V head (0 / 1 = plain multi-head) */
+  int32_t causal;
+  int32_t dtype;     /* f3r_dtype of the lowp planes */
+  int32_t head_dim;  /* 0 = 64, or a multiple of 16 up to 128 */
+  float scale;
+} f3r_attn_f32_args;
+int f3r_rope_f32(float* qkv, int64_t rows, int64_t ld, int n_rot_heads, int64_t seq_len, int rope_w, int rope_mode, const float* rope_cos,
+                 const float* rope_sin, f3r_stream_t stream);
+int f3r_silu_mul_f32(const float* ab, void* out_hi, void* out_lo, int64_t rows, int hidden, int dtype, f3r_stream_t stream);
+int f3r_attn_f32_ex(const f3r_attn_f32_args* args, f3r_stream_t stream);
 
 #ifdef __cplusplus
 }

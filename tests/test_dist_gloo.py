@@ -63,11 +63,18 @@ def _worker(rank, world, port, ret):
             assert kvx.has_remote and loc[2] == t_loc and [s[2] for s in rem] == [2 * P if rank == 0 else 3 * P]
             out2 = _segment_attention(qf[r0:r0 + t_loc], [loc] + rem, 0.16)  # softmax is order independent
             assert torch.allclose(out2, full[r0:r0 + t_loc], atol=1e-5)
+        # precision "exact": the fp32 K / V rows of all ranks in global token order
+        k_all, v_all = kvx.gather_rows_f32(kf[r0:r0 + t_loc, :64].contiguous(), vf[r0:r0 + t_loc, :64].contiguous())
+        assert torch.equal(k_all, kf[:, :64]) and torch.equal(v_all, vf[:, :64])
+        # the model passes the token counts it derives from the (shared) list of views: same exchange object, no collective
+        assert sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), t_all=[3 * P, 2 * P]) is kvx
         res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
         assert len(res) == hi - lo  # outputs stay sharded by default
         sh.gather_outputs = True
-        res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
+        mine = [{"x": torch.full((1, 2 + i), float(i)), "c": torch.arange(3 * (i + 1), dtype=torch.float32).view(3, i + 1)} for i in range(lo, hi)]
+        res = sh.gather_results(mine, n_views, torch.device("cpu"))   # ragged shapes per view, two tensors per view
         assert [float(r["x"][0, 0]) for r in res] == [0.0, 1.0, 2.0, 3.0, 4.0]
+        assert all(r["x"].shape == (1, 2 + i) and torch.equal(r["c"], torch.arange(3 * (i + 1), dtype=torch.float32).view(3, i + 1)) for i, r in enumerate(res))
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

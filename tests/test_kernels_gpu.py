@@ -593,6 +593,54 @@ def test_exact_mode_rope_and_fp32_attention(built_lib, dt, n_seq, gh, gw, H):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,kv_group,causal,tq,tk,q_pos0", [(4, 2, True, 300, 300, 0), (4, 4, False, 70, 333, 0), (2, 1, True, 130, 520, 260),
+                                                            (4, 2, True, 64, 200, 100)])
+def test_exact_mode_general_attention_rope_and_swiglu(built_lib, dt, H, kv_group, causal, tq, tk, q_pos0):
+    """The general forms of the fp32-equivalent mode (LlamaDecoder and view-sharded models): f3r_attn_f32_ex with grouped-query heads, a causal
+    mask on absolute positions and keys that are not the queries' own rows (a rank's queries over the gathered keys of all ranks);
+    f3r_rope_f32 in the per-view form of the Llama blocks; f3r_silu_mul_f32 -- all vs fp64."""
+    D, Dkv = H * 64, H // kv_group * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn((tq, D + 2 * Dkv), generator=g)
+    k_all, v_all = torch.randn((tk, Dkv), generator=g), torch.randn((tk, Dkv), generator=g)
+    scale = 0.125
+    own = tq == tk and q_pos0 == 0   # the queries' own keys (columns of qkv) or an external K / V
+    kv = None if own else (k_all.to(DEV), v_all.to(DEV))
+    o_hi, o_lo, o32 = ops.attention_f32(qkv.to(DEV), H, 1, tq, scale, dt, want_f32=True, kv_group=kv_group, causal=causal, kv=kv, q_pos0=q_pos0)
+    kk, vv = (qkv[:, D:D + Dkv], qkv[:, D + Dkv:]) if own else (k_all, v_all)
+    q64 = qkv[:, :D].double().reshape(tq, H, 64).transpose(0, 1)
+    k64 = kk.double().reshape(tk, H // kv_group, 64).transpose(0, 1).repeat_interleave(kv_group, dim=0)
+    v64 = vv.double().reshape(tk, H // kv_group, 64).transpose(0, 1).repeat_interleave(kv_group, dim=0)
+    sc = q64 @ k64.transpose(-1, -2) * scale
+    if causal:
+        vis = torch.arange(tk)[None, :] <= (q_pos0 + torch.arange(tq))[:, None]
+        sc = sc.masked_fill(~vis[None], float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ v64).transpose(0, 1).reshape(tq, D)
+    assert_close(o32, ref, 3e-6, "fp32 attention (general)")
+    assert_close(o_hi.float().cpu().double() + o_lo.float().cpu().double(), ref, 3e-6 if dt == torch.float16 else 3e-5, "hi + lo planes")
+    # per-view rotary embedding (rope_mode 1): rows of view v rotate by table row v; dims [0,32) pair (i, i+16) with columns 0-15, [32,64) with 16-31
+    n_views, per_view = 5, 12
+    T = n_views * per_view
+    x = torch.randn((T, D + 2 * Dkv), generator=g)
+    ang = torch.rand((n_views, 32), generator=g) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    buf = x.clone().to(DEV)
+    ops.rope_f32(buf, H + H // kv_group, T, (cos.to(DEV), sin.to(DEV), per_view), rope_mode=1)
+    xr = x[:, :D + Dkv].double().reshape(T, -1, 2, 2, 16)            # [T][head][half][pair member][i]
+    c = cos.double().reshape(n_views, 2, 16).repeat_interleave(per_view, dim=0)[:, None]   # [T][1][half][i]
+    s_ = sin.double().reshape(n_views, 2, 16).repeat_interleave(per_view, dim=0)[:, None]
+    a_, b_ = xr[:, :, :, 0], xr[:, :, :, 1]
+    rot = torch.stack([a_ * c - b_ * s_, b_ * c + a_ * s_], dim=3).reshape(T, D + Dkv)
+    assert_close(buf[:, :D + Dkv], rot, 2e-6, "per-view rope")
+    assert torch.equal(buf[:, D + Dkv:].cpu(), x[:, D + Dkv:])
+    hidden = 96
+    ab = torch.randn((37, 2 * hidden), generator=g) * 3
+    hi, lo = ops.silu_mul_f32(ab.to(DEV), hidden, dt)
+    want = F.silu(ab[:, :hidden].double()) * ab[:, hidden:].double()
+    assert_close(hi.float().cpu().double() + lo.float().cpu().double(), want, 3e-6 if dt == torch.float16 else 3e-5, "fp32 swiglu planes")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_patchify_any_patch_size_and_general_bilinear(built_lib, dt):
     """DINOv2's patch 14: im2col rows zero-padded to a row stride that is a multiple of 8; the head's Interpolate(scale_factor=14/8)."""
     img = torch.rand(2, 3, 28, 42) * 2 - 1
