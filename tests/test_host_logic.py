@@ -124,7 +124,7 @@ def test_inference_dtype_argument_selects_the_operand_format():
         warnings.simplefilter("ignore")
         assert _operand_format(torch.float32, m) == (torch.float16, "high")
         llama = Fast3R(*tiny_args(decoder_type="llama"))
-        assert _operand_format("32", llama) == (torch.float16, "high")  # not covered by "exact": the closest mode, with a warning
+        assert _operand_format("32", llama) == (torch.float16, "exact")  # since round 3 the fp32-equivalent mode covers the LlamaDecoder too
     with pytest.raises(ValueError, match="precision"):
         Fast3R(*tiny_args(), precision="fp32")
 
