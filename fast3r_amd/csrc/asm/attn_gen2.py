@@ -22,15 +22,18 @@ import sys
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from isa import Program, Ins, Label, LabelRef, Lit, Neg, V, A, S, VCC, M0, Reg  # noqa: E402
+from isa import Program, Ins, Label, LabelRef, Lit, Neg, V, A, S, VCC, M0, EXEC, Reg  # noqa: E402
 
-from attn_gen import (ARG_Q, ARG_O, ARG_LDQ, ARG_NTILES, ARG_QBS, ARG_KVSHIFT, ARG_STO, ARG_KBS, ARG_STLD, ARG_SEG, SEG_BYTES, ARG_SIZE,  # noqa: E402,F401
+from attn_gen import (ARG_TQ, ARG_Q, ARG_O, ARG_LDQ, ARG_NTILES, ARG_QBS, ARG_KVSHIFT, ARG_STO, ARG_KBS, ARG_STLD, ARG_SEG, SEG_BYTES, ARG_SIZE,  # noqa: E402,F401
                       FLAG_STATE_IN, FLAG_STATE_OUT, QPW, WG_Q, LDS_SLOT, s_q, s_k, s_vt, s_o, s_ldq, s_ldk, s_ldvt, s_ldo, s_nt, s_nseg,
                       s_wid, s_t, s_dma_u, s_seg_left, s_kstep, s_m0base, s_seg, s_hopret, s_flags, s_sto, s_lomask, s_ret, s_floor, s_ntm1,
                       SEG0, s_stml, seg_rec)
 import attn_gen as _v1  # noqa: E402
 
 s_delta = S(39)    # byte step of the fragment addresses from tile t to tile t+1 (one LDS slot, or back to slot 0)
+s_shift = S(5)     # rows at the start of this wave's 128-row tile that belong to an earlier wave (partial last workgroup: the tile is
+                   # moved back to end at the last query row, the overlap is computed twice and stored once)
+s_tq = S(6)
 
 # ---- register map
 LANE = 0           # v0 = lane id (after the prologue); v1 .. v11 temporaries
@@ -125,6 +128,7 @@ class AttnGen2:
         e("s_load_dwordx4", S(40, 4), S(0, 2), Lit(ARG_QBS), comment="q, o batch strides")
         e("s_load_dwordx2", S(44, 2), S(0, 2), Lit(ARG_KVSHIFT), comment="kv_shift, flags")
         e("s_load_dwordx4", S(48, 4), S(0, 2), Lit(ARG_STO), comment="st_o, st_ml")
+        e("s_load_dword", s_tq, S(0, 2), Lit(ARG_TQ), comment="query rows")
         for i in range(3):
             e("s_load_dwordx16", S(SEG0 + 16 * i, 16), S(0, 2), Lit(ARG_SEG + 64 * i))
         e("v_lshrrev_b32", V(1), 6, V(0))
@@ -148,6 +152,11 @@ class AttnGen2:
         e("s_lshl_b32", S(40), S(2), 9)
         e("s_lshl_b32", S(41), s_wid, 7)
         e("s_add_u32", S(40), S(40), S(41), comment="row0")
+        # any tq >= 128: a wave whose 128 rows would run past the last query works on the LAST 128 rows instead and stores only its own
+        e("s_sub_u32", S(42), s_tq, 128)
+        e("s_min_u32", S(43), S(40), S(42))
+        e("s_sub_u32", s_shift, S(40), S(43))
+        e("s_mov_b32", S(40), S(43))
         e("s_lshl_b32", S(41), S(3), 7, comment="head * 128 bytes")
         for base, ld in ((s_q, s_ldq), (s_o, s_ldo)):
             e("s_mul_i32", S(42), S(40), ld)
@@ -306,6 +315,14 @@ class AttnGen2:
         msk = self.nslot - 1
         return [I("s_add_u32", S(40), s_t, 1), I("s_and_b32", S(40), S(40), msk), I("s_mov_b32", S(41), Lit((-msk * LDS_SLOT) & 0xFFFFFFFF)),
                 I("s_cmp_eq_u32", S(40), 0), I("s_cselect_b32", s_delta, S(41), Lit(LDS_SLOT))]
+
+    def own_rows_mask(self, qb):
+        """EXEC = the lanes of block qb whose query row this wave owns: 32 qb + lq >= s_shift (v2 = lq); all of them unless the wave's
+        tile was moved back at the end of the query range"""
+        e = self.e
+        e("s_sub_i32", S(46), s_shift, 32 * qb)
+        e("v_cmp_le_i32", VCC, S(46), V(2))
+        e("s_mov_b64", EXEC, VCC)
 
     def state_rows_offsets(self):
         """v[16+qb] = byte offset of this lane's row of block qb in st_o (+ 16 g), v[20+qb] in st_ml, v[24+qb] = the latter + 4 g
@@ -637,11 +654,13 @@ class AttnGen2:
         k = 0
         for qb in range(QPW):
             if qb:
+                e("s_mov_b64", EXEC, -1)
                 e("v_add_u32", V(4), S(47), V(4))
             e("ds_bpermute_b32", V(5), V(7), V(LRUN + qb))
             e("s_waitcnt", "lgkmcnt(0)")
             e("v_add_f32", V(5), V(5), V(LRUN + qb))
             e("v_rcp_f32", V(6), V(5))
+            self.own_rows_mask(qb)
             for db in range(2):
                 for rq in range(4):
                     t = 16 + 6 * (k % 4)   # rotate through four sets of temporaries in the (dead) score registers
@@ -661,6 +680,7 @@ class AttnGen2:
         self.state_rows_offsets()
         k = 0
         for qb in range(QPW):
+            self.own_rows_mask(qb)
             for db in range(2):
                 for rq in range(4):
                     t = 32 + 4 * (k % 8)

@@ -52,6 +52,7 @@ class Special:
 
 VCC = Special("vcc")
 M0 = Special("m0")
+EXEC = Special("exec")
 OFF = Special("off")
 
 

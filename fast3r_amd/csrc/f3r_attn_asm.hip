@@ -29,7 +29,8 @@ struct f3r_attn_asm_args {
   float* st_o;
   float* st_ml;
   uint64_t k_bs, vt_bs;
-  uint32_t st_o_ld_b, st_ml_ld_b, pad[2];
+  uint32_t st_o_ld_b, st_ml_ld_b;
+  uint32_t tq, pad;                      // query rows (the last workgroup may be partial: ARG_TQ)
   f3r_attn_asm_seg seg[8];
 };
 static_assert(sizeof(f3r_attn_asm_args) == 304 && offsetof(f3r_attn_asm_args, seg) == 112, "must match ARG_SIZE / ARG_SEG of attn_gen.py");
@@ -69,7 +70,7 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   *why = none;
   if (a.causal) { *why = "causal mask"; return false; }
   if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
-  if (a.tq <= 0 || a.tq % 512 != 0) { *why = "tq not a multiple of 512"; return false; }
+  if (a.tq < 128) { *why = "fewer than 128 query rows"; return false; }
   if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return false; }
   if ((a.state_in || a.state_out) && a.batch != 1) { *why = "carried softmax state with batch > 1"; return false; }
   int first = -1;
@@ -93,7 +94,7 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
     *why = "row strides too large for 32-bit lane offsets";
     return false;
   }
-  if (a.tq / 512 >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
+  if (a.tq >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
   return true;
 }
 
@@ -120,6 +121,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   k.st_ml = a.st_ml;
   k.st_o_ld_b = (uint32_t)a.n_heads * 256u;
   k.st_ml_ld_b = (uint32_t)a.n_heads * 16u;
+  k.tq = (uint32_t)a.tq;
   for (int s = 0; s < a.n_seg; ++s) {
     if (a.seg_len[s] == 0) continue;
     f3r_attn_asm_seg& g = k.seg[k.n_seg++];
@@ -133,7 +135,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   }
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.tq / 512), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
+  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((a.tq + 511) / 512), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
     f3r_set_error("f3r_attn_fwd: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
     return F3R_ERR_LAUNCH;

@@ -226,7 +226,7 @@ typedef struct f3r_attn_args {
   int64_t seg_pos0[F3R_MAX_SEG];
   /* Kernel choice (per call, like f3r_gemm_args.kernel_sel; no process-wide switch):
        0 = automatic: the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_gen.py: 512-query workgroups, 128 queries per
-           wave) when the launch is eligible -- no causal mask, q_prescaled, tq a multiple of 512, every non-empty K/V segment a
+           wave; a partial last workgroup is fine) when the launch is eligible -- no causal mask, q_prescaled, tq >= 128, every non-empty K/V segment a
            multiple of 64 keys with one ldvt and one pair of batch strides, at least F3R_ATTN_ASM_MIN_KEYS keys in total, kv_group a
            power of two, batch 1 when the softmax state is carried (state_in / state_out; the state layout is the HIP kernel's, so
            the two kernels can resume each other's launches) -- and the general HIP kernel otherwise;

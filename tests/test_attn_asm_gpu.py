@@ -57,8 +57,11 @@ def run(qs, k, v, H, Hkv=None, sel=2):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Tq,Tk,H", [(512, 64, 1), (512, 128, 2), (1024, 192, 2), (512, 1024, 3), (1536, 4096, 2)])
+@pytest.mark.parametrize("Tq,Tk,H", [(512, 64, 1), (512, 128, 2), (1024, 192, 2), (512, 1024, 3), (1536, 4096, 2),
+                                     (128, 256, 1), (200, 192, 2), (768, 768, 2), (1000, 320, 1), (2304 + 60, 1024, 2)])
 def test_asm_kernel_vs_fp64(built_lib, dt, Tq, Tk, H):
+    """incl. query counts that are not multiples of 512 (3 views of 768 tokens; a ragged 1000): the waves of the partial last workgroup work
+    on the LAST 128 rows and store only the rows they own"""
     qs = rnd((Tq, H * 64), dt, 1, 0.125 * LOG2E * 1.5)
     k, v = rnd((Tk, H * 64), dt, 2, 1.5), rnd((Tk, H * 64), dt, 3)
     o = run(qs, k, v, H)
@@ -129,12 +132,14 @@ def test_asm_kernel_grouped_query_and_batch(built_lib, dt):
     assert_close(o.float(), ref, 2 * lp_tol(dt), "gqa + batch")
 
 
+@pytest.mark.parametrize("Tq", [1024, 1024 + 768])
 @pytest.mark.parametrize("dt", DTYPES)
-def test_asm_kernel_segments_and_carried_state(built_lib, dt):
+def test_asm_kernel_segments_and_carried_state(built_lib, dt, Tq):
     """The view-sharded layout: K/V as segments (one launch over all of them == one launch over their concatenation), and the
     two-launch form (local segment with state_out, remote segments with state_in) == one launch -- for the hand-scheduled kernel alone
-    and with the general HIP kernel taking either launch (one state layout for both)."""
-    H, Tq = 2, 1024
+    and with the general HIP kernel taking either launch (one state layout for both).  Tq = 1792: a partial last workgroup, whose moved
+    waves read state rows that another wave owns (and must not write them)."""
+    H = 2
     lens = [192, 64, 320, 128]
     qs = rnd((Tq, H * 64), dt, 70, 0.125 * LOG2E * 1.5)
     ks = [rnd((n, H * 64), dt, 71 + i, 1.5) for i, n in enumerate(lens)]
@@ -171,7 +176,7 @@ def test_asm_kernel_is_the_automatic_choice_and_refuses_what_it_cannot_do(built_
     auto, forced = run(qs, k, v, H, sel=0), run(qs, k, v, H, sel=2)
     assert torch.equal(auto, forced)  # >= F3R_ATTN_ASM_MIN_KEYS keys, eligible: kernel_sel 0 takes the hand-scheduled kernel
     with pytest.raises(ValueError, match="not eligible"):
-        run(qs[:300], k, v, H, sel=2)  # tq not a multiple of 512
+        run(qs[:100], k, v, H, sel=2)  # fewer than 128 query rows
     with pytest.raises(ValueError, match="not eligible"):
         run(qs, k[:100], v[:100], H, sel=2)  # keys not a multiple of 64
     o = torch.empty((Tq, 64), dtype=dt, device=DEV)

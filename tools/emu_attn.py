@@ -18,11 +18,11 @@ import attn_gen  # noqa: E402
 from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
 
 
-def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0):
+def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0):
     """segs: [(k address, vt address, tiles)] -> the kernel argument block (byte strides)"""
     nt = sum(t for _, _, t in segs)
-    b = struct.pack("<QQIIIIIIQQIIQQQQIIQ", q, o, ldq, ldk, ldvt, ldo, nt, len(segs), q_bs, o_bs, kv_shift, flags, st_o, st_ml, k_bs, vt_bs,
-                    st_o_ld, st_ml_ld, 0)
+    b = struct.pack("<QQIIIIIIQQIIQQQQIIII", q, o, ldq, ldk, ldvt, ldo, nt, len(segs), q_bs, o_bs, kv_shift, flags, st_o, st_ml, k_bs, vt_bs,
+                    st_o_ld, st_ml_ld, tq, 0)
     assert len(b) == attn_gen.ARG_SEG
     for i in range(8):
         k, vt, t = segs[i] if i < len(segs) else (0, 0, 0)
@@ -32,10 +32,12 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=1):
+             gen_kwargs=None, split_state=False, layout=1, tq=None):
+    """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
+    rows, so a store past the end raises in the emulator's memory model)"""
     rng = np.random.default_rng(seed)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
-    tq, tk = 512 * q_blocks, 64 * sum(seg_tiles)
+    tq, tk = (512 * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
     D = n_heads * 64
     kv_heads = n_heads >> kv_shift
     Dk = kv_heads * 64
@@ -67,7 +69,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
     st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
     common = dict(q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
-                  st_o_ld=D * 4, st_ml_ld=n_heads * 16)
+                  st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq)
     launches = []
     if split_state:
         assert len(segs) >= 2 and batch == 1
@@ -93,13 +95,14 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         og = mem.get(a_o, np.uint16, (batch, tq, D))
         x, head, b = wg
         kvh = head >> kv_shift
-        qf = half_to_f32(qh[b, x * 512:(x + 1) * 512, head * 64:(head + 1) * 64], dtype).astype(np.float64)
+        r1 = min(tq, (x + 1) * 512)
+        qf = half_to_f32(qh[b, x * 512:r1, head * 64:(head + 1) * 64], dtype).astype(np.float64)
         kf = half_to_f32(kh[b, :, kvh * 64:(kvh + 1) * 64], dtype).astype(np.float64)
         vf = half_to_f32(vth_all[b, kvh * 64:(kvh + 1) * 64, :], dtype).astype(np.float64).T
         s = qf @ kf.T
         p = np.exp2(s - s.max(axis=1, keepdims=True))
         ref = (p @ vf) / p.sum(axis=1, keepdims=True)
-        got = half_to_f32(og[b, x * 512:(x + 1) * 512, head * 64:(head + 1) * 64], dtype).astype(np.float64)
+        got = half_to_f32(og[b, x * 512:r1, head * 64:(head + 1) * 64], dtype).astype(np.float64)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         worst = max(worst, err)
         print(f"wg {wg}: {steps} instructions, rel-L2 {err:.3e}, max abs {np.abs(got - ref).max():.3e}, nan {np.isnan(got).sum()}")

@@ -92,6 +92,7 @@ class Wave:
         self.a = np.zeros((256, 64), np.uint32)
         self.s = np.zeros(128, np.uint32)
         self.vcc = 0
+        self.exec = MASK64   # honoured by the global stores only (the generators mask nothing else)
         self.scc = 0
         self.m0 = 0
         self.pc = 0
@@ -256,6 +257,14 @@ class Wave:
         if op == "s_mov_b32":
             self.wrs(a[0], self.rds(a[1]))
             return
+        if op == "s_mov_b64" and isinstance(a[0], Special) and a[0].name == "exec":
+            self.exec = self.rds64(a[1]) & MASK64
+            return
+        if op == "s_min_u32":
+            x, y = self.rds(a[1]), self.rds(a[2])
+            self.scc = int(x < y)
+            self.wrs(a[0], min(x, y))
+            return
         if op == "s_mov_b64":
             v = self.rds64(a[1])
             self.s[a[0].idx] = v & 0xFFFFFFFF
@@ -408,14 +417,16 @@ class Wave:
             with np.errstate(over="ignore"):
                 self.wr(a[0], u32(acc.astype(np.float32)))
             return
-        if op in ("v_cmp_eq_u32", "v_cmp_le_f32", "v_cmp_ge_f32", "v_cmp_lt_u32", "v_cmp_le_u32"):
+        if op in ("v_cmp_eq_u32", "v_cmp_le_f32", "v_cmp_ge_f32", "v_cmp_lt_u32", "v_cmp_le_u32", "v_cmp_le_i32"):
             assert isinstance(a[0], Special) and a[0].name == "vcc"
-            if op.endswith("u32"):
+            if op.endswith("i32"):
+                x, y = self.rd(a[1]).view(np.int32), self.rd(a[2]).view(np.int32)
+            elif op.endswith("u32"):
                 x, y = self.rd(a[1]), self.rd(a[2])
             else:
                 x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
             with np.errstate(invalid="ignore"):
-                m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_u32": x <= y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
+                m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_u32": x <= y, "v_cmp_le_i32": x <= y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
             self.vcc = int(sum(1 << i for i in range(64) if m[i]))
             return
         if op == "v_cndmask_b32":
@@ -476,7 +487,8 @@ class Wave:
             off = self.rd(voff).astype(np.int64)
             vals = self.tuple_read(src).copy()
             for lane in range(64):
-                mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
+                if (self.exec >> lane) & 1:
+                    mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
             self.vm.append(lambda: None)
             return
         if op == "global_store_dwordx2":
@@ -485,7 +497,8 @@ class Wave:
             off = self.rd(voff).astype(np.int64)
             vals = self.tuple_read(src).copy()
             for lane in range(64):
-                mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
+                if (self.exec >> lane) & 1:
+                    mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
             self.vm.append(lambda: None)
             return
         raise NotImplementedError(it.text())
