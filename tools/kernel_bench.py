@@ -104,9 +104,9 @@ def bench_attn_product(dt, views, H=16):
                       "tflops": round(4.0 * T * T * 64 * H / med / 1e9, 1)}), flush=True)
 
 
-def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2):
+def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2, tokens_per_view=1024):
     """The general HIP kernel (kernel_sel 1) next to the hand-scheduled one (kernel_sel 2) on the fusion shape, q pre-scaled."""
-    T = views * 1024
+    T = views * tokens_per_view
     D = H * 64
     q = (torch.randn((T, D), device=DEV) * (0.160192 * 1.4426950408889634)).to(dt)
     k = torch.randn((T, D), device=DEV).to(dt)
@@ -429,6 +429,7 @@ if __name__ == "__main__":
     ap.add_argument("--views", default="20,100")
     ap.add_argument("--attn-dtypes", default="bf16,fp16", help="attnproduct: which operand formats")
     ap.add_argument("--sels", default="1,2", help="attnsel: f3r_attn_args.kernel_sel values to time")
+    ap.add_argument("--tokens-per-view", type=int, default=1024, help="attnsel: 768 = 384x512 images (an odd view count gives a partial last workgroup)")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
@@ -459,7 +460,7 @@ if __name__ == "__main__":
     if args.what == "attnsel":
         for nv in [int(x) for x in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):
-                bench_attn_sel({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv, sels=tuple(int(x) for x in args.sels.split(",")))
+                bench_attn_sel({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv, sels=tuple(int(x) for x in args.sels.split(",")), tokens_per_view=args.tokens_per_view)
         sys.exit(0)
     if args.what == "attnonly":
         for nv in [int(v) for v in args.views.split(",")]:
