@@ -1,12 +1,21 @@
 // Small dense linear algebra in fp64 for the post-processing kernels (one thread per problem): 3x3 SVD, symmetric Jacobi eigen-solver,
-// Cholesky solve.  Device-only, header-only.
+// Cholesky solve.  Header-only; device functions in the library -- with F3R_HOST_BUILD defined the same source compiles as plain C++
+// (tests build f3r_sqpnp.h that way to check the arithmetic on the CPU; the product never does).
 #pragma once
+#ifdef F3R_HOST_BUILD
+#include <cmath>
+#define F3R_LA_FN inline
+#define F3R_LA_FORCE inline
+#else
 #include <hip/hip_runtime.h>
+#define F3R_LA_FN __device__ inline
+#define F3R_LA_FORCE __device__ __forceinline__
+#endif
 
 namespace f3r_la {
 
 // 3x3 SVD of M by two-sided use of the Jacobi eigen-decomposition of M^T M:  M = U diag(s) V^T, s sorted descending.
-__device__ inline void svd3(const double M[3][3], double U[3][3], double S[3], double V[3][3]) {
+F3R_LA_FN void svd3(const double M[3][3], double U[3][3], double S[3], double V[3][3]) {
   double A[3][3];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -83,7 +92,7 @@ __device__ inline void svd3(const double M[3][3], double U[3][3], double S[3], d
   }
 }
 
-__device__ __forceinline__ double det3(const double A[3][3]) {
+F3R_LA_FORCE double det3(const double A[3][3]) {
   return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
          A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
 }
@@ -91,7 +100,7 @@ __device__ __forceinline__ double det3(const double A[3][3]) {
 
 // Eigen-decomposition of a symmetric N x N matrix by cyclic Jacobi rotations: A <- diag(eigenvalues), V columns = eigenvectors.
 template <int N>
-__device__ inline void jacobi_sym(double A[N][N], double V[N][N]) {
+F3R_LA_FN void jacobi_sym(double A[N][N], double V[N][N]) {
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 40; ++sweep) {
@@ -128,7 +137,7 @@ __device__ inline void jacobi_sym(double A[N][N], double V[N][N]) {
 
 // Solve A x = b for a symmetric positive definite N x N matrix (Cholesky); returns false when A is not numerically SPD.
 template <int N>
-__device__ inline bool chol_solve(const double A[N][N], const double* b, double* x) {
+F3R_LA_FN bool chol_solve(const double A[N][N], const double* b, double* x) {
   double L[N][N];
   for (int i = 0; i < N; ++i)
     for (int j = 0; j <= i; ++j) {

@@ -12,10 +12,13 @@
 //      serves every focal, and |r1| / |r3| estimates the focal itself
 //   D. focal: the given one, or the candidate of np.geomspace(S/2, 3S, 100) (:312-316) nearest to the DLT estimate and its two
 //      neighbours, each refined and scored (inlier count :342, ties by truncated cost)
-//   E. nearest rotation (3x3 SVD), 6 gated Gauss-Newton steps on the reprojection error (28 fp64 sums per pass), cam-to-world (:349-350)
+//   E. nearest rotation (3x3 SVD), 6 gated Gauss-Newton steps on the reprojection error (28 fp64 sums per pass)
+//   F. SQPnP (f3r_sqpnp.h) on the points within 5 px of the selected pose: the solver the reference names, on the consensus set, as
+//      OpenCV's solvePnPRansac ends; cam-to-world (:349-350)
 // Same algorithm, independently written on torch.linalg: oracle/pnp_oracle.py.  All passes re-read the view's 4 MB from L2.
 #include "f3r_common.h"
 #include "f3r_linalg.h"
+#include "f3r_sqpnp.h"
 
 namespace {
 
@@ -23,6 +26,11 @@ constexpr int PT = 1024;
 constexpr int NW_ = PT / 64;
 constexpr int N_HYP = 32, SAMPLE = 6, N_GN = 6;
 constexpr float THR2 = 25.0f;  // reprojectionError = 5 px (init_im_poses.py:335)
+
+// out of line: the solver's 9 x 9 temporaries live in its own frame instead of lengthening the live ranges of the kernel's hot loops
+__device__ __attribute__((noinline)) bool sqpnp_solve(const double* sums, double unit2, f3r_sqpnp::Result* out) {
+  return f3r_sqpnp::solve(sums, unit2, *out);
+}
 
 struct Pose {  // world -> camera
   double R[3][3];
@@ -405,6 +413,42 @@ __global__ __launch_bounds__(PT) void pnp_kernel(const float* __restrict__ pts, 
   if (!best_pose.ok || best_cnt < 1.0) {
     fail();
     return;
+  }
+  // ---- F. SQPnP on the consensus set: cv2.solvePnPRansac(..., flags=SOLVEPNP_SQPNP) (init_im_poses.py:335) ends with the named solver on
+  // its inliers, so that -- not the Gauss-Newton iterate that selected them -- is the pose the reference returns.  One pass of 40 fp64
+  // sums over the points within 5 px of the selected pose (conditioned world points, pixels divided by the focal), then f3r_sqpnp::solve
+  // on one thread; the selected pose stays if the solver finds no admissible candidate.
+  {
+    for (int k = 0; k < f3r_sqpnp::N_SUMS; ++k) acc[k] = 0.0;
+    const Pose P = best_pose;
+    const double f = P.f, inv_f = 1.0 / P.f;
+    for (int64_t i = tid; i < npix; i += PT) {
+      if (!(cf[i] > conf_thr)) continue;
+      const double X = pt[i * 3], Y = pt[i * 3 + 1], Z = pt[i * 3 + 2];
+      const double px = (double)(int)(i % W) - ppx, py = (double)(int)(i / W) - ppy;
+      const double z = P.R[2][0] * X + P.R[2][1] * Y + P.R[2][2] * Z + P.t[2];
+      const double x = P.R[0][0] * X + P.R[0][1] * Y + P.R[0][2] * Z + P.t[0];
+      const double y = P.R[1][0] * X + P.R[1][1] * Y + P.R[1][2] * Z + P.t[1];
+      const double ex = f * x / z - px, ey = f * y / z - py;
+      if (!(z > 0.0 && ex * ex + ey * ey <= (double)THR2)) continue;
+      const double Mn[3] = {(X - cen[0]) * isig, (Y - cen[1]) * isig, (Z - cen[2]) * isig};
+      f3r_sqpnp::accumulate(acc, Mn, px * inv_f, py * inv_f);
+    }
+    block_sum<f3r_sqpnp::N_SUMS>(acc, red, sums);
+    if (tid == 0) {
+      f3r_sqpnp::Result r;
+      cur = P;
+      if (sqpnp_solve(sums, sig * sig, &r)) {
+        for (int a = 0; a < 3; ++a) {
+          for (int b = 0; b < 3; ++b) cur.R[a][b] = r.R[a][b];
+          cur.t[a] = sig * r.t[a] - (r.R[a][0] * cen[0] + r.R[a][1] * cen[1] + r.R[a][2] * cen[2]);
+        }
+      }
+    }
+    __syncthreads();
+    const double keep_f = best_pose.f;
+    best_pose = cur;
+    best_pose.f = keep_f;
   }
   if (tid == 0) {  // cam-to-world = inverse of [R | t] (init_im_poses.py:349-350)
     for (int r = 0; r < 3; ++r) {

@@ -11,7 +11,8 @@ the algorithm of the HIP path (f3r_post.hip::pnp_*), written independently on to
        {r1.P - (px/f) r3.P = 0, r2.P - (py/f) r3.P = 0} is [[S0,0,-S1x/f],[0,S0,-S1y/f],[.,.,S2/f^2]]; eliminating the first two
        blocks leaves (S2 - S1x S0^-1 S1x - S1y S0^-1 S1y) c = lambda c for the third row c = [r3 t3] INDEPENDENT of f, and
        [r1 t1] = S0^-1 S1x c / f, [r2 t2] = S0^-1 S1y c / f;
-    2. nearest rotation (SVD) + scale, positive-depth sign;  3. score = points within 5 px;  4. gated Gauss-Newton on the best.
+    2. nearest rotation (SVD) + scale, positive-depth sign;  3. score = points within 5 px;  4. gated Gauss-Newton on the best;
+    5. (round 3) SQPnP on the points within 5 px of that pose: the final solve of cv2.solvePnPRansac(SOLVEPNP_SQPNP), restated in oracle/sqpnp.py.
 PARITY UNPINNED against the reference for this row; anchored on ground truth instead (tests/test_pnp.py: known poses are recovered) and
 on HIP == this file.
 """
@@ -19,6 +20,8 @@ import math
 
 import numpy as np
 import torch
+
+from oracle import sqpnp
 
 REPROJ_THR = 5.0  # init_im_poses.py:335
 N_GN = 6
@@ -205,6 +208,12 @@ def fast_pnp(pts3d, focal, msk, pp=None, num_guessed_focals=100):
     if _count_inliers(R, t, X, px, py, f)[0] == 0:
         return None, None
     R, t = _refine(R, t, X, px, py, f)
+    # ---- stage 3: SQPnP (oracle/sqpnp.py) on the consensus set of that pose -- what cv2.solvePnPRansac(SOLVEPNP_SQPNP) ends with
+    u, v, z = _project(R, t, X, f)
+    inl = (((u - px) ** 2 + (v - py) ** 2) <= REPROJ_THR ** 2) & (z > 0)
+    sol = sqpnp.solve(X[inl].numpy(), torch.stack([px[inl] / f, py[inl] / f], 1).numpy()) if int(inl.sum()) >= 3 else None
+    if sol is not None:
+        R, t = torch.from_numpy(sol[0]), torch.from_numpy(sol[1])
     T = torch.eye(4, dtype=torch.float64)
     T[:3, :3] = R.t()
     T[:3, 3] = -R.t() @ t
