@@ -128,6 +128,23 @@ def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2, tokens_per_v
                           "rel_l2_asm_vs_hip": float((a - b).norm() / a.norm()), "nan": int(torch.isnan(b).sum())}), flush=True)
 
 
+def bench_attn_head_dim(dt, views, hd, H=16):
+    """f3r_attn_fwd on a fusion-shaped problem with head_dim hd (64: the tuned kernels; else attn_generic_kernel)"""
+    T = views * 1024
+    D = H * hd
+    q = (torch.randn((T, D), device=DEV) * (hd ** -0.5 * 1.4426950408889634)).to(dt)
+    k = torch.randn((T, D), device=DEV).to(dt)
+    vt = torch.randn((D, T), device=DEV).to(dt)
+    o = torch.empty((T, D), dtype=dt, device=DEV)
+
+    def f():
+        ops.attention(q, o, H, hd ** -0.5, [(k, vt, T, 0, 0)], q_prescaled=True, head_dim=hd)
+    f()
+    med, mn = time_ms(f, rounds=3, inner=2)
+    print(json.dumps({"kernel": "attn_head_dim", "head_dim": hd, "dtype": str(dt).split(".")[-1], "views": views, "T": T, "ms": round(med, 3),
+                      "tflops": round(4.0 * T * T * hd * H / med / 1e9, 1)}), flush=True)
+
+
 def bench_attn_encoder(dt, views, variants, H=16):
     S, D = 1024, H * 64
     q = torch.randn((views * S, D), device=DEV).to(dt)
@@ -456,6 +473,11 @@ if __name__ == "__main__":
             bench_conv(dt, 8, 512, 512, 128, 128, "head2", sels=(4,))
         bench_gemm(torch.float16, 102400, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2", sels=(2, 5))
         bench_conv(torch.float16, 8, 128, 128, 256, 256, "refinenet1 rcu x3", split="x3", sels=(2, 5))
+        sys.exit(0)
+    if args.what == "attnhd":  # generic head_dim kernel next to the tuned head_dim-64 path
+        for hd in (64, 80, 128):
+            for nv in [int(x) for x in args.views.split(",")]:
+                bench_attn_head_dim(torch.float16, nv, hd)
         sys.exit(0)
     if args.what == "attnsel":
         for nv in [int(x) for x in args.views.split(",")]:
