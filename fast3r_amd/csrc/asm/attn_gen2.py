@@ -99,7 +99,8 @@ class AttnGen2:
         self.lds_bytes = nslot * LDS_SLOT
         if big_gap is None:
             big_gap = 4 if rowsum == "pkadd" else 5   # fillers per MFMA gap: (exp, exp, cvt, pk_add) resp. (exp, exp, cvt, add, add)
-        self.big_gap, self.k8_gap = big_gap, k8_gap
+        # an int, or a tuple that is cycled over the gaps of a stage (e.g. (4, 5): every other gap takes a fifth filler)
+        self.big_gap, self.k8_gap = (tuple(big_gap) if isinstance(big_gap, (tuple, list)) else (int(big_gap),)), k8_gap
         self.ablate = set(ablate)  # timing experiments only (wrong results): nosoftmax, nodma, nobarrier, nok8, noexp, nocvt, nosum
         self.name = name or f"f3r_attn_asm_{dtype}"
         self.p = Program(self.name)
@@ -554,7 +555,7 @@ class AttnGen2:
             out.append(m)
             took = len(pinned[i])
             out += pinned[i]
-            while took < self.big_gap and fi < len(flow) and flow[fi][1] <= i:
+            while took < self.big_gap[i % len(self.big_gap)] and fi < len(flow) and flow[fi][1] <= i:
                 out.append(flow[fi][0])
                 fi += 1
                 took += 1
