@@ -58,6 +58,13 @@ def parse(argv=None):
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other operand format (bf16 / fast)")
     ap.add_argument("--fusion-only", action="store_true",
                     help="BASELINE configs[1]: time only the fusion decoder on frozen random encoder features")
+    ap.add_argument("--weights", default="default", choices=["default", "hot"],
+                    help="synthetic weight distribution (fast3r_amd/synthetic.py): default = the reference's own random init (near-uniform softmax); "
+                         "hot = N(0, 1/fan_in): sharp attention, the lazy softmax reference of the attention kernel really moves")
+    ap.add_argument("--no-hot", action="store_true", help="skip the short second measurement on the hot weights (default-weights runs only)")
+    ap.add_argument("--parity-exact", action="store_true",
+                    help="also run the same views through precision='exact' (the on-device fp32-equivalent path) and report the rel-L2 of the timed format "
+                         "against it (N <= 128: the exact attention runs on the FMA pipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=3)
@@ -180,7 +187,13 @@ def main():
 
     enc, dec, head = vit_large_args(max_image_idx=max(1000, V))
     shapes = {k: tuple(v.shape) for k, v in Fast3R(enc, dec, head).state_dict().items()}
-    sd = synth_state_dict(shapes, seed=0)
+    sds = {}
+
+    def state_dict_for(weights):
+        if weights not in sds:
+            sds[weights] = synth_state_dict(shapes, seed=0, dist=weights)
+        return sds[weights]
+    sd = state_dict_for(args.weights)
 
     # every rank holds only ITS views in HBM (the list is indexed globally by the model)
     views = [None] * V
@@ -192,13 +205,14 @@ def main():
     placeholder = {"img": views[lo]["img"]}
     views = [v if v is not None else placeholder for v in views]  # never read outside [lo, hi)
 
-    def measure(dtype_name, precision, steps=None, warmup=None):
+    def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False):
         """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
+        weights = args.weights if weights is None else weights
         lp = torch.float16 if dtype_name == "fp16" else torch.bfloat16
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
-        model.load_state_dict(sd, strict=True)
+        model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
         if distributed:
             model.shard_views(exchange=args.exchange)
@@ -214,13 +228,15 @@ def main():
             for _ in range(warmup):
                 step_fn()
             ops.ATTN_TIMER = []
+            ops.ATTN_COUNTERS = torch.zeros(4, dtype=torch.int32, device=dev)
             barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
-                step_fn()
+                last_out = step_fn()
             barrier()
             dt = time.perf_counter() - t0
             timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
+            counters, ops.ATTN_COUNTERS = [int(c) & 0xFFFFFFFF for c in ops.ATTN_COUNTERS.tolist()], None
         dt = max_over_ranks(dt)
         # dominant kernel = the fusion attention launches (the ones whose key count is the whole scene)
         if emu:
@@ -248,7 +264,16 @@ def main():
                        "allgather_ms_per_layer_all_links": kvx.comm_bytes_per_layer / (7 * 153e9) * 1e3,
                        "exchange": args.exchange, "attention_launches_per_layer": len(fus) // max(1, n_layers),
                        "attention_ms_per_layer": avg_ms}
+        # how often the lazy softmax reference of the hand-scheduled kernel moved (f3r_attn_args.dbg_counters, summed over every launch of
+        # the timed steps that took that kernel): per wave and 64-key tile, the forced first re-base of each wave not counted
+        entries, waves = counters[0], counters[1]
+        tiles_per_wave = None if (distributed or emu) else V * 1024 // 64   # every asm launch of the unsharded forward walks all keys
+        rebase = None if waves == 0 else {"rebases_per_wave": (entries - waves) / waves,
+                                          "rebases_per_tile": None if tiles_per_wave is None else (entries - waves) / waves / tiles_per_wave,
+                                          "waves": waves, "tiles_per_wave": tiles_per_wave,
+                                          "note": "summed over the timed steps; the forced first re-base of each wave is excluded"}
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
+               "weights": weights, "attn_rebase": rebase,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
                "roofline": {"bound": "mfma", "kernel": " / ".join(kname) + " -- the fusion self-attention launches of f3r_attn_fwd",
                             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
@@ -258,6 +283,26 @@ def main():
             res["emulation"] = res_emu
         if rank == 0 and not args.no_parity and not emu:
             res["parity"] = parity_on_stress_fixture(lp, precision, dev)
+        if parity_exact and not (emu or distributed or args.fusion_only):
+            keep = [{k: v.float().cpu() for k, v in o.items()} for o in last_out]
+            del model, last_out
+            torch.cuda.empty_cache()
+            mx = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision="exact").eval()
+            mx.load_state_dict(state_dict_for(weights), strict=True)
+            mx = mx.to(dev)
+            with torch.no_grad():
+                torch.manual_seed(1234)
+                ref = mx(views)
+            worst = {}
+            for o, g in zip(keep, ref):
+                for k in g:
+                    a, b = o[k].double().flatten(), g[k].double().flatten().cpu()
+                    worst[k] = max(worst.get(k, 0.0), float((a - b).norm() / b.norm()))
+            res["parity_vs_exact"] = {"checker": "precision='exact' on the same views and weights (fp32-equivalent path, 3e-7 of the reference on its golden outputs)",
+                                      "rel_l2": max(worst.values()), "per_output": worst, "bar": 1e-3}
+            model = mx
+            del ref
+        last_out = None
         del model
         torch.cuda.empty_cache()
         return res
@@ -267,7 +312,7 @@ def main():
     else:
         workload = f"Fast3R ViT-L 512x512 end-to-end single forward pass (encoder + fusion decoder + 2 DPT heads), N={V} views"
 
-    main_res = measure(args.dtype, args.precision)
+    main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact)
     if emu:
         out = {"metric": "EMULATED per-rank step: ONE GPU runs rank %d of %d of the view-sharded forward at N=%d (no collectives, remote K/V segments "
                          "pre-filled) -- NOT a multi-GPU measurement" % (args.emulate_rank, args.of, V),
@@ -285,6 +330,12 @@ def main():
     # (bounded: at most 3 timed steps after at most 1 warm-up, whatever --steps / --warmup ask of the main measurement)
     alt_res = None if args.no_alt else measure(*alt_fmt, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
 
+    # The dominant kernel on inputs that exercise it: with the default-init weights the softmax is near-uniform and the
+    # kernel's re-base branch is never taken in the timed region; the hot weights attend sharply.  Bounded: 1 warm-up + at most 2 steps.
+    hot_res = None
+    if args.weights == "default" and not args.no_hot and not emu and not args.fusion_only:
+        hot_res = measure(args.dtype, args.precision, steps=min(args.steps, 2), warmup=min(args.warmup, 1), weights="hot")
+
     if rank == 0:
         out = {
             "metric": "views/sec (512^2, ViT-L) single forward pass at N=%d" % V,
@@ -296,8 +347,15 @@ def main():
                        "operands": main_res["operands"]},
             "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), pmc=load_pmc(main_res["dtype"])),
         }
-        if "parity" in main_res:
-            out["parity"] = main_res["parity"]
+        out["weights"] = main_res["weights"]
+        out["attn_rebase"] = main_res["attn_rebase"]
+        for k in ("parity", "parity_vs_exact"):
+            if k in main_res:
+                out[k] = main_res[k]
+        if hot_res is not None:
+            out["hot_weights"] = {k: hot_res[k] for k in ("weights", "value", "ms_per_step", "steps", "warmup", "dtype", "precision", "attn_rebase")}
+            out["hot_weights"]["roofline"] = {k: hot_res["roofline"][k] for k in ("achieved", "frac", "avg_launch_ms", "e2e")}
+            out["hot_weights"]["frac_vs_default_weights"] = hot_res["roofline"]["frac"] / main_res["roofline"]["frac"]
         if alt_res is not None:
             out["alt_format"] = {k: alt_res[k] for k in ("dtype", "precision", "value", "ms_per_step", "steps", "warmup", "operands") if k in alt_res}
             out["alt_format"]["roofline"] = {k: alt_res["roofline"][k] for k in ("achieved", "frac", "avg_launch_ms", "e2e")}

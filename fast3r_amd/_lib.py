@@ -60,6 +60,7 @@ class AttnArgs(ctypes.Structure):
         ("st_o", _c_vp), ("st_ml", _c_vp), ("state_in", _c_i32), ("state_out", _c_i32),
         ("kv_group", _c_i32), ("causal", _c_i32), ("q_pos0", _c_i64), ("seg_pos0", _c_i64 * F3R_MAX_SEG),
         ("kernel_sel", _c_i32), ("head_dim", _c_i32),
+        ("dbg_counters", _c_vp),
     ]
 
 
@@ -118,7 +119,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 300  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 310  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():
@@ -135,7 +136,8 @@ def lib():
             fn.argtypes = args
         if l.f3r_sizeof(0) != ctypes.sizeof(GemmArgs) or l.f3r_sizeof(1) != ctypes.sizeof(AttnArgs) or l.f3r_sizeof(2) != ctypes.sizeof(AttnF32Args):
             raise F3RError("fast3r_amd/_lib.py struct layout does not match include/f3r.h "
-                           f"(gemm {l.f3r_sizeof(0)} vs {ctypes.sizeof(GemmArgs)}, attn {l.f3r_sizeof(1)} vs {ctypes.sizeof(AttnArgs)})")
+                           f"(gemm {l.f3r_sizeof(0)} vs {ctypes.sizeof(GemmArgs)}, attn {l.f3r_sizeof(1)} vs {ctypes.sizeof(AttnArgs)}, "
+                           f"attn_f32 {l.f3r_sizeof(2)} vs {ctypes.sizeof(AttnF32Args)}): rebuild the library (fast3r_amd/csrc/build.sh)")
         if l.f3r_version() < ABI_VERSION:
             raise F3RError(f"{LIB_PATH} is version {l.f3r_version()}, this host code needs >= {ABI_VERSION}: rebuild it (fast3r_amd/csrc/build.sh)")
         _lib = l

@@ -24,7 +24,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from isa import Program, Ins, Label, LabelRef, Lit, Neg, V, A, S, VCC, M0, EXEC, Reg  # noqa: E402
 
-from attn_gen import (ARG_TQ, ARG_Q, ARG_O, ARG_LDQ, ARG_NTILES, ARG_QBS, ARG_KVSHIFT, ARG_STO, ARG_KBS, ARG_STLD, ARG_SEG, SEG_BYTES, ARG_SIZE,  # noqa: E402,F401
+from attn_gen import (ARG_TQ, ARG_Q, ARG_O, ARG_LDQ, ARG_NTILES, ARG_QBS, ARG_KVSHIFT, ARG_STO, ARG_KBS, ARG_STLD, ARG_SEG, SEG_BYTES, ARG_SIZE, ARG_DBG,  # noqa: E402,F401
                       FLAG_STATE_IN, FLAG_STATE_OUT, QPW, WG_Q, LDS_SLOT, s_q, s_k, s_vt, s_o, s_ldq, s_ldk, s_ldvt, s_ldo, s_nt, s_nseg,
                       s_wid, s_t, s_dma_u, s_seg_left, s_kstep, s_m0base, s_seg, s_hopret, s_flags, s_sto, s_lomask, s_ret, s_floor, s_ntm1,
                       SEG0, s_stml, seg_rec)
@@ -34,6 +34,7 @@ s_delta = S(39)    # byte step of the fragment addresses from tile t to tile t+1
 s_shift = S(5)     # rows at the start of this wave's 128-row tile that belong to an earlier wave (partial last workgroup: the tile is
                    # moved back to end at the last query row, the overlap is computed twice and stored once)
 s_tq = S(6)
+s_rebase = S(7)    # entries of this wave into the re-base block (the forced first one included): f3r_attn_args.dbg_counters
 
 # ---- register map
 LANE = 0           # v0 = lane id (after the prologue); v1 .. v11 temporaries
@@ -210,6 +211,8 @@ class AttnGen2:
         e("s_sub_u32", s_ntm1, s_nt, 1)
         e("s_mov_b32", s_t, 0)
         e("s_mov_b32", s_dma_u, 0)
+        e("s_mov_b32", s_rebase, 0)
+        e("s_nop", 0, comment="(keeps the loop's code placement: hand-written streams are edited in multiples of 8 bytes)")
         # ---- Q fragments straight into the accumulator file: lane (lq, g) of block qb reads Q[row0 + 32 qb + lq][16 ds + 8 g ..+7]
         e("v_mul_lo_u32", V(4), V(2), s_ldq)
         e("v_lshlrev_b32", V(8), 4, V(3))
@@ -591,6 +594,7 @@ class AttnGen2:
         e = self.e
         e_nxt = 1 - e_cur
         self.lab(f"RARE_{e_cur}")
+        e("s_add_u32", s_rebase, s_rebase, 1)
         e("s_nop", 15)
         e("s_nop", 15, comment="every MFMA in flight has written back")
         T = lambda i: V(1 + i)  # noqa: E731  temporaries v1..v11
@@ -641,6 +645,21 @@ class AttnGen2:
         e("s_waitcnt", "vmcnt(0)", comment="re-issued tail tiles of the LDS-DMA stream")
         e("s_nop", 15)
         e("s_nop", 15)
+        # ---- optional counters (f3r_attn_args.dbg_counters; bench.py --weights hot reports how often the lazy reference moved)
+        e("s_load_dwordx2", S(40, 2), S(0, 2), Lit(ARG_DBG))
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_cmp_eq_u64", S(40, 2), 0)
+        e("s_cbranch_scc1", self.L("NO_DBG"))
+        e("v_mov_b32", V(8), 0)
+        e("v_mov_b32", V(9), s_rebase)
+        e("v_mov_b32", V(10), 1)
+        e("v_mov_b32", V(11), s_nt)
+        e("s_mov_b64", EXEC, 1, comment="lane 0")
+        e("global_atomic_add", V(8), V(9), S(40, 2))
+        e("global_atomic_add", V(8), V(10), S(40, 2), offset=4)
+        e("global_atomic_add", V(8), V(11), S(40, 2), offset=8)
+        e("s_mov_b64", EXEC, -1)
+        self.lab("NO_DBG")
         e("s_and_b32", S(40), s_flags, FLAG_STATE_OUT)
         e("s_cmp_lg_u32", S(40), 0)
         e("s_cbranch_scc1", self.L("STATE_OUT"))

@@ -267,7 +267,7 @@ def operand_rw(it):
     if not args:
         return [], []
     no_dst = (op.startswith("s_cmp") or op.startswith("s_cbranch") or op in ("s_branch", "s_waitcnt", "s_nop", "s_barrier",
-              "s_endpgm", "s_setprio") or op.startswith("global_store") or op.startswith("global_load_lds") or
+              "s_endpgm", "s_setprio") or op.startswith("global_store") or op.startswith("global_atomic") or op.startswith("global_load_lds") or
               op.startswith("v_cmp"))
     if no_dst:
         r = []

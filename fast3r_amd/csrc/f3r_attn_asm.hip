@@ -4,6 +4,7 @@
 // decides per call whether a launch goes here (f3r_attn_args.kernel_sel, include/f3r.h).
 #include <cstddef>
 #include <cstring>
+#include <map>
 #include <mutex>
 
 #include "f3r_common.h"
@@ -32,21 +33,24 @@ struct f3r_attn_asm_args {
   uint32_t st_o_ld_b, st_ml_ld_b;
   uint32_t tq, pad;                      // query rows (the last workgroup may be partial: ARG_TQ)
   f3r_attn_asm_seg seg[8];
+  uint32_t* dbg;                         // ARG_DBG: optional counters (f3r_attn_args.dbg_counters)
 };
-static_assert(sizeof(f3r_attn_asm_args) == 304 && offsetof(f3r_attn_asm_args, seg) == 112, "must match ARG_SIZE / ARG_SEG of attn_gen.py");
+static_assert(sizeof(f3r_attn_asm_args) == 312 && offsetof(f3r_attn_asm_args, seg) == 112 && offsetof(f3r_attn_asm_args, dbg) == 304,
+              "must match ARG_SIZE / ARG_SEG / ARG_DBG of attn_gen.py");
 
-constexpr int MAX_DEV = 16;
+// The code object is loaded once per DEVICE (hipModule handles are per device context): the only process-wide state of the library
+// besides the per-thread error string.  Any device index: the table grows on demand.
 struct DevKernels {
   bool tried = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[2] = {nullptr, nullptr};  // F3R_F16, F3R_BF16
 };
-DevKernels g_dev[MAX_DEV];
+std::map<int, DevKernels> g_dev;
 std::mutex g_mu;
 
 hipFunction_t get_fn(int dtype) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevKernels& d = g_dev[dev];
   if (!d.tried) {
@@ -95,6 +99,9 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
     return false;
   }
   if (a.tq >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
+  // a code object that does not load on this device makes the launch INELIGIBLE (kernel_sel 0 then takes the general HIP kernel,
+  // kernel_sel 2 reports why) instead of failing every fusion-attention call of the process
+  if (get_fn(a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }
 
@@ -122,6 +129,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   k.st_o_ld_b = (uint32_t)a.n_heads * 256u;
   k.st_ml_ld_b = (uint32_t)a.n_heads * 16u;
   k.tq = (uint32_t)a.tq;
+  k.dbg = a.dbg_counters;
   for (int s = 0; s < a.n_seg; ++s) {
     if (a.seg_len[s] == 0) continue;
     f3r_attn_asm_seg& g = k.seg[k.n_seg++];

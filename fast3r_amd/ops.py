@@ -17,6 +17,9 @@ ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F
 # Optional per-launch timing of the attention kernel (bench.py's live roofline): when set to a list, every
 # f3r_attn_fwd launch is bracketed by events on the launch stream and (start, end, flops) is appended.
 ATTN_TIMER = None
+# Optional device uint32[4] that the hand-scheduled attention kernel adds its counters to (f3r_attn_args.dbg_counters: entries into the
+# re-base block, waves, tiles walked); bench.py --weights hot sets it around the timed steps.
+ATTN_COUNTERS = None
 
 
 def round_up(x: int, m: int) -> int:
@@ -357,6 +360,9 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
             pos = [int(v) for v in seg_pos0]
         for i, v in enumerate(pos):
             a.seg_pos0[i] = v
+    if ATTN_COUNTERS is not None:
+        assert ATTN_COUNTERS.dtype == torch.int32 and ATTN_COUNTERS.numel() >= 4 and ATTN_COUNTERS.device == q.device
+        a.dbg_counters = ptr(ATTN_COUNTERS)
     if state is not None:
         a.st_o, a.st_ml = ptr(state[0]), ptr(state[1])
         a.state_in, a.state_out = int(state_in), int(state_out)

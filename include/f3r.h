@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 300 = 0.3.0, the round-3 ABI (f3r_attn_args.kernel_sel, head_dim field); 200 = round 2 */
+int f3r_version(void);  /* 310 = 0.3.1, round 4 (f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6); 300 = round 3; 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
@@ -237,6 +237,10 @@ typedef struct f3r_attn_args {
      same layouts with head_dim columns per head (q / k / o rows, head_dim V^T planes per head, st_o rows of n_heads * head_dim),
      no causal mask. */
   int32_t head_dim;
+  /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310): device uint32[4], zeroed by the caller; every wave of a launch
+     that takes that kernel adds {entries into the block that moves the softmax reference (the forced first one included), 1, 64-key
+     tiles it walked, 0}.  bench.py --weights hot reports (entries - waves) / waves: how often the lazy reference really moved. */
+  uint32_t* dbg_counters;
 } f3r_attn_args;
 #define F3R_ATTN_ASM_MIN_KEYS 2048
 

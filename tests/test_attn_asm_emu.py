@@ -47,6 +47,18 @@ def test_emulated_second_layout(kw):
     assert err < kw.get("tol", 6e-4)
 
 
+def test_emulated_kernel_counts_its_rebases():
+    """f3r_attn_args.dbg_counters: {entries into the re-base block, waves, tiles walked} summed over waves.  Every wave enters once (the
+    forced first re-base) and at most once per half-tile stage; these logits (std ~2.3) move the reference a few more times."""
+    import emu_attn
+    c = []
+    assert emu_attn.run_case("f16", 4, n_heads=2, wgs=((0, 1, 0),), layout=2, counters=c) < 6e-4
+    assert c[1:3] == [4, 16] and 4 <= c[0] <= 2 * 16, c
+    base = c[0]
+    assert emu_attn.run_case("f16", 4, n_heads=2, wgs=((0, 1, 0),), spike=True, layout=2, counters=c) < 6e-4
+    assert c[1:3] == [4, 16] and c[0] > base, c   # same keys + one spiked key in the last tile: at least one more re-base
+
+
 @pytest.mark.parametrize("kw", [dict(tq=200, wg=(0, 1, 0), tiles=2), dict(tq=1000, wg=(1, 0, 0), tiles=[1, 2], split=True, spike=True),
                                 dict(tq=640, wg=(1, 1, 0), tiles=3, dtype="bf16", tol=5e-3)])
 def test_emulated_partial_last_workgroup(kw):

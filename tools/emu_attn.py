@@ -18,7 +18,7 @@ import attn_gen  # noqa: E402
 from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
 
 
-def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0):
+def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0, dbg=0):
     """segs: [(k address, vt address, tiles)] -> the kernel argument block (byte strides)"""
     nt = sum(t for _, _, t in segs)
     b = struct.pack("<QQIIIIIIQQIIQQQQIIII", q, o, ldq, ldk, ldvt, ldo, nt, len(segs), q_bs, o_bs, kv_shift, flags, st_o, st_ml, k_bs, vt_bs,
@@ -27,14 +27,16 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
     for i in range(8):
         k, vt, t = segs[i] if i < len(segs) else (0, 0, 0)
         b += struct.pack("<QQII", k, vt, t, 0)
+    b += struct.pack("<Q", dbg)
     assert len(b) == attn_gen.ARG_SIZE
     return b
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=1, tq=None):
+             gen_kwargs=None, split_state=False, layout=1, tq=None, counters=None):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
-    rows, so a store past the end raises in the emulator's memory model)"""
+    rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
+    {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2)"""
     rng = np.random.default_rng(seed)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
     tq, tk = (512 * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
@@ -68,7 +70,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     a_o = mem.alloc(o)
     st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
     st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
-    common = dict(q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
+    a_dbg = mem.alloc(np.zeros(4, np.uint32)) if counters is not None else 0
+    common = dict(dbg=a_dbg, q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
                   st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq)
     launches = []
     if split_state:
@@ -106,6 +109,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         worst = max(worst, err)
         print(f"wg {wg}: {steps} instructions, rel-L2 {err:.3e}, max abs {np.abs(got - ref).max():.3e}, nan {np.isnan(got).sum()}")
+    if counters is not None:
+        counters[:] = [int(x) for x in mem.get(a_dbg, np.uint32, (4,))]
     return worst
 
 

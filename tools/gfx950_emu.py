@@ -295,6 +295,9 @@ class Wave:
             self.scc = int(r != 0)
             self.wrs(a[0], r)
             return
+        if op == "s_cmp_eq_u64":
+            self.scc = int(self.rds64(a[0]) == self.rds64(a[1]))
+            return
         if op.startswith("s_cmp_"):
             x, y = self.rds(a[0]), self.rds(a[1])
             self.scc = int({"s_cmp_lt_u32": x < y, "s_cmp_eq_u32": x == y, "s_cmp_ge_u32": x >= y, "s_cmp_gt_u32": x > y,
@@ -489,6 +492,17 @@ class Wave:
             for lane in range(64):
                 if (self.exec >> lane) & 1:
                     mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
+            self.vm.append(lambda: None)
+            return
+        if op == "global_atomic_add":
+            voff, src, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            vals = self.rd(src)
+            for lane in range(64):
+                if (self.exec >> lane) & 1:
+                    cur = mem.read(base + off[lane], 4).view(np.uint32)[0]
+                    mem.write(base + off[lane], np.array([(int(cur) + int(vals[lane])) & 0xFFFFFFFF], np.uint32).view(np.uint8))
             self.vm.append(lambda: None)
             return
         if op == "global_store_dwordx2":

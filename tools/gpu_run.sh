@@ -1,0 +1,34 @@
+#!/bin/bash
+# One parametrised script for every gpurun call of a round (replaces the one-shot tools/gpu_r2_*.sh / gpu_r3_*.sh of earlier rounds):
+#     gpurun -- 'bash tools/gpu_run.sh STEP [STEP ...]'
+# Each step writes its logs under gpurun_out/<step>/; summaries worth judging are copied to profiles/ by hand afterwards.
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for step in "$@"; do
+  d=gpurun_out/$step; mkdir -p $d
+  t0=$(date +%s)
+  case $step in
+    depth)      # parity at depth + GEMM roles at N = 320 shapes (tests/test_depth_parity_gpu.py)
+      timeout 1500 python -m pytest tests/test_depth_parity_gpu.py -q -rA -s -p no:cacheprovider 2>&1 | tail -120 > $d/pytest.log; grep -E "parity|passed|failed|FAILED|Error" $d/pytest.log | tail -40 ;;
+    gputests)   # the whole GPU suite + smoke
+      timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;
+    hot100)     # N = 100 on the hot weights: views/s, attention frac, re-base rate, parity vs the exact mode -- and the default weights beside it
+      timeout 900 python bench.py --views 100 --weights hot --steps 3 --warmup 1 --no-alt --no-cpu-baseline --parity-exact > $d/bench_n100_hot.json 2> $d/hot.err; tail -c 1500 $d/bench_n100_hot.json
+      timeout 900 python bench.py --views 100 --steps 3 --warmup 1 --no-alt --no-cpu-baseline --no-hot > $d/bench_n100_default.json 2> $d/def.err; tail -c 600 $d/bench_n100_default.json ;;
+    bench320)   # the default line (N = 320, fp16 / high) with its hot-weights object, short
+      timeout 1200 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline > $d/bench_n320.json 2> $d/err.log; tail -c 2500 $d/bench_n320.json ;;
+    benchfull)  # what the driver runs
+      timeout 1500 python bench.py > $d/bench_default.json 2> $d/err.log; tail -c 3000 $d/bench_default.json ;;
+    gemmref)    # the transformer GEMM roles at N = 320 beside the vendor library
+      timeout 900 python tools/kernel_bench.py --what gemmref --views ${GEMM_VIEWS:-320} --sels ${GEMM_SELS:-2} > $d/gemmref.jsonl 2> $d/err.log; cat $d/gemmref.jsonl | cut -c1-260 ;;
+    gemmpmc)    # rocprofv3 PMC over the GEMM micro-benchmark
+      timeout 900 bash tools/pmc_gemm.sh > $d/pmc.log 2>&1; tail -30 $d/pmc.log; cp gpurun_out/pmcg/gemm_pmc.json $d/ 2>/dev/null ;;
+    prof320)    # rocprofv3 kernel stats of the default bench command (3 forwards)
+      ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$d/prof --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-parity > $OLDPWD/$d/bench.json 2> $OLDPWD/$d/err.log )
+      f=$(ls $d/prof/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $d/kernel_stats.csv && head -12 $d/kernel_stats.csv | cut -c1-200
+      find $d/prof -name "*kernel_trace.csv" -delete ;;
+    *) echo "unknown step $step" ;;
+  esac
+  echo "== $step: $(( $(date +%s) - t0 )) s"
+done

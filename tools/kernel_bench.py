@@ -163,7 +163,8 @@ def bench_attn_encoder(dt, views, variants, H=16):
     lab_lib().f3r_attn_set_variant(-1)
 
 
-SEL_NAME = {1: "128-tile", 2: "256-tile persistent", 3: "256-tile lock-step", 4: "256x128-tile", 5: "256-tile one tile per workgroup"}
+SEL_NAME = {0: "automatic", 1: "128-tile", 2: "256-tile persistent", 3: "256-tile lock-step", 4: "256x128-tile", 5: "256-tile one tile per workgroup",
+            6: "hand-scheduled (asm)"}
 
 
 def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
@@ -192,6 +193,19 @@ def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3)
         print(json.dumps({"kernel": "gemm", "name": name, "variant": SEL_NAME[sel], "split": split, "dtype": str(dt).split(".")[-1], "M": M, "N": N, "K": K,
                           "ms": round(ms, 3), "tflops_algorithmic": round(2.0 * M * N * K / ms / 1e9, 1),
                           "tflops_mfma": round(2.0 * M * N * K * mult / ms / 1e9, 1)}), flush=True)
+
+
+def bench_library_matmul(dt, M, N, K, name):
+    """A KNOWN-GOOD reference on the same box and the same random data (cdna_hip_programming.md rule 10 / 25): torch.matmul, i.e. the vendor
+    library (hipBLASLt / rocBLAS), plain A W^T -> lowp, no epilogue.  Not a product path: a yardstick for what the chip gives this shape."""
+    a = torch.randn((M, K), device=DEV).to(dt)
+    w = (torch.randn((N, K), device=DEV) * K ** -0.5).to(dt)
+    out = torch.empty((M, N), dtype=dt, device=DEV)
+    f = lambda: torch.matmul(a, w.t(), out=out)  # noqa: E731
+    f()
+    ms = sorted(time_ms(f, rounds=3, inner=3)[0] for _ in range(3))[1]
+    print(json.dumps({"kernel": "library matmul (torch.matmul -> hipBLASLt/rocBLAS)", "name": name, "dtype": str(dt).split(".")[-1], "M": M, "N": N, "K": K,
+                      "ms": round(ms, 3), "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
 
 
 LAB_BITS = {0: "lab baseline (staggered)", 1: "no LDS-DMA in loop", 2: "no fragment reads", 3: "no DMA, no reads (MFMA + barriers)", 4: "no MFMA",
@@ -460,6 +474,20 @@ if __name__ == "__main__":
         for nv in [int(v) for v in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):
                 bench_attn_product({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv)
+        sys.exit(0)
+    if args.what == "gemmref":  # the transformer's GEMM roles at N = 320 beside the vendor library on the same data
+        sels = tuple(int(x) for x in args.sels.split(","))
+        for dt in (torch.float16, torch.bfloat16):
+            for M in [int(v) * 1024 for v in args.views.split(",")]:
+                for (n, k, nm, kw) in ((1024, 1024, "proj+res", dict(res=True)), (4096, 1024, "fc1+gelu", dict(act="gelu", out="lp")),
+                                       (1024, 4096, "fc2+res", dict(res=True)), (4096, 1024, "fc1 plain lp", dict(out="lp"))):
+                    bench_gemm(dt, M, n, k, f"{nm} M={M}", sels=sels, **kw)
+                    bench_library_matmul(dt, M, n, k, f"{nm} M={M}")
+                bench_qkv(dt, M, 1024, M, sels=sels)
+                bench_library_matmul(dt, M, 3072, 1024, f"qkv M={M}")
+        for M in [int(v) * 1024 for v in args.views.split(",")]:
+            bench_gemm(torch.float16, M, 4096, 1024, f"fc1+gelu w2 M={M}", act="gelu", out="lp", split="w2", sels=sels)
+            bench_gemm(torch.float16, M, 1024, 4096, f"fc2+res w2 M={M}", res=True, split="w2", sels=sels)
         sys.exit(0)
     if args.what == "gemmpersist":  # persistent grid (kernel_sel 2) next to one tile per workgroup (5) on the model's shapes
         for dt in (torch.bfloat16, torch.float16):
