@@ -96,6 +96,10 @@ bool f3r_gemm256_preferred(const f3r_gemm_args& a);  // ... and is expected to b
 int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger);
 int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_LAB builds only (tools/lab)
 
+// f3r_gemm_asm.hip: the hand-scheduled GEMM kernels (csrc/asm/gemm_gen.py) behind f3r_gemm
+bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why);
+int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream);
+
 // f3r_attn_asm.hip: the hand-scheduled attention kernel (csrc/asm/attn_gen.py) behind f3r_attn_fwd
 bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why);
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream);

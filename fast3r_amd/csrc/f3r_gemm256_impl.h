@@ -28,6 +28,8 @@
 // Operand roles, epilogues, the split-precision K segments and the LDS swizzle are those of f3r_gemm.hip; the implicit-GEMM 3x3
 // convolution stages its operand by LDS-DMA too: out-of-image taps read a 16-byte zero line instead of being predicated.
 #pragma once
+#include <atomic>
+
 #include "f3r_common.h"
 #include "f3r_gemm_epi.h"
 
@@ -46,13 +48,19 @@ template <int NH> struct TileCfg {
   static constexpr int LDS_BYTES = NBUF * BUF * 2;   // 131072 / 147456
 };
 
-inline int f3r_num_cus() {  // CUs of the current device, rounded down to a multiple of 8 (XCDs)
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
-    n = cu / 8 * 8;
+inline int f3r_num_cus() {  // CUs of the CURRENT device, rounded down to a multiple of 8 (XCDs); cached per device index
+  constexpr int MAXD = 64;
+  static std::atomic<int> cache[MAXD];  // zero-initialised; a racing first call computes the same value twice
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= 0 && dev < MAXD) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c) return c;
   }
+  int cu = 0;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+  const int n = cu / 8 * 8;
+  if (dev >= 0 && dev < MAXD) cache[dev].store(n, std::memory_order_relaxed);
   return n;
 }
 

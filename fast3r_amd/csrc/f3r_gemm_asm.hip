@@ -1,0 +1,129 @@
+// Host side of the hand-scheduled GEMM kernels: the code object assembled from csrc/asm/gemm_gen.py is embedded in the library
+// (obj/f3r_gemm_asm_blob.cpp, written by build.sh), loaded once per device with hipModuleLoadData and launched with hipModuleLaunchKernel
+// on the caller's stream.  f3r_gemm (f3r_gemm.hip) decides per call whether a launch goes here (f3r_gemm_args.kernel_sel, include/f3r.h).
+#include <cstddef>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "f3r_common.h"
+
+extern "C" const unsigned char f3r_gemm_asm_hsaco[];
+extern "C" const unsigned int f3r_gemm_asm_hsaco_len;
+
+namespace {
+
+// kernel argument block: the ARG_* offsets of csrc/asm/gemm_gen.py
+struct f3r_gemm_asm_args {
+  const void* A;
+  const void* W;
+  const float* bias;
+  const float* res;
+  void* out;
+  uint32_t lda_b, ldw_b, ldr_b, ldo_b;  // row strides in bytes
+  uint32_t nk, nk1;                     // K-tiles over all K segments / per segment
+  uint32_t xq, xr, pg, pg_magic, gm_shift, act, pad0, pad1;  // tile map (gemm_gen.pack_args) + activation
+};
+static_assert(sizeof(f3r_gemm_asm_args) == 96 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64,
+              "must match ARG_* of gemm_gen.py");
+
+enum { ROLE_F32 = 0, ROLE_LP = 1 };
+struct DevKernels {
+  bool tried = false;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [role][F3R_F16 | F3R_BF16]
+};
+std::map<int, DevKernels> g_dev;  // one code-object handle per device (see f3r_attn_asm.hip)
+std::mutex g_mu;
+
+hipFunction_t get_fn(int role, int dtype) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  DevKernels& d = g_dev[dev];
+  if (!d.tried) {
+    d.tried = true;
+    if (hipModuleLoadData(&d.mod, f3r_gemm_asm_hsaco) == hipSuccess) {
+      static const char* names[2][2] = {{"f3r_gemm_asm_f32_f16", "f3r_gemm_asm_f32_bf16"}, {"f3r_gemm_asm_lp_f16", "f3r_gemm_asm_lp_bf16"}};
+      for (int r = 0; r < 2; ++r)
+        for (int t = 0; t < 2; ++t)
+          if (hipModuleGetFunction(&d.fn[r][t], d.mod, names[r][t]) != hipSuccess) d.fn[r][t] = nullptr;
+    }
+    (void)hipGetLastError();
+  }
+  return d.fn[role][dtype];
+}
+
+int role_of(const f3r_gemm_args& a) { return a.out_f32 ? ROLE_F32 : ROLE_LP; }
+
+}  // namespace
+
+// Can the hand-scheduled kernel take this (already validated) launch?  *why names the first obstacle.
+bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
+  *why = "";
+  if (a.a_mode != F3R_A_PLAIN) { *why = "not a plain GEMM operand (convolution)"; return false; }
+  if (a.epi != F3R_EPI_GENERIC) { *why = "QKV / ConvT epilogue"; return false; }
+  if (a.split != F3R_SPLIT_NONE && a.split != F3R_SPLIT_W2) { *why = "X3 split"; return false; }
+  if (a.M <= 0 || a.M % 256 != 0 || a.N % 256 != 0) { *why = "M or N not a multiple of 256"; return false; }
+  const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
+  if (a.K != Kpad1 || Kpad1 % 64 != 0) { *why = "K is not the padded depth (a K tail cannot be zero-filled by LDS-DMA)"; return false; }
+  if (a.rowadd || a.res_lp || a.res_lp2 || a.out_lp_lo || a.out_relu || a.out_relu_lo) { *why = "additive rows / lowp residuals / second outputs"; return false; }
+  if (a.out_f32 && a.out_lp) { *why = "both an fp32 and a lowp output"; return false; }
+  if (a.out_f32) {
+    if (a.act != F3R_ACT_NONE) { *why = "activation on the fp32 role"; return false; }
+    if ((a.ldo_f32 * 4) % 16 != 0 || (a.res_f32 && (a.ldr_f32 * 4) % 16 != 0)) { *why = "fp32 row strides not multiples of 16 bytes"; return false; }
+    if ((int64_t)256 * a.ldo_f32 * 4 >= (1ll << 32) || (a.res_f32 && (int64_t)256 * a.ldr_f32 * 4 >= (1ll << 32))) { *why = "fp32 row strides too large"; return false; }
+  } else {
+    if (a.res_f32) { *why = "fp32 residual with a lowp output"; return false; }
+    if ((((uintptr_t)a.out_lp) & 15) != 0 || (a.ldo_lp * 2) % 16 != 0) { *why = "lowp output not 16-byte aligned"; return false; }
+    if ((int64_t)256 * a.ldo_lp * 2 >= (1ll << 32)) { *why = "lowp row stride too large"; return false; }
+  }
+  if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 2 >= (1ll << 32)) { *why = "operand row strides too large for 32-bit lane offsets"; return false; }
+  const int64_t tiles = (a.M / 256) * (a.N / 256);
+  if (tiles >= (1ll << 24)) { *why = "grid too large"; return false; }
+  if (get_fn(role_of(a), a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  return true;
+}
+
+int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
+  const int role = role_of(a);
+  hipFunction_t fn = get_fn(role, a.dtype);
+  if (!fn) {
+    f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
+    return F3R_ERR_LAUNCH;
+  }
+  f3r_gemm_asm_args k;
+  memset(&k, 0, sizeof(k));
+  const int planes = a.split ? 2 : 1;
+  const int Kpad1 = a.Kpad / planes;
+  const uint32_t ntm = (uint32_t)(a.M / 256), ntn = (uint32_t)(a.N / 256);
+  const uint32_t n_wg = ntm * ntn;
+  k.A = a.A;
+  k.W = a.W;
+  k.bias = a.bias;
+  k.res = role == ROLE_F32 ? a.res_f32 : nullptr;
+  k.out = role == ROLE_F32 ? (void*)a.out_f32 : a.out_lp;
+  k.lda_b = (uint32_t)(a.lda * 2);
+  k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
+  k.ldr_b = (uint32_t)(a.ldr_f32 * 4);
+  k.ldo_b = role == ROLE_F32 ? (uint32_t)(a.ldo_f32 * 4) : (uint32_t)(a.ldo_lp * 2);
+  k.nk1 = (uint32_t)(Kpad1 / 64);
+  k.nk = k.nk1 * (uint32_t)planes;
+  // tile map (gemm_gen.pack_args): XCD-contiguous runs, groups of gm m-tiles x all n-tiles, gm = the largest power of two <= 8 dividing ntm
+  uint32_t gsh = 3;
+  while (ntm % (1u << gsh)) --gsh;
+  k.xq = n_wg / 8;
+  k.xr = n_wg % 8;
+  k.pg = (1u << gsh) * ntn;
+  k.pg_magic = k.pg > 1 ? (uint32_t)(((1ull << 32) + k.pg - 1) / k.pg) : 0;
+  k.gm_shift = gsh;
+  k.act = (uint32_t)a.act;
+  size_t size = sizeof(k);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  hipError_t e = hipModuleLaunchKernel(fn, n_wg, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
+  if (e != hipSuccess) {
+    f3r_set_error("f3r_gemm: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
+    return F3R_ERR_LAUNCH;
+  }
+  return f3r_check_launch("f3r_gemm(asm)");
+}

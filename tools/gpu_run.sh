@@ -10,6 +10,32 @@ for step in "$@"; do
   case $step in
     depth)      # parity at depth + GEMM roles at N = 320 shapes (tests/test_depth_parity_gpu.py)
       timeout 1500 python -m pytest tests/test_depth_parity_gpu.py -q -rA -s -p no:cacheprovider 2>&1 | tail -120 > $d/pytest.log; grep -E "parity|passed|failed|FAILED|Error" $d/pytest.log | tail -40 ;;
+    gemmasm)    # parity of the hand-scheduled GEMM kernels + the role tests at N = 320 shapes (automatic selection takes them there)
+      timeout 900 python -m pytest tests/test_gemm_asm_gpu.py tests/test_depth_parity_gpu.py -q -rA -p no:cacheprovider -k "gemm_asm or role" 2>&1 | tail -60 > $d/pytest.log; grep -E "passed|failed|FAILED|Error|error" $d/pytest.log | tail -30 ;;
+    gemmlab)    # variants of the hand-scheduled GEMM (tools/gemm_lab.py --build on the CPU box first) + a PMC pass of the product variant
+      timeout 600 python tools/gemm_lab.py --run ${GEMMLAB_ARGS:-} > $d/gemm_lab.jsonl 2> $d/err.log; cat $d/gemm_lab.jsonl | cut -c1-250; tail -3 $d/err.log
+      if [ -z "${NO_PMC:-}" ]; then
+      ( cd /tmp; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $OLDPWD/$d/pmc --output-format csv -- python $OLDPWD/tools/gemm_lab.py --run --variants product --rounds 2 --shapes ${PMC_SHAPES:-lp:327680:4096:4096,lp:327680:4096:1024,f32:327680:1024:4096} > $OLDPWD/$d/pmc.log 2>&1 )
+      python - $d <<'PY'
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+fs = glob.glob(f"{d}/pmc/*/*counter_collection.csv")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in fs:
+    for r in csv.DictReader(open(f)):
+        if "f3r_gemm_asm" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"] + " grid=" + r.get("Grid_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, c in acc.items():
+    v = {n: sum(x) / len(x) for n, x in c.items()}
+    if v.get("GRBM_GUI_ACTIVE"):
+        v["mfma_util_cycles"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+    out[k] = v
+    print(k, {n: (round(x, 4) if x < 100 else int(x)) for n, x in v.items()})
+json.dump(out, open(f"{d}/gemm_asm_pmc.json", "w"), indent=1)
+PY
+      find $d/pmc -name "*kernel_trace.csv" -delete
+      fi ;;
     gputests)   # the whole GPU suite + smoke
       timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;
