@@ -22,7 +22,8 @@ struct f3r_gemm_asm_args {
   void* out;
   uint32_t lda_b, ldw_b, ldr_b, ldo_b;  // row strides in bytes
   uint32_t nk, nk1;                     // K-tiles over all K segments / per segment
-  uint32_t xq, xr, pg, pg_magic, gm_shift, act, pad0, pad1;  // tile map (gemm_gen.pack_args) + activation
+  uint32_t xq, xr, pg, pg_magic, gm_shift, act, grid, n_wg;  // tile map (gemm_gen.pack_args), activation, persistent grid: workgroup b
+                                                             // computes output tiles b, b + grid, b + 2 grid, ...
 };
 static_assert(sizeof(f3r_gemm_asm_args) == 96 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64,
               "must match ARG_* of gemm_gen.py");
@@ -67,6 +68,7 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
   if (a.M <= 0 || a.M % 256 != 0 || a.N % 256 != 0) { *why = "M or N not a multiple of 256"; return false; }
   const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
   if (a.K != Kpad1 || Kpad1 % 64 != 0) { *why = "K is not the padded depth (a K tail cannot be zero-filled by LDS-DMA)"; return false; }
+  if ((a.Kpad / 64) < 4) { *why = "fewer than 4 K-tiles (the operand streams run three K-tiles ahead)"; return false; }
   if (a.rowadd || a.res_lp || a.res_lp2 || a.out_lp_lo || a.out_relu || a.out_relu_lo) { *why = "additive rows / lowp residuals / second outputs"; return false; }
   if (a.out_f32 && a.out_lp) { *why = "both an fp32 and a lowp output"; return false; }
   if (a.out_f32) {
@@ -118,9 +120,16 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.pg_magic = k.pg > 1 ? (uint32_t)(((1ull << 32) + k.pg - 1) / k.pg) : 0;
   k.gm_shift = gsh;
   k.act = (uint32_t)a.act;
+  // persistent grid: one workgroup per CU (160 KiB of LDS, 512 registers per lane: one resident workgroup), a multiple of 8 so that a
+  // workgroup's tiles stay on its XCD's contiguous run
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  cus = cus / 8 * 8;
+  k.n_wg = n_wg;
+  k.grid = n_wg < (uint32_t)cus ? n_wg : (uint32_t)cus;
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(fn, n_wg, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
+  hipError_t e = hipModuleLaunchKernel(fn, k.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
     f3r_set_error("f3r_gemm: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
     return F3R_ERR_LAUNCH;

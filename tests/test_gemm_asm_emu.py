@@ -14,15 +14,26 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "fast3r_amd", "csrc", "asm"))
 
 
-@pytest.mark.parametrize("nk1", [1, 2, 3, 5, 6, 11])
+@pytest.mark.parametrize("nk1", [4, 5, 6, 7, 8, 11])
 def test_emulated_f32_role_over_the_ring(nk1):
-    """K-tile counts that stop the five-slot ring in every one of its unrolled copies (and before it wraps once): x += A W^T + b in place"""
+    """K-tile counts that end an output tile in every one of the five unrolled copies of the ring: x += A W^T + b in place"""
     import emu_gemm
     assert emu_gemm.run_case("f16", "f32", nk1=nk1) < 1e-6
 
 
-@pytest.mark.parametrize("kw", [dict(nk1=3, segs=2), dict(nk1=4, segs=2, res=False), dict(nk1=2, bias=False), dict(nk1=2, bias=False, res=False),
-                                dict(nk1=2, dtype="bf16"), dict(nk1=1, dtype="bf16", segs=2), dict(nk1=2, lda_pad=64)])
+@pytest.mark.parametrize("kw", [dict(nk1=4, ntm=3, grid=1), dict(nk1=5, ntm=3, grid=1), dict(nk1=6, ntm=3, grid=1), dict(nk1=7, ntm=3, grid=1),
+                                dict(nk1=8, ntm=3, grid=1), dict(nk1=4, ntm=2, ntn=3, grid=2), dict(nk1=2, segs=2, ntm=2, ntn=2, grid=1),
+                                dict(nk1=5, ntm=3, grid=1, bias=False), dict(nk1=5, ntm=3, grid=1, res=False)])
+def test_emulated_persistent_workgroups(kw):
+    """fewer workgroups than output tiles: a workgroup walks tiles b, b + grid, ...; the operand streams cross into the next tile's panels
+    up to three K-tiles ahead of the MFMAs (at every phase of the ring), the accumulators are written out and re-initialised with the next
+    tile's bias between two k-steps, the last tile ends the kernel"""
+    import emu_gemm
+    assert emu_gemm.run_case("f16", "f32", **kw) < 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(nk1=3, segs=2), dict(nk1=4, segs=2, res=False), dict(nk1=4, bias=False), dict(nk1=4, bias=False, res=False),
+                                dict(nk1=4, dtype="bf16"), dict(nk1=2, dtype="bf16", segs=2), dict(nk1=4, lda_pad=64)])
 def test_emulated_f32_role_variants(kw):
     """split-precision weights as K segments (the A stream wraps to k = 0, the W stream runs on into the lo plane), no bias / no residual,
     bf16 operands (three-term bias split by truncation), a padded A row stride"""
@@ -36,7 +47,7 @@ def test_emulated_f32_role_variants(kw):
 def test_emulated_lowp_role(dtype, act, segs, tol):
     """out_lp = act(A W^T + b) with the permuted weight rows (a lane half owns 16 consecutive columns); tolerance = one rounding of the output"""
     import emu_gemm
-    assert emu_gemm.run_case(dtype, "lp", nk1=3, segs=segs, act=act) < tol
+    assert emu_gemm.run_case(dtype, "lp", nk1=3 if segs == 2 else 5, segs=segs, act=act, ntm=2, grid=1) < tol
 
 
 @pytest.mark.parametrize("tiles,wgs", [((2, 2), None), ((3, 2), None), ((5, 1), None), ((12, 3), (0, 7, 8, 13, 35)), ((16, 4), (0, 1, 9, 31, 63))])
@@ -44,7 +55,7 @@ def test_emulated_tile_map(tiles, wgs):
     """several workgroups: every emulated workgroup writes exactly one 256 x 256 tile, no two the same one (the XCD-aware order is a
     bijection), with the right operand panels"""
     import emu_gemm
-    assert emu_gemm.run_case("f16", "f32", ntm=tiles[0], ntn=tiles[1], nk1=1, wgs=wgs) < 1e-6
+    assert emu_gemm.run_case("f16", "f32", ntm=tiles[0], ntn=tiles[1], nk1=4, wgs=wgs, grid=tiles[0] * tiles[1]) < 1e-6
 
 
 def test_tile_map_is_a_bijection_at_the_model_shapes():

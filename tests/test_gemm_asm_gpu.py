@@ -17,7 +17,8 @@ ASM, HIP = 6, 7
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (768, 512, 192), (2048, 1024, 320), (4096, 1024, 1024), (2304, 256, 4096), (1280, 768, 704)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 256, 320), (768, 512, 384), (2048, 1024, 448), (4096, 1024, 1024), (2304, 256, 4096), (1280, 768, 704),
+                                   (70 * 256, 1024, 512), (300 * 256, 256, 576)])  # the last two: more tiles than CUs -> persistent workgroups, uneven tile counts
 def test_gemm_asm_roles(built_lib, dt, M, N, K):
     a, w, bias = rnd((M, K), dt, 3), rnd((N, K), dt, 4, K ** -0.5), torch.randn(N)
     wp = ops.pack_linear_weight(w.float(), dt).to(DEV)
@@ -42,7 +43,7 @@ def test_gemm_asm_roles(built_lib, dt, M, N, K):
         assert_close(y.float(), F.relu(base), lp_tol(dt), f"relu sel={sel}")
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (1024, 1024, 1024), (2048, 512, 448)])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1024, 1024, 1024), (2048, 512, 448), (80 * 256, 1024, 256)])
 def test_gemm_asm_split_weights(built_lib, M, N, K):
     """W2: A W_hi + A W_lo as two K segments of the same loop -- fp32-class weights (vs fp64 on the UNROUNDED weight)"""
     dt = torch.float16
@@ -81,16 +82,18 @@ def test_gemm_asm_strided_operand_and_outputs(built_lib):
 
 def test_gemm_asm_refuses_what_it_cannot_take(built_lib):
     dt = torch.float16
-    a = rnd((300, 128), dt, 1).to(DEV)                                       # M not a multiple of 256
-    wp = ops.pack_linear_weight(rnd((256, 128), dt, 2).float(), dt).to(DEV)
+    a = rnd((300, 256), dt, 1).to(DEV)                                       # M not a multiple of 256
+    wp = ops.pack_linear_weight(rnd((256, 256), dt, 2).float(), dt).to(DEV)
     with pytest.raises((ValueError, RuntimeError)):
         ops.gemm(a, wp, want_f32=True, kernel_sel=ASM)
-    a = rnd((256, 128), dt, 1).to(DEV)
+    a = rnd((256, 256), dt, 1).to(DEV)
     with pytest.raises((ValueError, RuntimeError)):
         ops.gemm(a, wp, want_f32=True, want_lp=True, kernel_sel=ASM)          # two outputs
+    with pytest.raises((ValueError, RuntimeError)):                          # fewer than 4 K-tiles
+        ops.gemm(rnd((256, 128), dt, 1).to(DEV), ops.pack_linear_weight(rnd((256, 128), dt, 2).float(), dt).to(DEV), want_f32=True, kernel_sel=ASM)
     with pytest.raises((ValueError, RuntimeError)):
         ops.gemm(a, wp, act="gelu", want_f32=True, kernel_sel=ASM)            # activation on the fp32 role
-    f32, _ = ops.gemm(rnd((300, 128), dt, 1).to(DEV), wp, want_f32=True)      # automatic: the compiler-scheduled kernels take it
+    f32, _ = ops.gemm(rnd((300, 256), dt, 1).to(DEV), wp, want_f32=True)      # automatic: the compiler-scheduled kernels take it
     assert f32.shape == (300, 256)
 
 

@@ -22,7 +22,7 @@ def gelu64(x):
     return 0.5 * x * (1.0 + np.vectorize(math.erf)(x / math.sqrt(2.0)))
 
 
-def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=2, segs=1, act="none", bias=True, res=True, wgs=None, seed=0, lda_pad=0, gen_kwargs=None):
+def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=4, segs=1, act="none", bias=True, res=True, wgs=None, seed=0, lda_pad=0, gen_kwargs=None, grid=None):
     """one launch of (ntm x ntn) tiles, K = 64 * nk1 per segment, `segs` K segments (2 = split weights hi | lo planes in one W row); emulates the
     workgroups `wgs` (default: all) and returns the worst max-abs error relative to the output scale"""
     rng = np.random.default_rng(seed)
@@ -46,14 +46,16 @@ def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=2, segs=1, act="none", b
     else:
         a_o = mem.alloc(np.full((M, N), 0x7E00, np.uint16))
         a_r = 0
-    karg, n_wg = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, lda * 2, K1 * segs * 2, N * 4, N * esize, nk1 * segs, nk1, ntm, ntn, ACTS[act])
+    karg, grid = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, lda * 2, K1 * segs * 2, N * 4, N * esize, nk1 * segs, nk1, ntm, ntn, ACTS[act], grid=grid)
     g = gemm_gen.GemmGen(dtype, role, **(gen_kwargs or {}))
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
     a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
     steps = 0
-    for wg in (range(n_wg) if wgs is None else wgs):
+    n_tiles = 0
+    for wg in (range(grid) if wgs is None else wgs):
+        n_tiles += len(range(wg, ntm * ntn, grid))
         steps += Workgroup(prog, mem, a_arg, (wg, 0, 0), 4, g.lds_bytes, dtype).run()
     af = half_to_f32(ah, dtype).astype(np.float64)[:, :K1]
     wf = half_to_f32(wh, dtype).astype(np.float64)
@@ -75,7 +77,7 @@ def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=2, segs=1, act="none", b
             done = mem.get(a_o, np.uint16, (M, N)) != 0x7E00
         elif res:
             done = got != x.astype(np.float64)
-        assert done.sum() == 65536 * len(list(wgs)), ("tiles written", int(done.sum()))
+        assert done.sum() == 65536 * n_tiles, ("tiles written", int(done.sum()), n_tiles)
         got, ref = got[done], ref[done]
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max()) / scale
@@ -88,7 +90,8 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--role", default="f32")
     ap.add_argument("--tiles", default="1x1")
-    ap.add_argument("--nk1", type=int, default=2)
+    ap.add_argument("--nk1", type=int, default=4)
+    ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--segs", type=int, default=1)
     ap.add_argument("--act", default="none")
     ap.add_argument("--no-bias", action="store_true")
@@ -96,4 +99,4 @@ if __name__ == "__main__":
     ap.add_argument("--wgs", default="")
     a = ap.parse_args()
     tm, tn = (int(v) for v in a.tiles.split("x"))
-    run_case(a.dtype, a.role, tm, tn, a.nk1, a.segs, a.act, not a.no_bias, not a.no_res, wgs=[int(v) for v in a.wgs.split(",")] if a.wgs else None)
+    run_case(a.dtype, a.role, tm, tn, a.nk1, a.segs, a.act, not a.no_bias, not a.no_res, wgs=[int(v) for v in a.wgs.split(",")] if a.wgs else None, grid=a.grid)
