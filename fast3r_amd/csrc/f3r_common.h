@@ -99,6 +99,8 @@ int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_
 // f3r_gemm_asm.hip: the hand-scheduled GEMM kernels (csrc/asm/gemm_gen.py) behind f3r_gemm
 bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why);
 int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream);
+bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why);  // the QKV projection without rotary embedding, as two launches
+int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream);
 
 // f3r_attn_asm.hip: the hand-scheduled attention kernel (csrc/asm/attn_gen.py) behind f3r_attn_fwd
 bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why);

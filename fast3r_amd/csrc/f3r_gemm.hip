@@ -372,7 +372,9 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   // it is built for (the transformer's big linear layers: >= F3R_GEMM_ASM_MIN_TILES full 256 x 256 tiles); 7 = automatic WITHOUT it
   if (a.kernel_sel == 6 || a.kernel_sel == 0) {
     const char* why = "";
-    const bool ok = f3r_gemm_asm_eligible(a, &why);
+    if (a.epi == F3R_EPI_QKV && f3r_gemm_asm_qkv_eligible(a, &why) && (a.kernel_sel == 6 || (a.M / 256) * (a.N / 256) >= F3R_GEMM_ASM_MIN_TILES))
+      return f3r_gemm_asm_qkv_launch(a, s);
+    const bool ok = a.epi != F3R_EPI_QKV && f3r_gemm_asm_eligible(a, &why);
     if (a.kernel_sel == 6 && !ok) {
       f3r_set_error("f3r_gemm: kernel_sel 6 (hand-scheduled kernel) but the launch is not eligible: %s", why);
       return F3R_ERR_UNSUPPORTED;

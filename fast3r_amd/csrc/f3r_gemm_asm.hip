@@ -24,9 +24,14 @@ struct f3r_gemm_asm_args {
   uint32_t nk, nk1;                     // K-tiles over all K segments / per segment
   uint32_t xq, xr, pg, pg_magic, gm_shift, act, grid, n_wg;  // tile map (gemm_gen.pack_args), activation, persistent grid: workgroup b
                                                              // computes output tiles b, b + grid, b + 2 grid, ...
+  int64_t seg_stride;                   // ARG_SEG: output segments along n (bytes from one segment's buffer to the next)
+  uint32_t tps, tps_magic;              // n tiles per segment, ceil(2^32 / tps)
+  float scale;                          // ACT_SCALE: segment 0 is multiplied by it
+  uint32_t flags, nk1_w, pad;           // FLAG_BIAS_ON_M = 1; wrap period of the W stream
 };
-static_assert(sizeof(f3r_gemm_asm_args) == 96 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64,
-              "must match ARG_* of gemm_gen.py");
+static_assert(sizeof(f3r_gemm_asm_args) == 128 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
+              offsetof(f3r_gemm_asm_args, seg_stride) == 96 && offsetof(f3r_gemm_asm_args, nk1_w) == 120, "must match ARG_* of gemm_gen.py");
+enum { ACT_SCALE = 3, FLAG_BIAS_ON_M = 1 };
 
 enum { ROLE_F32 = 0, ROLE_LP = 1 };
 struct DevKernels {
@@ -87,30 +92,12 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
   return true;
 }
 
-int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
-  const int role = role_of(a);
-  hipFunction_t fn = get_fn(role, a.dtype);
-  if (!fn) {
-    f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
-    return F3R_ERR_LAUNCH;
-  }
-  f3r_gemm_asm_args k;
-  memset(&k, 0, sizeof(k));
-  const int planes = a.split ? 2 : 1;
-  const int Kpad1 = a.Kpad / planes;
-  const uint32_t ntm = (uint32_t)(a.M / 256), ntn = (uint32_t)(a.N / 256);
+namespace {
+
+// fills the tile map / persistent grid and launches one kernel: M x N outputs in 256 x 256 tiles
+int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, hipStream_t stream) {
+  const uint32_t ntm = (uint32_t)(M / 256), ntn = (uint32_t)(N / 256);
   const uint32_t n_wg = ntm * ntn;
-  k.A = a.A;
-  k.W = a.W;
-  k.bias = a.bias;
-  k.res = role == ROLE_F32 ? a.res_f32 : nullptr;
-  k.out = role == ROLE_F32 ? (void*)a.out_f32 : a.out_lp;
-  k.lda_b = (uint32_t)(a.lda * 2);
-  k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
-  k.ldr_b = (uint32_t)(a.ldr_f32 * 4);
-  k.ldo_b = role == ROLE_F32 ? (uint32_t)(a.ldo_f32 * 4) : (uint32_t)(a.ldo_lp * 2);
-  k.nk1 = (uint32_t)(Kpad1 / 64);
-  k.nk = k.nk1 * (uint32_t)planes;
   // tile map (gemm_gen.pack_args): XCD-contiguous runs, groups of gm m-tiles x all n-tiles, gm = the largest power of two <= 8 dividing ntm
   uint32_t gsh = 3;
   while (ntm % (1u << gsh)) --gsh;
@@ -119,7 +106,8 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.pg = (1u << gsh) * ntn;
   k.pg_magic = k.pg > 1 ? (uint32_t)(((1ull << 32) + k.pg - 1) / k.pg) : 0;
   k.gm_shift = gsh;
-  k.act = (uint32_t)a.act;
+  if (k.tps == 0) k.tps = ntn;
+  k.tps_magic = k.tps > 1 ? (uint32_t)(((1ull << 32) + k.tps - 1) / k.tps) : 0;
   // persistent grid: one workgroup per CU (160 KiB of LDS, 512 registers per lane: one resident workgroup), a multiple of 8 so that a
   // workgroup's tiles stay on its XCD's contiguous run
   int dev = 0, cus = 0;
@@ -135,4 +123,105 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
     return F3R_ERR_LAUNCH;
   }
   return f3r_check_launch("f3r_gemm(asm)");
+}
+
+}  // namespace
+
+int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
+  const int role = role_of(a);
+  hipFunction_t fn = get_fn(role, a.dtype);
+  if (!fn) {
+    f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
+    return F3R_ERR_LAUNCH;
+  }
+  f3r_gemm_asm_args k;
+  memset(&k, 0, sizeof(k));
+  const int planes = a.split ? 2 : 1;
+  const int Kpad1 = a.Kpad / planes;
+  k.A = a.A;
+  k.W = a.W;
+  k.bias = a.bias;
+  k.res = role == ROLE_F32 ? a.res_f32 : nullptr;
+  k.out = role == ROLE_F32 ? (void*)a.out_f32 : a.out_lp;
+  k.lda_b = (uint32_t)(a.lda * 2);
+  k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
+  k.ldr_b = (uint32_t)(a.ldr_f32 * 4);
+  k.ldo_b = role == ROLE_F32 ? (uint32_t)(a.ldo_f32 * 4) : (uint32_t)(a.ldo_lp * 2);
+  k.nk1 = (uint32_t)(Kpad1 / 64);
+  k.nk = k.nk1 * (uint32_t)planes;
+  k.nk1_w = k.nk;  // the weight row holds its planes back to back: that stream never wraps
+  k.act = (uint32_t)a.act;
+  k.scale = 1.0f;
+  return launch_tiles(fn, k, a.M, a.N, stream);
+}
+
+// ---- the QKV projection without rotary embedding (the fusion decoder: blocks.py:138-143 with rope = None) as two launches of the lowp
+// role: q | k columns into their two buffers (output segments; q scaled by q_scale), then V^T = W_v X^T with the operand roles swapped
+// (the kernel's A operand = the v rows of the fused weight incl. their lo plane, its W operand = the activations; bias by output row; one
+// output segment per sequence).  The activations are read twice; the weights once.
+bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why) {
+  *why = "";
+  if (a.epi != F3R_EPI_QKV || a.a_mode != F3R_A_PLAIN) { *why = "not a QKV launch"; return false; }
+  if (a.rope_cos) { *why = "rotary embedding in the epilogue"; return false; }
+  if (a.split != F3R_SPLIT_NONE && a.split != F3R_SPLIT_W2) { *why = "X3 split"; return false; }
+  const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
+  const int Dkv = (a.N - Dq) / 2;
+  if (Dq != Dkv) { *why = "grouped-query widths (q and k segments differ)"; return false; }
+  if (Dq % 256 != 0 || a.M <= 0 || a.M % 256 != 0 || a.seq_len % 256 != 0) { *why = "D, M or seq_len not a multiple of 256"; return false; }
+  const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
+  if (a.K != Kpad1 || Kpad1 % 64 != 0 || a.Kpad / 64 < 4) { *why = "K tail or fewer than 4 K-tiles"; return false; }
+  if ((((uintptr_t)a.q) & 15) || (((uintptr_t)a.k) & 15) || (((uintptr_t)a.vt) & 15) || (a.ldvt * 2) % 16 != 0) { *why = "outputs not 16-byte aligned"; return false; }
+  if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 2 >= (1ll << 32) || (int64_t)256 * a.ldvt * 2 >= (1ll << 32)) { *why = "row strides too large"; return false; }
+  if ((a.M / 256) * (int64_t)(a.N / 256) >= (1ll << 24)) { *why = "grid too large"; return false; }
+  if (get_fn(ROLE_LP, a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  return true;
+}
+
+int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
+  hipFunction_t fn = get_fn(ROLE_LP, a.dtype);
+  if (!fn) {
+    f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
+    return F3R_ERR_LAUNCH;
+  }
+  const int planes = a.split ? 2 : 1;
+  const int Kpad1 = a.Kpad / planes;
+  const int D = a.qkv_dq ? a.qkv_dq : a.N / 3;
+  f3r_gemm_asm_args k;
+  memset(&k, 0, sizeof(k));
+  // launch 1: q | k
+  k.A = a.A;
+  k.W = a.W;
+  k.bias = a.bias;
+  k.out = a.q;
+  k.lda_b = (uint32_t)(a.lda * 2);
+  k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
+  k.ldo_b = (uint32_t)(D * 2);
+  k.nk1 = (uint32_t)(Kpad1 / 64);
+  k.nk = k.nk1 * (uint32_t)planes;
+  k.nk1_w = k.nk;
+  k.act = ACT_SCALE;
+  k.scale = a.q_scale != 0.f ? a.q_scale : 1.0f;
+  k.seg_stride = (int64_t)((const char*)a.k - (const char*)a.q);
+  k.tps = (uint32_t)(D / 256);
+  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream);
+  if (rc != F3R_OK) return rc;
+  // launch 2: V^T[seq][d][t] = W_v X^T
+  f3r_gemm_asm_args v;
+  memset(&v, 0, sizeof(v));
+  v.A = (const char*)a.W + (int64_t)2 * D * a.Kpad * 2;
+  v.W = a.A;
+  v.bias = a.bias ? a.bias + 2 * D : nullptr;
+  v.out = a.vt;
+  v.lda_b = (uint32_t)((int64_t)a.Kpad * 2);
+  v.ldw_b = (uint32_t)(a.lda * 2);
+  v.ldo_b = (uint32_t)(a.ldvt * 2);
+  v.nk = k.nk;
+  v.nk1 = k.nk;      // the weight planes follow each other in a row: that stream runs on
+  v.nk1_w = k.nk1;   // the activations wrap per K segment
+  v.act = 0;
+  v.scale = 1.0f;
+  v.flags = FLAG_BIAS_ON_M;
+  v.seg_stride = (int64_t)D * a.ldvt * 2;
+  v.tps = (uint32_t)(a.seq_len / 256);
+  return launch_tiles(fn, v, D, a.M, stream);
 }

@@ -58,9 +58,19 @@ def test_emulated_tile_map(tiles, wgs):
     assert emu_gemm.run_case("f16", "f32", ntm=tiles[0], ntn=tiles[1], nk1=4, wgs=wgs, grid=tiles[0] * tiles[1]) < 1e-6
 
 
+@pytest.mark.parametrize("kw,tol", [(dict(), 5e-4), (dict(n_seq=1, seq_tiles=2, d_tiles=2, nk1=2, segs=2, grid=2), 5e-4),
+                                    (dict(dtype="bf16", n_seq=3, nk1=5, grid=1), 4e-3)])
+def test_emulated_qkv_as_two_launches(kw, tol):
+    """the fusion decoder's QKV projection (no rotary embedding): q | k through output segments with the q scale, V^T through the swapped
+    operand roles (weights with their lo plane as the kernel's A operand, activations wrapping per K segment as its W operand, bias by
+    output row, one output segment per sequence, padding columns of V^T untouched)"""
+    import emu_gemm
+    assert emu_gemm.run_qkv_case(**kw) < tol
+
+
 def test_tile_map_is_a_bijection_at_the_model_shapes():
     """the kernel's tile order restated in Python (gemm_gen.tile_of) over whole grids -- N = 320 (1280 x 4 / x 16 tiles), N = 100, odd view
-    counts (ntm % 8 == 4), grids smaller than 8 -- and, for a few workgroups, checked against what the emulated scalar prologue computes"""
+    counts (ntm % 8 == 4), grids smaller than 8 (test_emulated_tile_map checks the kernel's own scalar code against written tiles)"""
     import gemm_gen
     for ntm, ntn in ((1280, 4), (1280, 16), (400, 4), (12, 16), (1, 1), (3, 1), (7, 5), (44, 12), (1500 * 4, 4)):
         seen = set(gemm_gen.tile_of(wg, ntm, ntn) for wg in range(ntm * ntn))

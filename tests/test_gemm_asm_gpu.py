@@ -61,6 +61,37 @@ def test_gemm_asm_split_weights(built_lib, M, N, K):
         assert_close(y.float(), F.gelu(base), lp_tol(dt), f"w2 gelu sel={sel}")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n_seq,S,D,K,split", [(1, 1024, 256, 256, None), (3, 512, 512, 320, None), (2, 768, 256, 256, "w2"), (1, 70 * 256, 1024, 1024, None)])
+def test_gemm_asm_qkv(built_lib, dt, n_seq, S, D, K, split):
+    """QKV without rotary embedding as two launches of the hand-scheduled lowp role (q | k segments with the q scale; V^T with swapped
+    operand roles) against fp64 and against the compiler-scheduled kernel's QKV epilogue"""
+    if split and dt == torch.bfloat16:
+        pytest.skip("the split planes are an fp16 design")
+    M = n_seq * S
+    a = rnd((M, K), dt, 21)
+    w32 = torch.randn((3 * D, K), generator=torch.Generator().manual_seed(22)) * K ** -0.5
+    bias = torch.randn(3 * D) * 0.3
+    wp = ops.pack_linear_weight(w32, dt, split=bool(split)).to(DEV)
+    w_eff = w32 if split else w32.to(dt).float()
+    ref = a.double() @ w_eff.double().t() + bias.double()
+    qs = 0.160192 * ops.LOG2E
+    for sel in (ASM, HIP):
+        q = torch.zeros((M, D), dtype=dt, device=DEV)
+        k = torch.zeros((M, D), dtype=dt, device=DEV)
+        ld = ops.vt_ld(S) + 64
+        vt = torch.zeros((n_seq, D, ld), dtype=dt, device=DEV)
+        ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, None, q_scale=qs, split=split, kernel_sel=sel)
+        assert_close(q.float(), ref[:, :D] * qs, lp_tol(dt), f"q sel={sel}")
+        assert_close(k.float(), ref[:, D:2 * D], lp_tol(dt), f"k sel={sel}")
+        got_v = vt[:, :, :S].float().cpu().permute(0, 2, 1).reshape(M, D)
+        assert_close(got_v, ref[:, 2 * D:], lp_tol(dt), f"v^T sel={sel}")
+        assert float(vt[:, :, S:].float().abs().sum()) == 0.0  # padding untouched
+    cos, sin = ops.rope_tables(64, 100.0, DEV)
+    with pytest.raises((ValueError, RuntimeError)):  # rotary embedding stays on the compiler-scheduled kernel: forced -> error
+        ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, (cos, sin, 16), q_scale=qs, split=split, kernel_sel=ASM)
+
+
 def test_gemm_asm_strided_operand_and_outputs(built_lib):
     """A as a column block of a wider matrix (lda > K), outputs as column blocks of wider buffers (ldo > N)"""
     dt = torch.float16

@@ -85,6 +85,57 @@ def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=4, segs=1, act="none", b
     return err
 
 
+def run_qkv_case(dtype="f16", n_seq=2, seq_tiles=1, d_tiles=1, nk1=4, segs=1, scale=0.231, seed=0, grid=None):
+    """the decoder-style QKV projection as the product issues it (f3r_gemm_asm.hip): launch 1 = q | k columns of the fused weight into two
+    buffers (output segments, ACT_SCALE on the q segment); launch 2 = V^T with the operand roles swapped (kernel A = the v weight rows incl.
+    their lo plane, kernel W = the activations, wrapping per K segment; bias indexed by the output ROW; one output segment per sequence)"""
+    rng = np.random.default_rng(seed)
+    T_, D, K1 = 256 * seq_tiles * n_seq, 256 * d_tiles, 64 * nk1
+    S_ = 256 * seq_tiles
+    x = rng.standard_normal((T_, K1)).astype(np.float32)
+    w = (rng.standard_normal((3 * D, K1 * segs)) * K1 ** -0.5).astype(np.float32)
+    if segs == 2:
+        w[:, K1:] *= 2.0 ** -11
+    b = (rng.standard_normal(3 * D) * 0.5).astype(np.float32)
+    xh, wh = f32_to_half(x, dtype), f32_to_half(w, dtype)
+    mem = Memory()
+    a_x, a_w, a_b = mem.alloc(xh), mem.alloc(wh), mem.alloc(b)
+    a_q = mem.alloc(np.full((T_, D), 0x7E00, np.uint16))
+    a_k = mem.alloc(np.full((T_, D), 0x7E00, np.uint16))
+    ldvt = S_ + 64
+    a_vt = mem.alloc(np.full((n_seq, D, ldvt), 0x7E00, np.uint16))
+    g = gemm_gen.GemmGen(dtype, "lp")
+    prog = g.build()
+    assert not prog.check_hazards()
+    nk = nk1 * segs
+    ldw_b = K1 * segs * 2
+    # launch 1: q | k
+    karg, gr = gemm_gen.pack_args(a_x, a_w, a_b, 0, a_q, K1 * 2, ldw_b, 0, D * 2, nk, nk1, T_ // 256, 2 * d_tiles, gemm_gen.ACT_SCALE, grid=grid,
+                                  seg_stride=a_k - a_q, tps=d_tiles, scale=scale)
+    arg = mem.alloc(np.frombuffer(karg, np.uint8))
+    for wg in range(gr):
+        Workgroup(prog, mem, arg, (wg, 0, 0), 4, g.lds_bytes, dtype).run()
+    # launch 2: V^T = W_v X^T, roles swapped
+    karg, gr = gemm_gen.pack_args(a_w + 2 * D * ldw_b, a_x, a_b + 2 * D * 4, 0, a_vt, ldw_b, K1 * 2, 0, ldvt * 2, nk, nk, d_tiles, T_ // 256, gemm_gen.ACT_NONE,
+                                  grid=grid, seg_stride=D * ldvt * 2, tps=seq_tiles, flags=gemm_gen.FLAG_BIAS_ON_M, nk1_w=nk1)
+    arg = mem.alloc(np.frombuffer(karg, np.uint8))
+    for wg in range(gr):
+        Workgroup(prog, mem, arg, (wg, 0, 0), 4, g.lds_bytes, dtype).run()
+    xf = half_to_f32(xh, dtype).astype(np.float64)
+    wf = half_to_f32(wh, dtype).astype(np.float64)
+    ref = xf @ wf[:, :K1].T + (xf @ wf[:, K1:].T if segs == 2 else 0.0) + b.astype(np.float64)
+    q = half_to_f32(mem.get(a_q, np.uint16, (T_, D)), dtype).astype(np.float64)
+    k = half_to_f32(mem.get(a_k, np.uint16, (T_, D)), dtype).astype(np.float64)
+    vt = half_to_f32(mem.get(a_vt, np.uint16, (n_seq, D, ldvt)), dtype).astype(np.float64)
+    pad = mem.get(a_vt, np.uint16, (n_seq, D, ldvt))[:, :, S_:]
+    assert (pad == 0x7E00).all(), "V^T padding columns were written"
+    v = np.transpose(vt[:, :, :S_], (0, 2, 1)).reshape(T_, D)
+    errs = [float(np.abs(q - ref[:, :D] * np.float32(scale)).max() / np.abs(ref[:, :D] * scale).max()), float(np.abs(k - ref[:, D:2 * D]).max() / np.abs(ref).max()),
+            float(np.abs(v - ref[:, 2 * D:]).max() / np.abs(ref).max())]
+    print(f"qkv {dtype}: {n_seq} x {S_} tokens, D = {D}, K = {segs} x {K1}: q {errs[0]:.3e} k {errs[1]:.3e} v {errs[2]:.3e}")
+    return max(errs)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="f16")
