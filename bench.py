@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--parity-exact", action="store_true",
                     help="also run the same views through precision='exact' (the on-device fp32-equivalent path) and report the rel-L2 of the timed format "
                          "against it (N <= 128: the exact attention runs on the FMA pipe)")
+    ap.add_argument("--no-inference", action="store_true", help="skip timing the same forward through fast3r_amd.inference() (host in, host out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=3)
@@ -72,9 +73,11 @@ def parse(argv=None):
                     help="EMULATION, not a multi-GPU measurement: this one GPU runs exactly the work of rank R of --of W view-sharded ranks (its "
                          "views, local + remote attention launches over pre-filled K/V segments, parked softmax state) with no collective")
     ap.add_argument("--of", type=int, default=8, help="world size of the emulated job (--emulate-rank)")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "p2p"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
                     help="K/V exchange of the view-sharded path: one all-gather per tensor and layer + ONE remote attention launch, or pairwise "
-                         "rounds + one remote launch per arrived shard")
+                         "rounds (dealt onto --p2p-channels communicators) + one remote launch per arrived shard; auto (default with --gpus > 1): "
+                         "three fusion layers with each form in the first warm-up forward, then the one that exposed less (fast3r_amd/dist.py)")
+    ap.add_argument("--p2p-channels", type=int, default=3)
     return ap.parse_args(argv)
 
 
@@ -176,7 +179,10 @@ def main():
         if rank == 0:
             out = {"metric": "DRY RUN (no GPU work)", "dry_run": True, "value": None, "unit": "views/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "rccl_ranks_seen": ranks_seen, "backend": "gloo",
-                   "config": {"views": V, "views_per_gpu": views_per_gpu}}
+                   "config": {"views": V, "views_per_gpu": views_per_gpu},
+                   "exchange": {"requested": args.exchange, "p2p_channels": args.p2p_channels, "in_use": None, "exposed_ms_per_layer": None,
+                                "note": "filled by a real run: the form the start-up probe chose and, per fusion layer, how long the compute stream sat "
+                                        "between the local and the first remote attention launch (max over ranks)"}}
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if distributed:
             dist.destroy_process_group()
@@ -205,7 +211,7 @@ def main():
     placeholder = {"img": views[lo]["img"]}
     views = [v if v is not None else placeholder for v in views]  # never read outside [lo, hi)
 
-    def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False):
+    def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False, time_inference=False):
         """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
@@ -215,9 +221,9 @@ def main():
         model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
         if distributed:
-            model.shard_views(exchange=args.exchange)
+            model.shard_views(exchange=args.exchange, p2p_channels=args.p2p_channels)
         if emu:
-            model.emulate_rank(args.emulate_rank, args.of, exchange=args.exchange)
+            model.emulate_rank(args.emulate_rank, args.of, exchange="allgather" if args.exchange == "auto" else args.exchange)
         if args.fusion_only:
             step_fn = make_fusion_only_step(model, V, lp, dev)
         else:
@@ -229,6 +235,10 @@ def main():
                 step_fn()
             ops.ATTN_TIMER = []
             ops.ATTN_COUNTERS = torch.zeros(4, dtype=torch.int32, device=dev)
+            if distributed:  # exposed exchange per layer over the timed steps (events on the compute stream, read after the last barrier)
+                model.sharding.time_exchange = True
+                for kvx in model.sharding._kvx_cache.values():
+                    kvx.timing = []
             barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -238,6 +248,14 @@ def main():
             timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
             counters, ops.ATTN_COUNTERS = [int(c) & 0xFFFFFFFF for c in ops.ATTN_COUNTERS.tolist()], None
         dt = max_over_ranks(dt)
+        exch = None
+        if distributed:
+            ms = [x for kvx in model.sharding._kvx_cache.values() for x in kvx.exposed_ms()]
+            per_layer = max_over_ranks(sum(ms) / max(1, len(ms)))
+            exch = {"requested": args.exchange, "in_use": model.sharding.exchange_in_use, "p2p_channels": args.p2p_channels,
+                    "exposed_ms_per_layer": per_layer, "layers_timed_on_rank0": len(ms), "probe": {k: v for k, v in model.sharding._probe.items() if k != "layer"},
+                    "what": "mean gap on the compute stream between the end of the local-shard attention launch and the start of the first remote one "
+                            "(max over ranks): the part of the K / V^T exchange the local launch did not hide"}
         # dominant kernel = the fusion attention launches (the ones whose key count is the whole scene)
         if emu:
             # two launches per fusion layer: queries = the rank's tokens, keys = its own shard (local) / the other ranks' shards (remote)
@@ -281,6 +299,31 @@ def main():
                             "e2e": None if e2e is None else {"flops_per_forward": flops_forward(V), "achieved_per_gpu": e2e, "frac": e2e / MFMA_PEAK_TFLOPS}}}
         if emu:
             res["emulation"] = res_emu
+        if exch is not None:
+            res["exchange"] = exch
+        if time_inference and not (emu or distributed or args.fusion_only):
+            # the function users call (fast3r/dust3r/inference_multiview.py:70-99): host images in, everything back on the host.  Same model,
+            # same views (as host tensors, like load_images returns them); 1 warm-up (pinned buffers of the output leg) + 2 timed calls
+            from fast3r_amd import inference as f3r_inference
+            host_views = [dict(v, img=v["img"].cpu()) for v in views]
+            last_out = None
+            times = []
+            for it in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                torch.manual_seed(1234)
+                r = f3r_inference(host_views, model, dev, dtype="16-mixed" if dtype_name == "fp16" else "bf16-mixed", verbose=False)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                assert r["preds"][0]["pts3d_in_other_view"].device.type == "cpu"
+                del r
+            inf_ms = min(times[1:]) * 1e3
+            step_ms = dt / steps * 1e3
+            res["inference"] = {"what": "fast3r_amd.inference(host views, model, device, dtype): upload + forward + every output on the host (pinned, copied by a "
+                                        "side stream per head chunk) -- the call the reference's users make (inference_multiview.py:70-99)",
+                                "inference_ms": inf_ms, "ms_per_step": step_ms, "extra_ms": inf_ms - step_ms, "extra_frac_of_step": (inf_ms - step_ms) / step_ms,
+                                "calls_ms": [t * 1e3 for t in times]}
+            del host_views
         if rank == 0 and not args.no_parity and not emu:
             res["parity"] = parity_on_stress_fixture(lp, precision, dev)
         if parity_exact and not (emu or distributed or args.fusion_only):
@@ -312,7 +355,7 @@ def main():
     else:
         workload = f"Fast3R ViT-L 512x512 end-to-end single forward pass (encoder + fusion decoder + 2 DPT heads), N={V} views"
 
-    main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact)
+    main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact, time_inference=not args.no_inference)
     if emu:
         out = {"metric": "EMULATED per-rank step: ONE GPU runs rank %d of %d of the view-sharded forward at N=%d (no collectives, remote K/V segments "
                          "pre-filled) -- NOT a multi-GPU measurement" % (args.emulate_rank, args.of, V),
@@ -347,9 +390,11 @@ def main():
                        "operands": main_res["operands"]},
             "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), pmc=load_pmc(main_res["dtype"])),
         }
+        if "exchange" in main_res:
+            out["exchange"] = main_res["exchange"]
         out["weights"] = main_res["weights"]
         out["attn_rebase"] = main_res["attn_rebase"]
-        for k in ("parity", "parity_vs_exact"):
+        for k in ("parity", "parity_vs_exact", "inference"):
             if k in main_res:
                 out[k] = main_res[k]
         if hot_res is not None:

@@ -46,18 +46,21 @@ def _all_gather_into(out, inp, group):
 class KVExchange:
     """Per-forward send/receive buffers for the per-layer K / V^T all-gather (allocated once, reused by all layers)."""
 
-    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device, n_heads=None, q_dim=None, mode="allgather"):
+    def __init__(self, group, world, rank, t_loc, t_all, D, dtype, device, n_heads=None, q_dim=None, mode="allgather", p2p_groups=None):
         """D = width of the K rows / number of V^T planes x 64 (= the model width, or n_kv_heads * 64 with grouped-query attention);
         q_dim = width of the parked O state (the model width).  mode: "allgather" (one collective per tensor, the remote shards are
         attended in ONE launch when all have landed) or "p2p" (W-1 rounds of pairwise send / receive in ring-distance order, one remote
         launch per ARRIVED shard: the attention over shard d hides the transfer of shard d+1 whatever algorithm RCCL would have picked
         for the collective; costs one round trip of the parked softmax state per extra launch)."""
-        assert mode in ("allgather", "p2p")
-        self.mode = mode
+        assert mode in ("allgather", "p2p", "auto")
+        self.mode = "allgather" if mode == "auto" else mode   # "auto": ViewSharding.begin_layer() sets it per layer (probe, then the winner)
         self.group, self.world, self.rank = group, world, rank
+        self.p2p_groups = list(p2p_groups) if p2p_groups else [group]
         self.t_loc, self.t_all, self.D = t_loc, list(t_all), D
         q_dim = D if q_dim is None else q_dim
-        n_heads = q_dim // 64 if n_heads is None else n_heads
+        if n_heads is None:  # (no guess from the width: head_dim is not always 64 -- model_scaling_huge.yaml has 80)
+            raise ValueError("KVExchange needs n_heads (the parked softmax state is [tokens][n_heads][4])")
+        self.timing = None       # a list when ViewSharding.time_exchange is on: one exposed-exchange figure (ms) per layer
         t_max = max(self.t_all)
         self.t_max = t_max
         self.ldvt = _round_up(t_max, 64)
@@ -124,18 +127,22 @@ class KVExchange:
         self._rounds = []
         nccl = self.k_all.is_cuda and dist.get_backend(self.group) == "nccl"
         glob = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
-        for src, dst in self._peer_order():
+        for rd, (src, dst) in enumerate(self._peer_order()):
+            # Rounds are dealt round-robin onto the exchange's CHANNELS = process groups of the same ranks (ViewSharding(p2p_channels=k)):
+            # with RCCL every group has its own communicator and stream, so round d + 1 moves while round d is still in flight instead of
+            # queueing behind it on one stream (xGMI is point to point: different peers, different links)
+            grp = self.p2p_groups[rd % len(self.p2p_groups)]
             ops, stage = [], []
             if self.t_loc > 0:
                 ks, vs = (self.k_loc, self.vt_loc.view(self.D, self.ldvt)) if nccl or not self.k_loc.is_cuda else (self.k_loc.cpu(), self.vt_loc.view(self.D, self.ldvt).cpu())
-                ops += [dist.P2POp(dist.isend, ks, glob(dst), self.group), dist.P2POp(dist.isend, vs, glob(dst), self.group)]
+                ops += [dist.P2POp(dist.isend, ks, glob(dst), grp), dist.P2POp(dist.isend, vs, glob(dst), grp)]
             if self.t_all[src] > 0:
                 if nccl or not self.k_all.is_cuda:
                     kr, vr = self.k_all[src], self.vt_all[src]
                 else:  # gloo with device buffers (the 2-process single-GPU test): receive on the host, copy at wait()
                     kr, vr = torch.empty(self.k_all[src].shape, dtype=self.k_all.dtype), torch.empty(self.vt_all[src].shape, dtype=self.vt_all.dtype)
                     stage = [(self.k_all[src], kr), (self.vt_all[src], vr)]
-                ops += [dist.P2POp(dist.irecv, kr, glob(src), self.group), dist.P2POp(dist.irecv, vr, glob(src), self.group)]
+                ops += [dist.P2POp(dist.irecv, kr, glob(src), grp), dist.P2POp(dist.irecv, vr, glob(src), grp)]
             works = dist.batch_isend_irecv(ops) if ops else []
             self._rounds.append([src, works, stage])
 
@@ -170,6 +177,38 @@ class KVExchange:
                 return pos[r]
         raise ValueError("not a segment of this exchange")
 
+    # ---- how much of the exchange the local-shard launch did NOT hide: the gap on the compute stream between the end of the local
+    # launch and the start of the first remote one (device: two events; host transports: the time blocked in the first wait)
+    def mark_local_done(self):
+        if self.timing is None:
+            return
+        if self.k_all.is_cuda:
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
+        else:
+            import time
+            self._t0 = time.perf_counter()
+
+    def mark_remote_start(self):
+        if self.timing is None:
+            return
+        if self.k_all.is_cuda:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.timing.append((self._ev0, ev1))
+        else:
+            import time
+            self.timing.append((time.perf_counter() - self._t0) * 1e3)
+
+    def exposed_ms(self):
+        """per layer since timing was switched on (synchronises the device)"""
+        if not self.timing:
+            return []
+        if self.k_all.is_cuda:
+            torch.cuda.synchronize(self.k_all.device)
+            return [a.elapsed_time(b) for a, b in self.timing]
+        return list(self.timing)
+
     def start(self):
         """Launch both all-gathers.  With RCCL they are asynchronous (their own stream, ordered after the QKV GEMM that
         produced k_loc / vt_loc on the current stream); other backends gather synchronously through the host."""
@@ -199,17 +238,69 @@ class KVExchange:
 
 
 class ViewSharding:
-    def __init__(self, process_group=None, gather_outputs=False, exchange="allgather"):
+    PROBE_LAYERS = 3   # exchange="auto": this many fusion layers with each form on the first forward, then the one that exposed less
+
+    def __init__(self, process_group=None, gather_outputs=False, exchange="allgather", p2p_channels=3):
+        """exchange: "allgather" | "p2p" (KVExchange.mode) | "auto" (the first forward runs PROBE_LAYERS layers with each form, every rank
+        measures how long its compute stream sat between the local and the first remote attention launch, the maxima over ranks are compared
+        and the cheaper form is used from then on).  p2p_channels: process groups (RCCL: communicators = streams) the per-peer rounds are
+        dealt onto, so that consecutive rounds overlap instead of queueing on one stream."""
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("ViewSharding needs an initialised torch.distributed process group (RCCL: backend 'nccl')")
+        if exchange not in ("allgather", "p2p", "auto"):
+            raise ValueError(f"exchange={exchange!r}")
         self.group = process_group
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
         self.gather_outputs = gather_outputs
-        self.exchange = exchange  # "allgather" | "p2p" (KVExchange.mode)
+        self.exchange = exchange
+        self.time_exchange = False   # bench.py: collect KVExchange.timing (exposed exchange per layer)
         self._kvx_cache = {}  # geometry -> KVExchange (make_kv_exchange)
         if self.world > 8:
             raise ValueError("the attention kernel takes at most 8 K/V segments (one MI355X node)")
+        self.p2p_groups = [process_group]
+        if exchange in ("p2p", "auto") and self.world > 2 and p2p_channels > 1:
+            ranks = [dist.get_global_rank(process_group, r) for r in range(self.world)] if process_group is not None else list(range(self.world))
+            # (a collective call: every rank of the group constructs its ViewSharding with the same arguments)
+            self.p2p_groups = [dist.new_group(ranks) for _ in range(min(p2p_channels, self.world - 1))]
+        self._probe = {"layer": 0, "allgather": [], "p2p": [], "choice": None if exchange == "auto" else exchange}
+
+    # ---- exchange="auto"
+    def begin_layer(self, kvx):
+        """called by the model before a fusion layer's exchange starts: picks the form for this layer"""
+        if self.exchange != "auto":
+            return
+        pr = self._probe
+        if pr["choice"] is not None:
+            kvx.mode = pr["choice"]
+            return
+        n = pr["layer"]
+        kvx.mode = "allgather" if n < self.PROBE_LAYERS else "p2p"
+        if kvx.timing is None:
+            kvx.timing = []
+        pr["layer"] = n + 1
+
+    def end_layer(self, kvx):
+        """after the layer's attention launches: during the probe, file the exposure under the form that ran; after 2 x PROBE_LAYERS layers
+        agree on the winner (MAX over ranks per form, the same decision everywhere)"""
+        if self.exchange != "auto" or self._probe["choice"] is not None:
+            return
+        pr = self._probe
+        if pr["layer"] < 2 * self.PROBE_LAYERS:
+            return
+        ms = kvx.exposed_ms()
+        if not self.time_exchange:
+            kvx.timing = None
+        sums = [sum(ms[:self.PROBE_LAYERS]), sum(ms[self.PROBE_LAYERS:2 * self.PROBE_LAYERS])]
+        cd = self._comm_device(kvx.k_all.device)
+        t = torch.tensor(sums, dtype=torch.float64, device=cd)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        pr["allgather"], pr["p2p"] = float(t[0]), float(t[1])
+        pr["choice"] = "allgather" if pr["allgather"] <= pr["p2p"] else "p2p"
+
+    @property
+    def exchange_in_use(self):
+        return self._probe["choice"] or "auto (probing)"
 
     def my_range(self, n_views):
         return split_range(n_views, self.world, self.rank)
@@ -241,8 +332,12 @@ class ViewSharding:
         cache = self._kvx_cache
         if key not in cache:
             cache.clear()  # one geometry at a time: a different scene releases the previous buffers
-            cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim, mode=self.exchange)
-        return cache[key]
+            cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim, mode=self.exchange,
+                                    p2p_groups=self.p2p_groups)
+        kvx = cache[key]
+        if self.time_exchange and kvx.timing is None:
+            kvx.timing = []
+        return kvx
 
     def gather_results(self, results, n_total, dev):
         """Outputs stay sharded by default (each rank returns the dicts of ITS views, in view order); with gather_outputs=True every rank
@@ -250,6 +345,10 @@ class ViewSharding:
         all_gather_into_tensor (RCCL: device to device); only their names and shapes (a few hundred bytes) are exchanged as objects."""
         if not self.gather_outputs:
             return results
+        for r in results:
+            for k, v in r.items():
+                if v.dtype not in (torch.float32, torch.float16, torch.bfloat16):  # everything travels through one fp32 buffer: exact for these only
+                    raise TypeError(f"gather_results: output {k!r} has dtype {v.dtype}; only float32 / float16 / bfloat16 outputs survive the fp32 transport")
         meta = [[(k, tuple(v.shape), v.dtype) for k, v in r.items()] for r in results]
         metas = [None] * self.world
         dist.all_gather_object(metas, meta, group=self.group)
@@ -316,6 +415,14 @@ class EmulatedKVExchange:
     def gather_rows_f32(self, k_rows, v_rows):
         raise NotImplementedError("precision='exact' is not available under the one-GPU rank emulation (there is no fp32 K / V of the other ranks)")
 
+    timing = None
+
+    def mark_local_done(self):
+        pass
+
+    def mark_remote_start(self):
+        pass
+
     positions = KVExchange.positions
     remote_positions = KVExchange.remote_positions
     local_segment = KVExchange.local_segment
@@ -369,7 +476,8 @@ class EmulatedSharding:
             a, b = split_range(self._n_total, self.world, r)
             t_all.append((b - a) * per_view)
         q_dim = D if q_dim is None else q_dim
-        n_heads = q_dim // 64 if n_heads is None else n_heads
+        if n_heads is None:
+            raise ValueError("make_kv_exchange needs n_heads")
         key = (tuple(t_all), D, dtype, str(dev), n_heads, q_dim, self.exchange)
         if self._kvx is None or self._kvx[0] != key:
             self._kvx = (key, EmulatedKVExchange(self.world, self.rank, t_all, D, dtype, dev, n_heads, q_dim, self.kv_source, mode=self.exchange))
@@ -380,3 +488,9 @@ class EmulatedSharding:
 
     def gather_results(self, results, n_total, dev):
         return results
+
+    def begin_layer(self, kvx):
+        pass
+
+    def end_layer(self, kvx):
+        pass

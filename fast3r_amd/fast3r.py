@@ -497,7 +497,43 @@ except Exception:  # pragma: no cover  (huggingface_hub is a requirement of the 
             super().__init_subclass__()
 
 
-class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch/fast3r", tags=["image-to-3d"]):
+class _HostSink:
+    """Device -> host leg of `inference()` (fast3r/dust3r/inference_multiview.py:92-93 + utils/device.py:17-53 `to_cpu`): one pinned host
+    tensor per (view, output) -- torch's caching host allocator recycles them between calls, and a tensor the caller still holds is
+    never handed out again -- filled by non_blocking copies on a side stream that waits for the event recorded behind the head chunk that
+    produced the data.  The copies of chunk c overlap the heads of chunk c + 1; finish() waits for the last one."""
+
+    def __init__(self, dev, batch):
+        self.dev, self.B = dev, batch
+        self.stream = torch.cuda.Stream(device=dev)
+        self.bufs = {}
+
+    def push(self, items, keep_alive):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        for t in keep_alive:
+            if t is not None:
+                t.record_stream(self.stream)  # the caching allocator must not recycle the chunk's tensors before the side stream has read them
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            for i, b, name, src in items:
+                key = (i, name)
+                if key not in self.bufs:
+                    self.bufs[key] = torch.empty((self.B,) + tuple(src.shape), dtype=src.dtype, pin_memory=True)
+                self.bufs[key][b].copy_(src, non_blocking=True)
+
+    def result(self, i, name):
+        return self.bufs[(i, name)]
+
+    def finish(self):
+        self.stream.synchronize()
+
+
+# compute_dtype travels through config.json as text ("torch.float16"): the constructor accepts the string back
+_DTYPE_CODER = {torch.dtype: (lambda d: str(d), lambda s_: getattr(torch, str(s_).replace("torch.", "")))}
+
+
+class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch/fast3r", tags=["image-to-3d"], coders=_DTYPE_CODER):
     """`Fast3R.from_pretrained("jedyang97/Fast3R_ViT_Large_512")` (or a local directory holding config.json + model.safetensors) works as
     in the reference: the mixin reads the three *_args dicts from config.json, builds the model and loads the state dict (identical keys).
 
@@ -640,11 +676,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def set_max_parallel_views_for_head(self, n):
         self.max_parallel_views_for_head = n
 
-    def shard_views(self, process_group=None, exchange="allgather"):
+    def shard_views(self, process_group=None, exchange="allgather", p2p_channels=3):
         """Enable the view-sharded multi-GPU path: this rank encodes / decodes / regresses only its contiguous range of
         views and exchanges K / V^T per fusion layer over RCCL (fast3r_amd/dist.py).  exchange: "allgather" (one collective per tensor
-        and layer, one remote attention launch) or "p2p" (pairwise rounds, one remote launch per arrived shard)."""
-        self.sharding = ViewSharding(process_group, exchange=exchange)
+        and layer, one remote attention launch), "p2p" (pairwise rounds dealt onto p2p_channels communicators, one remote launch per
+        arrived shard) or "auto" (three fusion layers with each on the first forward, then the one that exposed less)."""
+        self.sharding = ViewSharding(process_group, exchange=exchange, p2p_channels=p2p_channels)
         return self
 
     def emulate_rank(self, rank, world, kv_source=None, exchange="allgather"):
@@ -779,6 +816,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:
             # view-sharded: the all-gather of the remote K / V^T runs while the kernel attends over the local shard; the
             # online-softmax state (m, l, O) is parked in fp32 and resumed over the remote segments once they have landed
+            sharding = self.sharding
+            sharding.begin_layer(kv_exchange)  # exchange="auto": which form this layer uses (probe, then the winner)
             kv_exchange.start()
             if seq_len == 0:
                 kv_exchange.finish()  # a rank without tokens still takes part in the collective
@@ -786,11 +825,14 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 pos = kv_exchange.positions()  # global token index of the first row of every rank's shard (causal attention only)
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True,
                               state=kv_exchange.state, state_out=True, q_pos0=pos[kv_exchange.rank], seg_pos0=[pos[kv_exchange.rank]], **gqa)
+                kv_exchange.mark_local_done()
                 # the remote shards, as ONE group once the all-gathers have landed or ("p2p" exchange) shard by shard in arrival order
                 groups = [(w, sg) for w, sg in kv_exchange.remote_groups()]
                 live = [i for i, (_, sg) in enumerate(groups) if sg]
                 for i, (wait, segs) in enumerate(groups):
                     wait()
+                    if live and i == live[0]:
+                        kv_exchange.mark_remote_start()  # what the local launch did not hide = the gap on this stream up to here
                     if not segs:
                         continue
                     ops.attention(q, o, n_heads, scale, segs, tq=seq_len, q_prescaled=True, state=kv_exchange.state, state_in=True,
@@ -799,6 +841,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             else:
                 kv_exchange.finish()
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True, **gqa)
+            sharding.end_layer(kv_exchange)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
@@ -1112,11 +1155,14 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1], depth_mode=tuple(hk.depth_mode))  # head[4] + postprocess
 
     # ---------------------------------------------------------------- forward
-    def forward(self, views, profiling=False):
-        """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device."""
+    def forward(self, views, profiling=False, host_outputs=False):
+        """fast3r.py:302-497.  views: list[N] of dicts with 'img' (B,3,H,W) on a ROCm device.
+        host_outputs (fast3r_amd.inference sets it): return the per-view tensors on the HOST instead of the device -- every head chunk's
+        pointmaps / confidences are copied into pinned host memory by a side stream as soon as the chunk is done, overlapped with the heads
+        of the next chunk (what the reference does after the forward with a blocking `to_cpu`, dust3r/inference_multiview.py:92-93)."""
         if len(views) == 0:
             return ([], {}) if profiling else []
-        if (self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
+        if (self.use_graphs and not profiling and not host_outputs and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
                 and self.precision != "exact"):  # (the validation mode allocates per layer: it always runs eagerly)
             dev = views[0]["img"].device
             if dev.type == "cuda":  # (anything else: the eager path raises its F3RError)
@@ -1124,7 +1170,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     out = self._graphs.run(self, views)
                 if out is not None:
                     return out
-        return self._forward_eager(views, profiling)
+        return self._forward_eager(views, profiling, host_outputs=host_outputs)
 
     def enable_graphs(self, on=True, max_views=64):
         """Opt-in hipGraph replay for launch-bound scenes (a forward of N <= max_views same-size views is a chain of
@@ -1169,7 +1215,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             plan.append(dict(enc_swap=enc_swap, head_hw=head_hw, head_swap=head_swap))
         return dict(views=plan, any_portrait=any_p)
 
-    def _forward_eager(self, views, profiling=False, _emb_rows=None):
+    def _forward_eager(self, views, profiling=False, _emb_rows=None, host_outputs=False):
         dev = views[0]["img"].device
         if dev.type != "cuda":
             raise F3RError(f"fast3r_amd.Fast3R runs only on a ROCm GPU (views are on {dev}); there is no CPU fallback")
@@ -1292,6 +1338,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         heads = [("pts3d_in_other_view", "conf", pk["head"])]
         if pk["head_local"] is not None:
             heads.append(("pts3d_local", "conf_local", pk["head_local"]))
+        sink = _HostSink(dev, B) if (host_outputs and sh is None) else None
         for b in range(B):
             i0 = 0
             while i0 < n_loc:
@@ -1309,10 +1356,14 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                         per_view[i][b][pname] = pts[i - i0].swapaxes(0, 1) if sw else pts[i - i0]  # transposed(): misc.py:105-106
                         if conf is not None:
                             per_view[i][b][cname] = conf[i - i0].swapaxes(0, 1) if sw else conf[i - i0]
+                    if sink is not None:  # this chunk's outputs start their way to the host while the next chunk's heads run
+                        sink.push([(i, b, nm, per_view[i][b][nm]) for i in range(i0, i1) for nm in (pname, cname) if nm in per_view[i][b]], (pts, conf))
                 i0 = i1
         for i in range(n_loc):
             for name in per_view[i][0]:
-                results[i][name] = torch.stack([per_view[i][b][name] for b in range(B)], dim=0)
+                results[i][name] = sink.result(i, name) if sink is not None else torch.stack([per_view[i][b][name] for b in range(B)], dim=0)
+        if sink is not None:
+            sink.finish()
         if sh is not None:
             results = sh.gather_results(results, N_total, dev)
         if profiling:

@@ -45,6 +45,8 @@ def collate_with_cat(whatever, lists=False):
         if isinstance(elem, dict):
             return {k: collate_with_cat([e[k] for e in whatever], lists=lists) for k in elem}
         if isinstance(elem, torch.Tensor):
+            if not lists and len(whatever) == 1:
+                return elem  # torch.cat of one tensor: the same values without the copy (N x 8.4 MB of outputs per call otherwise)
             return [x for e in whatever for x in e] if lists else torch.cat(whatever)
         if isinstance(elem, np.ndarray):
             return [x for e in whatever for x in e] if lists else torch.cat([torch.from_numpy(x) for x in whatever])
@@ -101,18 +103,28 @@ def _operand_format(precision, model, n_views=0):
 
 
 def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_batch=False, use_amp=False, ret=None,
-                      profiling=False):
+                      profiling=False, host_outputs=False):
+    """host_outputs (set by inference(), which returns everything on the CPU anyway): the predictions arrive in pinned host memory through
+    the model's overlapped device -> host leg (Fast3R.forward(host_outputs=True)) and the views' tensors that came from the host are
+    handed back as they came, so the `to_cpu` of inference() finds nothing left to move."""
+    host_side = []  # (view, name, the caller's host tensor): handed back as they came instead of being copied device -> host again
     for view in batch:
         for name in _TENSOR_KEYS:
             if name in view:
+                if torch.is_tensor(view[name]) and view[name].device.type == "cpu":
+                    host_side.append((view, name, view[name]))
                 view[name] = view[name].to(device, non_blocking=True)
     net = getattr(model, "net", model)  # accept the MultiViewDUSt3RLitModule shim too
     saved = (net.compute_dtype, net.precision)
     net.compute_dtype, net.precision = _operand_format(precision, net, n_views=len(batch))
     try:
-        out = model(batch, profiling=profiling) if net is model else (net(batch, profiling=profiling))
+        kw = dict(host_outputs=True) if host_outputs else {}
+        out = model(batch, profiling=profiling, **kw) if net is model else (net(batch, profiling=profiling, **kw))
     finally:
         net.compute_dtype, net.precision = saved
+    if host_outputs:
+        for view, name, t in host_side:
+            view[name] = t
     preds, profiling_info = out if profiling else (out, None)
     loss = criterion(batch, preds) if criterion is not None else None
     result = dict(views=batch, preds=preds, loss=loss)
@@ -127,7 +139,7 @@ def inference(multiple_views_in_one_sample, model, device, dtype, verbose=True, 
         print(f">> Inference with model on {len(multiple_views_in_one_sample)} images")
     multiple_shapes = not check_if_same_size(multiple_views_in_one_sample)
     res = loss_of_one_batch(collate_with_cat([tuple(multiple_views_in_one_sample)]), model, None, torch.device(device),
-                            dtype, profiling=profiling)
+                            dtype, profiling=profiling, host_outputs=True)
     profiling_info = res.pop("profiling_info") if profiling and "profiling_info" in res else None
     result = collate_with_cat([to_cpu(res)], lists=multiple_shapes)
     if profiling and profiling_info is not None:

@@ -51,8 +51,10 @@ def estimate_poses(pts3d, conf, focal=None, pp=None, conf_thr=CONF_THR, n_focals
 
 def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimation_method="individual"):
     """multiview_dust3r_module.py:807-869.  preds: list over views of dicts with 'pts3d_in_other_view' (B,H,W,3) and 'conf' (B,H,W).
-    `niter_PnP` is the RANSAC iteration count (init_im_poses.py:335): min(niter_PnP, 32) sampled hypotheses per view here.  Views of
-    different resolutions are solved per resolution group (the reference loops over views, :1038-1078)."""
+    `niter_PnP` is OpenCV's RANSAC iteration BOUND (init_im_poses.py:335: it stops earlier once the consensus is good enough).  The kernel
+    scores its sampled hypotheses in parallel, one per thread of a 32-thread group, so fewer than 32 would only idle threads and weaken the
+    consensus on outlier-heavy views: the wrapper asks for max(niter_PnP, 32) (the kernel caps at 32); `estimate_poses(n_iter=...)` is the
+    knob for fewer.  Views of different resolutions are solved per resolution group (the reference loops over views, :1038-1078)."""
     if focal_length_estimation_method not in ("individual", "first_view_from_global_head", "first_view_from_local_head"):
         raise ValueError(f"Unknown focal_length_estimation_method: {focal_length_estimation_method}")  # :843
     n_views = len(preds)
@@ -73,7 +75,7 @@ def estimate_camera_poses(preds, views=None, niter_PnP=10, focal_length_estimati
         pts = torch.stack([preds[v]["pts3d_in_other_view"] for v in vs], dim=1).reshape(B * len(vs), H, W, 3)  # sample-major
         conf = torch.stack([preds[v]["conf"] for v in vs], dim=1).reshape(B * len(vs), H, W)
         focal = None if f_b is None else f_b.repeat_interleave(len(vs))
-        poses, fout, _ = estimate_poses(pts, conf, focal, n_iter=niter_PnP)
+        poses, fout, _ = estimate_poses(pts, conf, focal, n_iter=max(int(niter_PnP), 32))
         poses = poses.view(B, len(vs), 4, 4).cpu().numpy().astype(np.float64)
         fout = fout.view(B, len(vs)).cpu().tolist()
         for b in range(B):

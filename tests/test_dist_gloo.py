@@ -41,7 +41,12 @@ def _worker(rank, world, port, ret):
         ids = sh.broadcast_ids(ids, torch.device("cpu"))
         assert ids.tolist() == [list(range(n_views))]
         t_loc = (hi - lo) * P
-        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"))
+        try:
+            sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), t_all=[3 * P, 2 * P])
+            raise AssertionError("n_heads must be given (no guess from the width)")
+        except ValueError:
+            pass
+        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), n_heads=2)
         assert kvx.t_all == [3 * P, 2 * P] and kvx.ldvt % 64 == 0 and kvx.ldvt >= 3 * P
         # full (unsharded) problem, identical on both ranks
         g = torch.Generator().manual_seed(0)
@@ -67,7 +72,13 @@ def _worker(rank, world, port, ret):
         k_all, v_all = kvx.gather_rows_f32(kf[r0:r0 + t_loc, :64].contiguous(), vf[r0:r0 + t_loc, :64].contiguous())
         assert torch.equal(k_all, kf[:, :64]) and torch.equal(v_all, vf[:, :64])
         # the model passes the token counts it derives from the (shared) list of views: same exchange object, no collective
-        assert sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), t_all=[3 * P, 2 * P]) is kvx
+        assert sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), t_all=[3 * P, 2 * P], n_heads=2) is kvx
+        try:
+            sh.gather_outputs = True
+            sh.gather_results([{"idx": torch.arange(3)} for _ in range(lo, hi)], n_views, torch.device("cpu"))
+            raise AssertionError("integer outputs must be refused by the fp32 transport")
+        except TypeError:
+            sh.gather_outputs = False
         res = sh.gather_results([{"x": torch.full((1, 2), float(i))} for i in range(lo, hi)], n_views, torch.device("cpu"))
         assert len(res) == hi - lo  # outputs stay sharded by default
         sh.gather_outputs = True
@@ -100,11 +111,12 @@ def _worker_p2p(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fast3r_amd.dist import ViewSharding
-        sh = ViewSharding(exchange="p2p")
+        sh = ViewSharding(exchange="p2p", p2p_channels=2)   # the two rounds of a world of three run on two communicators
+        assert len(sh.p2p_groups) == 2
         n_views, P, D = 7, 24, 128  # uneven: 3 + 2 + 2 views
         lo, hi = sh.my_range(n_views)
         t_loc = (hi - lo) * P
-        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"))
+        kvx = sh.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), n_heads=2)
         assert kvx.mode == "p2p" and kvx.t_all == [3 * P, 2 * P, 2 * P]
         g = torch.Generator().manual_seed(0)
         T = n_views * P
@@ -128,6 +140,34 @@ def _worker_p2p(rank, world, port, ret):
             full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
             assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
             assert [s[2] for s in kvx.finish()] == [t for r, t in enumerate(kvx.t_all) if r != rank]  # everything at once still works
+        # ---- exchange="auto": PROBE_LAYERS layers with each form, every rank times what the local launch did not hide, the maxima over
+        # ranks pick the winner -- the same one on every rank -- and later layers use it
+        sa = ViewSharding(exchange="auto", p2p_channels=2)
+        kva = sa.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), n_heads=2)
+        used = []
+        for layer in range(2 * sa.PROBE_LAYERS + 2):
+            kva.k_loc[:t_loc] = kf[r0:r0 + t_loc] + layer
+            kva.vt_loc[0, :, :t_loc] = (vf[r0:r0 + t_loc] + layer).t()
+            sa.begin_layer(kva)
+            used.append(kva.mode)
+            kva.start()
+            kva.mark_local_done()
+            arrived = [kva.local_segment()]
+            first = True
+            for wait, segs in kva.remote_groups():
+                wait()
+                if first and segs:
+                    kva.mark_remote_start()
+                    first = False
+                arrived += segs
+            sa.end_layer(kva)
+            out = _segment_attention(qf[r0:r0 + t_loc], arrived, 0.16)
+            full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
+            assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
+        assert used[:6] == ["allgather"] * 3 + ["p2p"] * 3 and sa.exchange_in_use in ("allgather", "p2p") and used[6] == used[7] == sa.exchange_in_use
+        votes = [None] * world
+        dist.all_gather_object(votes, sa.exchange_in_use)
+        assert len(set(votes)) == 1
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -211,6 +211,14 @@ def test_hub_mixin_round_trip(tmp_path):
     assert m2.encoder_args == m.encoder_args and m2.decoder_args == m.decoder_args and m2.head_args == m.head_args
     assert list(m2.state_dict()) == list(m.state_dict())
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # the two arguments the reference does not have travel with the snapshot: a model saved as bf16 / "fast" does not come back as the default
+    m3 = Fast3R(enc, dec, head, compute_dtype=torch.bfloat16, precision="fast")
+    m3.save_pretrained(tmp_path / "b")
+    cfg = json.load(open(tmp_path / "b" / "config.json"))
+    assert cfg["precision"] == "fast" and cfg["compute_dtype"] == "torch.bfloat16"
+    m4 = Fast3R.from_pretrained(tmp_path / "b")
+    assert m4.precision == "fast" and m4.compute_dtype == torch.bfloat16
+    assert m2.precision == "high" and m2.compute_dtype == torch.float16  # the constructor default = the benchmarked format
 
 
 def test_load_from_dust3r_checkpoint(tmp_path):
