@@ -306,7 +306,10 @@ def main():
             # same views (as host tensors, like load_images returns them); 1 warm-up (pinned buffers of the output leg) + 2 timed calls
             from fast3r_amd import inference as f3r_inference
             host_views = [dict(v, img=v["img"].cpu()) for v in views]
-            last_out = None
+            if parity_exact:
+                last_out = [{k: v.float().cpu() for k, v in o.items()} for o in last_out]  # kept for the parity leg below, off the device
+            else:
+                last_out = None
             times = []
             for it in range(3):
                 torch.cuda.synchronize()
@@ -327,7 +330,7 @@ def main():
         if rank == 0 and not args.no_parity and not emu:
             res["parity"] = parity_on_stress_fixture(lp, precision, dev)
         if parity_exact and not (emu or distributed or args.fusion_only):
-            keep = [{k: v.float().cpu() for k, v in o.items()} for o in last_out]
+            keep = [{k: v.float().cpu() for k, v in o.items()} for o in last_out]  # (.cpu() of a host tensor is the tensor itself)
             del model, last_out
             torch.cuda.empty_cache()
             mx = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision="exact").eval()

@@ -337,10 +337,11 @@ class PixelwiseTaskWithDPT(_Params):
 # ======================================================================================= packed (device) weights
 class _PackedBlock:
     __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim")
+                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim", "fc1_split")
 
     def __init__(self):
         self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
+        self.fc1_split = None  # None: like every other projection of the block
         self.head_dim = 64  # the Fast3R fusion decoder may have another width (model_scaling_huge.yaml: 80)
         self.q_dim, self.kv_dim, self.kv_group, self.causal = 0, None, 1, False  # grouped-query / causal attention (LlamaDecoder only)
 
@@ -349,14 +350,17 @@ def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 
 
-def _pack_block(blk: _Block, lp, split=False, head_dim=64):
+def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None):
     p = _PackedBlock()
     p.head_dim = head_dim
     p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
     p.eps = blk.norm1.eps
     p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp, split), _f32(blk.attn.qkv.bias)
     p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp, split), _f32(blk.attn.proj.bias)
-    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, split), _f32(blk.mlp.fc1.bias)
+    # "high" keeps fc1 single-plane (fc1_split False): its output is rounded to ONE 16-bit number by the GELU epilogue anyway, and the stress
+    # models say its weight planes buy nothing (oracle/precision_study.py per-role run, DESIGN.md section 3 "Precision")
+    p.fc1_split = bool(split) if fc1_split is None else bool(fc1_split)
+    p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, p.fc1_split), _f32(blk.mlp.fc1.bias)
     p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp, split), _f32(blk.mlp.fc2.bias)
     return p
 
@@ -756,7 +760,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:
             pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
             pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
-            pk["enc"] = [_pack_block(b, lp, hp) for b in enc.enc_blocks]
+            pk["enc"] = [_pack_block(b, lp, hp, fc1_split=hp and self.precision == "exact") for b in enc.enc_blocks]
             pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
@@ -765,7 +769,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
-            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads) for b in dec.dec_blocks]
+            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=hp and self.precision == "exact") for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
         pk["head"] = _pack_head(self.downstream_head, lp, hp)
         pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None
@@ -848,7 +852,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             _, ab = ops.gemm(h2, pb.fc1_w, out_lp=ws.hid, split=sp)
             hid = ops.silu_mul(ab, pb.swiglu_hidden)
         else:
-            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", out_lp=ws.hid, split=sp)
+            _, hid = ops.gemm(h2, pb.fc1_w, bias=pb.fc1_b, act="gelu", out_lp=ws.hid, split=sp if pb.fc1_split in (None, True) else None)
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split=sp)
         return x
 
@@ -1222,9 +1226,9 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if any(v["img"].device != dev for v in views) or next(self.parameters()).device != dev:
             raise F3RError("fast3r_amd.Fast3R: the model and every view must live on the same device")
         with torch.cuda.device(dev):  # kernels launch on the CURRENT device / stream: make that the tensors' device
-            return self._forward_on_device(views, profiling, _emb_rows, dev)
+            return self._forward_on_device(views, profiling, _emb_rows, dev, host_outputs)
 
-    def _forward_on_device(self, views, profiling, _emb_rows, dev):
+    def _forward_on_device(self, views, profiling, _emb_rows, dev, host_outputs=False):
         prof = {} if profiling else None
         lp = self.compute_dtype
         pk = self._pack(dev)

@@ -53,6 +53,12 @@ def split2(x, dt):
 
 class Zone:
     mode = "f32"
+    roles = {}   # per-role override inside the transformer zone: {"fc1" | "fc2" | "qkv" | "proj": mode} (a linear layer's role is read off its weight shape)
+
+
+def linear_role(w):
+    n, k = w.shape
+    return "fc1" if n == 4 * k else "fc2" if k == 4 * n else "qkv" if n == 3 * k else "proj" if n == k else "other"
 
 
 ZONE = Zone()
@@ -61,6 +67,8 @@ ZONE = Zone()
 def _apply(fn, a, w, *rest, **kw):
     """fn(a, w, ...) bilinear in (a, w): emulate the operand rounding of ZONE.mode."""
     mode = ZONE.mode
+    if fn is F.linear and ZONE.roles and w.dim() == 2:
+        mode = ZONE.roles.get(linear_role(w), mode)
     store = mode.endswith("+store")
     base = mode.replace("+store", "")
     bias = rest[0] if rest else kw.pop("bias", None)
@@ -146,8 +154,9 @@ def attention_emul(x, sd, pre, num_heads, scale, xpos=None, rope_base=None, q_ch
 ATTN = {}
 
 
-def run_design(views, sd, args, tr, hd, attn=None):
+def run_design(views, sd, args, tr, hd, attn=None, roles=None):
     enc, dec, head = args
+    ZONE.roles = dict(roles or {})
     ATTN.clear()
     if attn:
         ATTN.update(attn)
@@ -173,6 +182,7 @@ def run_design(views, sd, args, tr, hd, attn=None):
     finally:
         O.F, O.attention, O.dpt_forward = saveF, saveA, orig_dpt
         ZONE.mode = "f32"
+        ZONE.roles = {}
 
 
 def main():
