@@ -369,17 +369,19 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   // without the staggered wave rows (measurement; an ineligible shape is an error, not a silent fallback)
   if (a.kernel_sel >= 16) return f3r_gemm256_lab(a, s);
   // 6 = the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/gemm_gen.py), an ineligible launch is an error; 0 takes it for the launches
-  // it is built for (the transformer's big linear layers: >= F3R_GEMM_ASM_MIN_TILES full 256 x 256 tiles); 7 = automatic WITHOUT it
+  // it is built for (the transformer's big linear layers: enough full 256 x 256 tiles to fill its persistent grid, f3r_gemm_asm_preferred);
+  // 7 = automatic WITHOUT it
   if (a.kernel_sel == 6 || a.kernel_sel == 0) {
     const char* why = "";
-    if (a.epi == F3R_EPI_QKV && f3r_gemm_asm_qkv_eligible(a, &why) && (a.kernel_sel == 6 || (a.M / 256) * (a.N / 256) >= F3R_GEMM_ASM_MIN_TILES))
+    // (QKV = two launches: q | k with 2/3 of the tiles, V^T with 1/3; the smaller one decides)
+    if (a.epi == F3R_EPI_QKV && f3r_gemm_asm_qkv_eligible(a, &why) && (a.kernel_sel == 6 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 3 / 256))))
       return f3r_gemm_asm_qkv_launch(a, s);
     const bool ok = a.epi != F3R_EPI_QKV && f3r_gemm_asm_eligible(a, &why);
     if (a.kernel_sel == 6 && !ok) {
       f3r_set_error("f3r_gemm: kernel_sel 6 (hand-scheduled kernel) but the launch is not eligible: %s", why);
       return F3R_ERR_UNSUPPORTED;
     }
-    if (ok && (a.kernel_sel == 6 || (a.M / 256) * (a.N / 256) >= F3R_GEMM_ASM_MIN_TILES)) return f3r_gemm_asm_launch(a, s);
+    if (ok && (a.kernel_sel == 6 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 256)))) return f3r_gemm_asm_launch(a, s);
   }
   const int sel = a.kernel_sel == 7 ? 0 : a.kernel_sel;
   if (sel >= 2) F3R_REQUIRE(f3r_gemm256_eligible(a), "f3r_gemm: kernel_sel %d but the shape is not eligible for the 256-tile kernel", sel);

@@ -62,7 +62,23 @@ hipFunction_t get_fn(int role, int dtype) {
 
 int role_of(const f3r_gemm_args& a) { return a.out_f32 ? ROLE_F32 : ROLE_LP; }
 
+int num_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  return cus / 8 * 8;
+}
+
 }  // namespace
+
+// Is a launch of `tiles` 256 x 256 tiles worth the persistent one-workgroup-per-CU grid?  At least one full round, and the last round of
+// the tile walk at least 80 % full (320 tiles on 256 CUs would leave three quarters of the chip idle for half of the launch; the 8-wave
+// kernel scores its three tile forms for such launches, f3r_gemm256_impl.h tile_score).
+bool f3r_gemm_asm_preferred(int64_t tiles) {
+  const int64_t cus = num_cus();
+  if (tiles < cus) return false;
+  const int64_t rounds = (tiles + cus - 1) / cus;
+  return tiles * 5 >= rounds * cus * 4;
+}
 
 // Can the hand-scheduled kernel take this (already validated) launch?  *why names the first obstacle.
 bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
@@ -110,9 +126,7 @@ int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, h
   k.tps_magic = k.tps > 1 ? (uint32_t)(((1ull << 32) + k.tps - 1) / k.tps) : 0;
   // persistent grid: one workgroup per CU (160 KiB of LDS, 512 registers per lane: one resident workgroup), a multiple of 8 so that a
   // workgroup's tiles stay on its XCD's contiguous run
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-  cus = cus / 8 * 8;
+  const int cus = num_cus();
   k.n_wg = n_wg;
   k.grid = n_wg < (uint32_t)cus ? n_wg : (uint32_t)cus;
   size_t size = sizeof(k);

@@ -357,8 +357,9 @@ def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None):
     p.eps = blk.norm1.eps
     p.qkv_w, p.qkv_b = ops.pack_linear_weight(blk.attn.qkv.weight.detach().float(), lp, split), _f32(blk.attn.qkv.bias)
     p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp, split), _f32(blk.attn.proj.bias)
-    # "high" keeps fc1 single-plane (fc1_split False): its output is rounded to ONE 16-bit number by the GELU epilogue anyway, and the stress
-    # models say its weight planes buy nothing (oracle/precision_study.py per-role run, DESIGN.md section 3 "Precision")
+    # fc1_split False = fc1 single-plane inside "high" (Fast3R.high_fc1_planes = False): measured +3.5 % views/s at N = 100 for TWICE the
+    # distance to the fp32 path on the real-size stress model (4.8e-4 / 6.1e-4 against 2.4e-4 / 2.8e-4), so it is an experiment knob, not
+    # the default (oracle/precision_study.py per-role run, DESIGN.md section 3 "Precision")
     p.fc1_split = bool(split) if fc1_split is None else bool(fc1_split)
     p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, p.fc1_split), _f32(blk.mlp.fc1.bias)
     p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp, split), _f32(blk.mlp.fc2.bias)
@@ -723,6 +724,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """split (hi + lo) weight planes and head activations: "high" and "exact"."""
         return self.precision in ("high", "exact")
 
+    high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
+
+    @property
+    def _fc1_split(self):
+        return None if (self.high_fc1_planes or self.precision != "high") else False
+
     @property
     def _sp(self):
         """split mode of the transformer's linear layers: weights only ("w2") in "high", both operands ("x3") in "exact"."""
@@ -760,7 +767,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:
             pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
             pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
-            pk["enc"] = [_pack_block(b, lp, hp, fc1_split=hp and self.precision == "exact") for b in enc.enc_blocks]
+            pk["enc"] = [_pack_block(b, lp, hp, fc1_split=self._fc1_split) for b in enc.enc_blocks]
             pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
@@ -769,7 +776,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
-            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=hp and self.precision == "exact") for b in dec.dec_blocks]
+            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=self._fc1_split) for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
         pk["head"] = _pack_head(self.downstream_head, lp, hp)
         pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None

@@ -143,7 +143,8 @@ typedef struct f3r_gemm_args {
                          6 = the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/gemm_gen.py: 4 waves x 128 x 128 outputs of
                          v_mfma_f32_32x32x16, five-slot LDS-DMA ring; ABI 310).  It takes plain GEMMs with the GENERIC epilogue, M and N multiples
                          of 256, K == Kpad (split NONE or W2), ONE output: fp32 (+ bias, + fp32 residual, no activation) or lowp (+ bias,
-                         + GELU / ReLU) -- F3R_ERR_UNSUPPORTED otherwise.  0 uses it for eligible launches of >= F3R_GEMM_ASM_MIN_TILES tiles;
+                         + GELU / ReLU), or F3R_EPI_QKV without rotary embedding and equal q / k / v widths (two launches) -- F3R_ERR_UNSUPPORTED otherwise.
+                         0 uses it for eligible launches whose 256 x 256 tiles fill its persistent grid (>= one tile per CU, last round >= 80 % full);
                          7 = pick by shape among the compiler-scheduled kernels only */
   const void* A_lo;
   /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
@@ -164,7 +165,6 @@ typedef struct f3r_gemm_args {
 
 typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_split;
 
-#define F3R_GEMM_ASM_MIN_TILES 512
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -54,6 +54,8 @@ def split2(x, dt):
 class Zone:
     mode = "f32"
     roles = {}   # per-role override inside the transformer zone: {"fc1" | "fc2" | "qkv" | "proj": mode} (a linear layer's role is read off its weight shape)
+    conv_roles = {}  # per-convolution override inside a DPT head: {call index inside dpt_forward: mode}; 0-6 act_postprocess, 7-10 layer_rn,
+    conv_idx = 0     # 11-13 refinenet4, 14-18 refinenet3, 19-23 refinenet2, 24-28 refinenet1 (4 RCU convs + out_conv), 29 head.0, 30 head.2, 31 head.4
 
 
 def linear_role(w):
@@ -69,6 +71,9 @@ def _apply(fn, a, w, *rest, **kw):
     mode = ZONE.mode
     if fn is F.linear and ZONE.roles and w.dim() == 2:
         mode = ZONE.roles.get(linear_role(w), mode)
+    if fn is not F.linear and w.dim() == 4:
+        mode = ZONE.conv_roles.get(ZONE.conv_idx, mode)
+        ZONE.conv_idx += 1
     store = mode.endswith("+store")
     base = mode.replace("+store", "")
     bias = rest[0] if rest else kw.pop("bias", None)
@@ -154,9 +159,10 @@ def attention_emul(x, sd, pre, num_heads, scale, xpos=None, rope_base=None, q_ch
 ATTN = {}
 
 
-def run_design(views, sd, args, tr, hd, attn=None, roles=None):
+def run_design(views, sd, args, tr, hd, attn=None, roles=None, conv_roles=None):
     enc, dec, head = args
     ZONE.roles = dict(roles or {})
+    ZONE.conv_roles = dict(conv_roles or {})
     ATTN.clear()
     if attn:
         ATTN.update(attn)
@@ -168,6 +174,7 @@ def run_design(views, sd, args, tr, hd, attn=None, roles=None):
     def dpt_zone(tokens4, *a, **k):
         prev = ZONE.mode
         ZONE.mode = hd
+        ZONE.conv_idx = 0
         if hd != "f32":  # the hooks reach the head as 16-bit rows (they are GEMM operands) unless the head is exact
             pass
         try:
@@ -183,6 +190,7 @@ def run_design(views, sd, args, tr, hd, attn=None, roles=None):
         O.F, O.attention, O.dpt_forward = saveF, saveA, orig_dpt
         ZONE.mode = "f32"
         ZONE.roles = {}
+        ZONE.conv_roles = {}
 
 
 def main():
