@@ -73,10 +73,11 @@ def parse(argv=None):
                     help="EMULATION, not a multi-GPU measurement: this one GPU runs exactly the work of rank R of --of W view-sharded ranks (its "
                          "views, local + remote attention launches over pre-filled K/V segments, parked softmax state) with no collective")
     ap.add_argument("--of", type=int, default=8, help="world size of the emulated job (--emulate-rank)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "p2p"],
-                    help="K/V exchange of the view-sharded path: one all-gather per tensor and layer + ONE remote attention launch, or pairwise "
-                         "rounds (dealt onto --p2p-channels communicators) + one remote launch per arrived shard; auto (default with --gpus > 1): "
-                         "three fusion layers with each form in the first warm-up forward, then the one that exposed less (fast3r_amd/dist.py)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "auto", "p2p"],
+                    help="K/V exchange of the view-sharded path: one all-gather per tensor and layer + ONE remote attention launch (default: the form "
+                         "whose every RCCL call has run on an MI355X, in a world of one rank), or pairwise rounds (dealt onto --p2p-channels "
+                         "communicators) + one remote launch per arrived shard; auto: three fusion layers with each form in the first warm-up "
+                         "forward, then the one that exposed less (fast3r_amd/dist.py; the per-peer form has only ever run over gloo)")
     ap.add_argument("--p2p-channels", type=int, default=3)
     return ap.parse_args(argv)
 
