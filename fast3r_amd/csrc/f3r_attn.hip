@@ -390,7 +390,7 @@ extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
   if (hd != 64) return "attn_generic_kernel (f3r_attn_generic.hip)";
   const char* why = "";
   if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why))
-    return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen2.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen2.py)";
+    return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
   return a.causal ? "attn_kernel<causal> (f3r_attn.hip)" : (a.batch > 1 ? "attn_kernel<batched> (f3r_attn.hip)" : "attn_kernel (f3r_attn.hip)");
 }
 

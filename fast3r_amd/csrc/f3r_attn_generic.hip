@@ -1,7 +1,7 @@
 // f3r_attn_fwd for head dimensions other than 64 (f3r_attn_args.head_dim: a multiple of 16 up to 128): the reference's Attention takes any
 // dim // num_heads (croco/models/blocks.py:113-143) and its own scaling ablation runs a head_dim-80 fusion decoder
 // (configs/experiment/model_scaling/model_scaling_huge.yaml:13-15: 1280 / 16 heads).  head_dim 64 -- every released checkpoint -- stays on
-// the tuned kernels (f3r_attn.hip, csrc/asm/attn_gen2.py); this one is the same math laid out for any width:
+// the tuned kernels (f3r_attn.hip, csrc/asm/attn_gen.py); this one is the same math laid out for any width:
 //   * workgroup = 4 waves x 64 queries (two 32-query blocks per wave: every K / V^T fragment read from LDS feeds two MFMAs; one block
 //     per wave above head_dim 96, where two sets of accumulators no longer fit the register file); 64-key
 //     tiles of K [64][HD] and V^T [HD][64] in LDS (padded rows, 16-byte vector accesses), the NEXT tile's global loads are issued into

@@ -38,9 +38,8 @@ def test_emulated_kernel_walks_segments_and_carries_the_softmax_state(tiles, spl
 
 @pytest.mark.parametrize("kw", [dict(tiles=1), dict(tiles=6, spike=True), dict(tiles=[2, 1, 3], spike=True), dict(tiles=[2, 3], split=True),
                                 dict(tiles=7, spike=True, gen=dict(pf=3, nslot=4)), dict(tiles=5, dtype="bf16", spike=True, tol=5e-3)])
-def test_emulated_second_layout(kw):
-    """attn_gen2.py (the softmax reference in the C operand of the first Q K^T k-step, one block of packed probabilities, P V issued
-    before Q K^T): same checks as the first layout"""
+def test_emulated_generator_settings(kw):
+    """further tile counts, segments, the two-launch state form, a deeper prefetch setting and bf16 on the same generator"""
     import emu_attn
     err = emu_attn.run_case(kw.get("dtype", "f16"), kw["tiles"], n_heads=2, wgs=((0, 1, 0),), spike=kw.get("spike", False),
                             split_state=kw.get("split", False), layout=2, gen_kwargs=kw.get("gen"))
@@ -71,10 +70,9 @@ def test_emulated_partial_last_workgroup(kw):
     assert err < kw.get("tol", 6e-4)
 
 
-@pytest.mark.parametrize("layout", [1, 2])
-def test_generated_text_assembles_and_has_no_hazards(tmp_path, layout):
+def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     import attn_gen
-    gens = attn_gen.product_generators(layout=layout)
+    gens = attn_gen.product_generators()
     for g in gens:
         assert g.p.check_hazards() == []
     clang = "/opt/rocm/lib/llvm/bin/clang"

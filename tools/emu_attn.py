@@ -33,7 +33,7 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=1, tq=None, counters=None):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2)"""
@@ -80,11 +80,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
     else:
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
-    if layout == 2:
-        import attn_gen2
-        g = attn_gen2.AttnGen2(dtype, rowsum=rowsum, **(gen_kwargs or {}))
-    else:
-        g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))
+    g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
@@ -123,7 +119,7 @@ if __name__ == "__main__":
     ap.add_argument("--rowsum", default="pkadd")
     ap.add_argument("--cvt", default="rne")
     ap.add_argument("--split-state", action="store_true")
-    ap.add_argument("--layout", type=int, default=1)
+    ap.add_argument("--layout", type=int, default=2)
     a = ap.parse_args()
     tiles = [int(x) for x in a.tiles.split(",")]
     run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout)

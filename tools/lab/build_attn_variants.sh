@@ -10,7 +10,7 @@ mkdir -p "$here/var"
 while [ $# -ge 2 ]; do
   name="$1"; flags="$2"; shift 2
   w="${TMPDIR:-/tmp}/f3r_var_$name"; mkdir -p "$w"
-  python3 "$src/asm/attn_gen.py" "$w/a.s" $flags
+  python3 "$src/asm/attn_gen.py" "$w/a.s" $flags   # (one generator since round 4; --layout is accepted and ignored)
   "$LLVM/clang" -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c "$w/a.s" -o "$w/a.o"
   "$LLVM/ld.lld" -shared "$w/a.o" -o "$w/a.hsaco"
   python3 - "$w/a.hsaco" "$w/blob.cpp" <<'PY'
@@ -25,7 +25,7 @@ with open(sys.argv[2], "w") as f:
 PY
   g++ -O1 -fPIC -std=c++17 -c "$w/blob.cpp" -o "$w/blob.o"
   objs=""
-  for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_attn f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_capi; do objs="$objs $src/obj/$f.o"; done
+  for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_gemm_asm f3r_gemm_asm_blob f3r_attn f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_capi; do objs="$objs $src/obj/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$w/blob.o" -o "$here/var/libf3r_$name.so"
   echo "built $here/var/libf3r_$name.so ($flags)"
 done
