@@ -1,5 +1,7 @@
-"""Kernel micro-benchmarks on the GPU box (interleaved rounds, random data, HIP events on the launch stream):
-attention variants on fusion / encoder shapes and the model's GEMM / conv shapes.  Prints one JSON line per item."""
+"""Kernel micro-benchmarks on the GPU box (interleaved rounds, random data, HIP events on the launch stream): the attention kernels
+f3r_attn_fwd can take (--what attnproduct / attnsel / attnhd) and the model's GEMM / conv shapes per f3r_gemm_args.kernel_sel, with the vendor
+library beside them (--what gemmref).  Prints one JSON line per item.  (--what lab / labtime: ablations of the 8-wave GEMM, need
+F3R_LAB_LIB=tools/lab/libf3r_hip_lab.so.)"""
 import argparse
 import math
 import json
@@ -11,18 +13,6 @@ sys.path.insert(0, ".")
 from fast3r_amd import _lib, ops  # noqa: E402
 
 DEV = "cuda"
-
-
-def lab_lib():
-    """Attention variants (f3r_attn_set_variant / f3r_attn_read_prof) and GEMM ablations exist only in tools/lab/libf3r_hip_lab.so:
-    run with F3R_LAB_LIB=$PWD/tools/lab/libf3r_hip_lab.so (built by tools/lab/build_lab.sh).  The product library has neither."""
-    import ctypes
-    l = _lib.lib()
-    if not hasattr(l, "f3r_attn_set_variant"):
-        sys.exit("attention variants need the lab library: F3R_LAB_LIB=tools/lab/libf3r_hip_lab.so (tools/lab/build_lab.sh)")
-    l.f3r_attn_set_variant.restype, l.f3r_attn_set_variant.argtypes = ctypes.c_int, [ctypes.c_int]
-    l.f3r_attn_read_prof.restype, l.f3r_attn_read_prof.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64)]
-    return l
 
 
 def time_ms(fn, rounds=5, inner=3):
@@ -37,54 +27,6 @@ def time_ms(fn, rounds=5, inner=3):
         best.append(e0.elapsed_time(e1) / inner)
     best.sort()
     return best[len(best) // 2], best[0]
-
-
-def bench_attn(dt, views, variants, H=16):
-    T = views * 1024
-    D = H * 64
-    q = torch.randn((T, D), device=DEV).to(dt)
-    k = torch.randn((T, D), device=DEV).to(dt)
-    vt = torch.randn((D, T), device=DEV).to(dt)
-    o = torch.empty((T, D), dtype=dt, device=DEV)
-    flops = 4.0 * T * T * 64 * H
-    res = {}
-    fns = {}
-    for v in variants:
-        def f(v=v):
-            lab_lib().f3r_attn_set_variant(v)
-            ops.attention(q, o, H, 0.160192, [(k, vt, T, 0, 0)])
-        fns[v] = f
-        f()
-    torch.cuda.synchronize()
-    ref = None
-    for v in variants:  # all variants must agree
-        fns[v]()
-        torch.cuda.synchronize()
-        cur = o.float().clone()
-        if ref is None:
-            ref = cur
-        else:
-            assert v >= 6 or float((cur - ref).abs().max()) < 2e-2, ("variant mismatch", v)
-    for rnd in range(3):  # interleaved
-        for v in variants:
-            med, mn = time_ms(fns[v], rounds=3, inner=2)
-            res.setdefault(v, []).append(med)
-    for v in variants:
-        ms = sorted(res[v])[1]
-        print(json.dumps({"kernel": "attn", "dtype": str(dt).split(".")[-1], "views": views, "T": T, "variant": v, "ms": round(ms, 3),
-                          "tflops": round(flops / ms / 1e9, 1)}), flush=True)
-    for v in variants:
-        if v in (34, 35, 38, 44, 61, 62, 64, 66, 84):
-            import ctypes
-            fns[v]()
-            torch.cuda.synchronize()
-            buf = (ctypes.c_uint64 * 8)()
-            lab_lib().f3r_attn_read_prof(buf)
-            n = max(1, buf[4])
-            print(json.dumps({"kernel": "attn_sections", "variant": v, "tiles": int(buf[4]), "cycles_per_tile": {
-                "qk": round(buf[0] / n), "softmax": round(buf[1] / n), "pv": round(buf[2] / n), "stage+barrier": round(buf[3] / n),
-                "whole_loop": round(buf[5] / n)}}), flush=True)
-    lab_lib().f3r_attn_set_variant(-1)
 
 
 def bench_attn_product(dt, views, H=16):
@@ -143,28 +85,6 @@ def bench_attn_head_dim(dt, views, hd, H=16):
     med, mn = time_ms(f, rounds=3, inner=2)
     print(json.dumps({"kernel": "attn_head_dim", "head_dim": hd, "dtype": str(dt).split(".")[-1], "views": views, "T": T, "ms": round(med, 3),
                       "tflops": round(4.0 * T * T * hd * H / med / 1e9, 1)}), flush=True)
-
-
-def bench_attn_encoder(dt, views, variants, H=16):
-    S, D = 1024, H * 64
-    q = torch.randn((views * S, D), device=DEV).to(dt)
-    k = torch.randn((views * S, D), device=DEV).to(dt)
-    vt = torch.randn((views, D, S), device=DEV).to(dt)
-    o = torch.empty_like(q)
-    flops = 4.0 * S * S * 64 * H * views
-    for v in variants:
-        def f():
-            lab_lib().f3r_attn_set_variant(v)
-            ops.attention(q, o, H, 0.125, [(k, vt, S, S * D, D * S)], tq=S, batch=views, q_batch_stride=S * D, o_batch_stride=S * D)
-        f()
-        med, mn = time_ms(f)
-        print(json.dumps({"kernel": "attn_encoder", "dtype": str(dt).split(".")[-1], "views": views, "variant": v, "ms": round(med, 3),
-                          "tflops": round(flops / med / 1e9, 1)}), flush=True)
-    lab_lib().f3r_attn_set_variant(-1)
-
-
-SEL_NAME = {0: "automatic", 1: "128-tile", 2: "256-tile persistent", 3: "256-tile lock-step", 4: "256x128-tile", 5: "256-tile one tile per workgroup",
-            6: "hand-scheduled (asm)"}
 
 
 def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
@@ -457,14 +377,12 @@ def bench_image(H=3000, W=4000, size=512, n=16):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="attn,gemm,conv")
-    ap.add_argument("--variants", default="24,72", help="attention variants; anything but 24 53 55 70 71 72 84 needs a -DF3R_ATTN_LAB build")
+    ap.add_argument("--what", default="gemm,conv")
     ap.add_argument("--views", default="20,100")
     ap.add_argument("--attn-dtypes", default="bf16,fp16", help="attnproduct: which operand formats")
     ap.add_argument("--sels", default="1,2", help="attnsel: f3r_attn_args.kernel_sel values to time")
     ap.add_argument("--tokens-per-view", type=int, default=1024, help="attnsel: 768 = 384x512 images (an odd view count gives a partial last workgroup)")
     args = ap.parse_args()
-    variants = [int(v) for v in args.variants.split(",")]
     dt = torch.bfloat16
     if args.what == "gemmsmall":  # scenes of 3 - 40 views: which tile form fills 256 CUs best
         for M in (3072, 8192, 20480, 40960):
@@ -514,16 +432,6 @@ if __name__ == "__main__":
             for d in (args.attn_dtypes.split(",")):
                 bench_attn_sel({"bf16": torch.bfloat16, "fp16": torch.float16}[d], nv, sels=tuple(int(x) for x in args.sels.split(",")), tokens_per_view=args.tokens_per_view)
         sys.exit(0)
-    if args.what == "attnonly":
-        for nv in [int(v) for v in args.views.split(",")]:
-            bench_attn(torch.bfloat16, nv, variants)
-            bench_attn(torch.float16, nv, variants)
-        sys.exit(0)
-    if "attn" in args.what:
-        for nv in [int(v) for v in args.views.split(",")]:
-            bench_attn(dt, nv, variants)
-        bench_attn(torch.float16, 20, variants[:3])
-        bench_attn_encoder(dt, 64, variants)
     if args.what == "labtime":
         M = 40 * 1024
         for bits in (128, 384, 640):
