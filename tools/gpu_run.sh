@@ -36,6 +36,33 @@ json.dump(out, open(f"{d}/gemm_asm_pmc.json", "w"), indent=1)
 PY
       find $d/pmc -name "*kernel_trace.csv" -delete
       fi ;;
+    attnl2)     # L2 hit / miss / fabric read requests of the fusion-attention kernel at N = 320, fp16 vs bf16 (why fp16 fetches 2-3x the tiling floor)
+      rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u | tr "\n" " " > $d/tcc_counters.txt
+      for V in fp16 bf16; do
+        ( cd /tmp; PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $OLDPWD/$d/p_$V --output-format csv -- python $OLDPWD/tools/kernel_bench.py --what attnsel --attn-dtypes $V --views 320 --sels 2 > $OLDPWD/$d/p_$V.log 2>&1 )
+      done
+      python - $d <<'PY'
+import csv, glob, sys, json, collections
+d = sys.argv[1]
+out = {}
+for V in ("fp16", "bf16"):
+    fs = glob.glob(f"{d}/p_{V}/*/*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    per_disp = collections.defaultdict(dict)
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if "attn" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                per_disp[r.get("Dispatch_Id", "?")][r["Counter_Name"]] = float(r["Counter_Value"])
+    v = {k: sum(x) / len(x) for k, x in acc.items()}
+    if v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None:
+        v["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    v["per_dispatch_miss"] = [int(x.get("TCC_MISS_sum", -1)) for x in per_disp.values()]
+    out[V] = v
+    print(V, {k: (round(x, 4) if isinstance(x, float) and x < 10 else x) for k, x in v.items()})
+json.dump(out, open(f"{d}/attn_l2.json", "w"), indent=1)
+PY
+      find $d -name "*kernel_trace.csv" -delete ;;
     gputests)   # the whole GPU suite + smoke
       timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;
