@@ -63,6 +63,8 @@ for V in ("fp16", "bf16"):
 json.dump(out, open(f"{d}/attn_l2.json", "w"), indent=1)
 PY
       find $d -name "*kernel_trace.csv" -delete ;;
+    attnpmc)    # matrix-pipe utilisation + effective clock + FETCH / WRITE of the fusion attention at N = 320, both formats (tools/pmc_attn_util.sh)
+      timeout 900 bash tools/pmc_attn_util.sh 2 320 > $d/pmc.log 2>&1; tail -3 $d/pmc.log | cut -c1-600; cp gpurun_out/pmc_attn/attn_mfma_util.json gpurun_out/pmc_attn/attn_traffic_new.json $d/ 2>/dev/null ;;
     gputests)   # the whole GPU suite + smoke
       timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 PMC evidence for the fusion-attention kernel at T = 327 680 (N = 320), both operand formats, kernel_sel as given (default 2 =
+# PMC evidence for the fusion-attention kernel at T = 327 680 (N = 320), both operand formats, kernel_sel as given (default 2 =
 # the hand-scheduled kernel): matrix-pipe utilisation in cycles + effective clock (one pass), FETCH_SIZE and WRITE_SIZE (separate passes,
-# MI355X_MICROARCH.md "HBM").  Writes gpurun_out/pmc_r03/r03_attn_mfma_util.json and gpurun_out/pmc_r03/attn_traffic_r03.json.
+# MI355X_MICROARCH.md "HBM").  Writes gpurun_out/pmc_r03/attn_mfma_util.json and gpurun_out/pmc_r03/attn_traffic_new.json.
 SEL=${1:-2}; VIEWS=${2:-320}
-out=gpurun_out/pmc_r03; mkdir -p $out
+out=gpurun_out/pmc_attn; mkdir -p $out
 export TMPDIR=/tmp
 for V in fp16 bf16; do
   CMD="python tools/kernel_bench.py --what attnsel --attn-dtypes $V --views $VIEWS --sels $SEL"
@@ -14,7 +14,7 @@ done
 python - <<PY
 import csv, glob, json, collections
 out = "$out"
-res = {"_doc": "rocprofv3 --kernel-trace --pmc (tools/pmc_r03_attn.sh) over tools/kernel_bench.py --what attnsel --sels $SEL at T = %d (N = $VIEWS): the fusion-attention kernel f3r_attn_fwd takes for that shape (kernel_sel $SEL).  mfma_util_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); mfma_util_useful_cycles = the algorithm's 32x32x16 MFMA instructions x 32 pipe cycles over the same denominator (layout 2 of the hand-scheduled kernel issues no other MFMA, so the two agree; layout 1 and the HIP kernel spend extra pipe cycles on bias steps); effective clock = GRBM_GUI_ACTIVE/8/duration.  Profiled runs clock a few per cent below plain ones." % ($VIEWS * 1024), "formats": {}}
+res = {"_doc": "rocprofv3 --kernel-trace --pmc (tools/pmc_attn_util.sh) over tools/kernel_bench.py --what attnsel --sels $SEL at T = %d (N = $VIEWS): the fusion-attention kernel f3r_attn_fwd takes for that shape (kernel_sel $SEL).  mfma_util_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); mfma_util_useful_cycles = the algorithm's 32x32x16 MFMA instructions x 32 pipe cycles over the same denominator (layout 2 of the hand-scheduled kernel issues no other MFMA, so the two agree; layout 1 and the HIP kernel spend extra pipe cycles on bias steps); effective clock = GRBM_GUI_ACTIVE/8/duration.  Profiled runs clock a few per cent below plain ones." % ($VIEWS * 1024), "formats": {}}
 traffic = {}
 for V in ("fp16", "bf16"):
     def counters(tag):
@@ -46,8 +46,8 @@ for V in ("fp16", "bf16"):
     f, _ = counters("f")
     w, _ = counters("w")
     traffic[V] = {"FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "bytes": (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024, "kernel": names}
-json.dump(res, open(f"{out}/r03_attn_mfma_util.json", "w"), indent=1)
-json.dump(traffic, open(f"{out}/attn_traffic_r03.json", "w"), indent=1)
+json.dump(res, open(f"{out}/attn_mfma_util.json", "w"), indent=1)
+json.dump(traffic, open(f"{out}/attn_traffic_new.json", "w"), indent=1)
 print(json.dumps({V: {k: res["formats"][V][k] for k in ("avg_dispatch_ms", "mfma_util_cycles", "mfma_util_useful_cycles", "effective_clock_ghz", "tflops_profiled")} for V in res["formats"]}))
 print(json.dumps(traffic))
 PY
