@@ -35,6 +35,7 @@ def build(extra=None):
         subprocess.run([f"{LLVM}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", s[:-2] + ".o"], check=True)
         subprocess.run([f"{LLVM}/ld.lld", "-shared", s[:-2] + ".o", "-o", s[:-2] + ".hsaco"], check=True)
         os.remove(s[:-2] + ".o")
+        os.remove(s)   # (generated text: the .hsaco is what travels to the GPU box; neither is tracked)
         print("built", s[:-2] + ".hsaco")
 
 
