@@ -387,10 +387,13 @@ extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
   if (!args) return "";
   const f3r_attn_args& a = *args;
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
-  if (hd != 64) return "attn_generic_kernel (f3r_attn_generic.hip)";
   const char* why = "";
-  if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why))
+  if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) {
+    if (hd == 80) return a.dtype == F3R_F16 ? "f3r_attn_asm_d80_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d80_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
+    if (hd == 128) return a.dtype == F3R_F16 ? "f3r_attn_asm_d128_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d128_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
     return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
+  }
+  if (hd != 64) return "attn_generic_kernel (f3r_attn_generic.hip)";
   return a.causal ? "attn_kernel<causal> (f3r_attn.hip)" : (a.batch > 1 ? "attn_kernel<batched> (f3r_attn.hip)" : "attn_kernel (f3r_attn.hip)");
 }
 
@@ -430,10 +433,6 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 2, "f3r_attn_fwd: kernel_sel %d", a.kernel_sel);
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (hd != 64) {
-    F3R_REQUIRE(a.kernel_sel != 2, "f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) is built for head_dim 64");
-    return f3r_attn_generic_launch(a, s);
-  }
   if (a.kernel_sel != 1) {  // the hand-scheduled one-wave-per-SIMD kernel where the launch allows it (include/f3r.h)
     const char* why = "";
     if (f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) return f3r_attn_asm_launch(a, s);
@@ -442,5 +441,6 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
       return F3R_ERR_UNSUPPORTED;
     }
   }
+  if (hd != 64) return f3r_attn_generic_launch(a, s);
   return a.dtype == F3R_F16 ? attn_launch<F16>(a, s) : attn_launch<BF16>(a, s);
 }

@@ -3,6 +3,7 @@
 // hipModuleLaunchKernel on the caller's stream (capturable in a hipGraph like any other launch).  f3r_attn_fwd (f3r_attn.hip)
 // decides per call whether a launch goes here (f3r_attn_args.kernel_sel, include/f3r.h).
 #include <cstddef>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -40,28 +41,46 @@ static_assert(sizeof(f3r_attn_asm_args) == 312 && offsetof(f3r_attn_asm_args, se
 
 // The code object is loaded once per DEVICE (hipModule handles are per device context): the only process-wide state of the library
 // besides the per-thread error string.  Any device index: the table grows on demand.
+// The generated kernels: head_dim 64 (512 queries per workgroup), 80 and 128 (256 queries per workgroup); HEAD_DIMS of attn_gen.py
+constexpr int kNumHd = 3;
+constexpr int kHd[kNumHd] = {64, 80, 128};
+int hd_index(int hd) {
+  for (int i = 0; i < kNumHd; ++i)
+    if (kHd[i] == hd) return i;
+  return -1;
+}
+int wave_rows(int hd) { return hd == 64 ? 128 : 64; }  // query rows of a wave (32 x the query blocks per wave)
+
 struct DevKernels {
   bool tried = false;
   hipModule_t mod = nullptr;
-  hipFunction_t fn[2] = {nullptr, nullptr};  // F3R_F16, F3R_BF16
+  hipFunction_t fn[kNumHd][2] = {};  // [head_dim index][F3R_F16, F3R_BF16]
 };
 std::map<int, DevKernels> g_dev;
 std::mutex g_mu;
 
-hipFunction_t get_fn(int dtype) {
+hipFunction_t get_fn(int dtype, int hd) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1) return nullptr;
+  const int hi = hd_index(hd);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1 || hi < 0) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevKernels& d = g_dev[dev];
   if (!d.tried) {
     d.tried = true;
     if (hipModuleLoadData(&d.mod, f3r_attn_asm_hsaco) == hipSuccess) {
-      if (hipModuleGetFunction(&d.fn[F3R_F16], d.mod, "f3r_attn_asm_f16") != hipSuccess) d.fn[F3R_F16] = nullptr;
-      if (hipModuleGetFunction(&d.fn[F3R_BF16], d.mod, "f3r_attn_asm_bf16") != hipSuccess) d.fn[F3R_BF16] = nullptr;
+      for (int i = 0; i < kNumHd; ++i)
+        for (int t = 0; t < 2; ++t) {
+          char name[48];
+          if (kHd[i] == 64)
+            snprintf(name, sizeof(name), "f3r_attn_asm_%s", t == F3R_F16 ? "f16" : "bf16");
+          else
+            snprintf(name, sizeof(name), "f3r_attn_asm_d%d_%s", kHd[i], t == F3R_F16 ? "f16" : "bf16");
+          if (hipModuleGetFunction(&d.fn[i][t], d.mod, name) != hipSuccess) d.fn[i][t] = nullptr;
+        }
     }
     (void)hipGetLastError();
   }
-  return d.fn[dtype];
+  return d.fn[hi][dtype];
 }
 
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -72,9 +91,12 @@ bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why) {
   static const char* none = "";
   *why = none;
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  if (hd_index(hd) < 0) { *why = "no generated kernel for this head_dim (64, 80, 128)"; return false; }
+  const int64_t wrows = wave_rows(hd);
   if (a.causal) { *why = "causal mask"; return false; }
   if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
-  if (a.tq < 128) { *why = "fewer than 128 query rows"; return false; }
+  if (a.tq < wrows) { *why = "fewer query rows than one wave takes (128 at head_dim 64, 64 otherwise)"; return false; }
   if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return false; }
   if ((a.state_in || a.state_out) && a.batch != 1) { *why = "carried softmax state with batch > 1"; return false; }
   int first = -1;
@@ -92,21 +114,22 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   if (first < 0) { *why = "no keys"; return false; }
   if (keys < min_keys) { *why = "fewer keys than F3R_ATTN_ASM_MIN_KEYS"; return false; }
   if (keys / 64 >= (1ll << 31)) { *why = "too many keys"; return false; }
-  // 32-bit lane offsets: 128 query rows, 64 key rows, 64 V^T rows must span < 4 GiB
-  if (128 * a.ldq * 2 >= (1ll << 32) || 128 * a.ldo * 2 >= (1ll << 32) || 64 * a.ldk * 2 >= (1ll << 32) || 64 * a.ldvt[first] * 2 >= (1ll << 32) ||
-      (int64_t)128 * a.n_heads * 256 >= (1ll << 32)) {
+  // 32-bit lane offsets: a wave's query rows, 64 key rows, head_dim V^T rows must span < 4 GiB
+  if (wrows * a.ldq * 2 >= (1ll << 32) || wrows * a.ldo * 2 >= (1ll << 32) || 64 * a.ldk * 2 >= (1ll << 32) || (int64_t)hd * a.ldvt[first] * 2 >= (1ll << 32) ||
+      wrows * a.n_heads * hd * 4 >= (1ll << 32)) {
     *why = "row strides too large for 32-bit lane offsets";
     return false;
   }
   if (a.tq >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
   // a code object that does not load on this device makes the launch INELIGIBLE (kernel_sel 0 then takes the general HIP kernel,
   // kernel_sel 2 reports why) instead of failing every fusion-attention call of the process
-  if (get_fn(a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  if (get_fn(a.dtype, hd) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }
 
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
-  hipFunction_t fn = get_fn(a.dtype);
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  hipFunction_t fn = get_fn(a.dtype, hd);
   if (!fn) {
     f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");
     return F3R_ERR_LAUNCH;
@@ -126,7 +149,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   k.flags = (a.state_in ? 1u : 0u) | (a.state_out ? 2u : 0u);
   k.st_o = a.st_o;
   k.st_ml = a.st_ml;
-  k.st_o_ld_b = (uint32_t)a.n_heads * 256u;
+  k.st_o_ld_b = (uint32_t)a.n_heads * (uint32_t)hd * 4u;
   k.st_ml_ld_b = (uint32_t)a.n_heads * 16u;
   k.tq = (uint32_t)a.tq;
   k.dbg = a.dbg_counters;
@@ -143,7 +166,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   }
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((a.tq + 511) / 512), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
+  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((a.tq + 4 * wave_rows(hd) - 1) / (4 * wave_rows(hd))), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
     f3r_set_error("f3r_attn_fwd: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
     return F3R_ERR_LAUNCH;

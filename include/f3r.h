@@ -239,9 +239,10 @@ typedef struct f3r_attn_args {
        1 = the general HIP kernel;  2 = the hand-scheduled kernel (F3R_ERR_UNSUPPORTED if the launch is not eligible). */
   int32_t kernel_sel;
   /* Width of a head: 0 or 64 = the tuned kernels; any other multiple of 16 up to 128 (the reference's Attention takes any dim //
-     num_heads, blocks.py:113-143; its model_scaling_huge.yaml fusion decoder has 80) runs the generic kernel (f3r_attn_generic.hip):
-     same layouts with head_dim columns per head (q / k / o rows, head_dim V^T planes per head, st_o rows of n_heads * head_dim),
-     no causal mask. */
+     num_heads, blocks.py:113-143; its model_scaling_huge.yaml fusion decoder has 80): same layouts with head_dim columns per head
+     (q / k / o rows, head_dim V^T planes per head, st_o rows of n_heads * head_dim), no causal mask.  80 and 128 have hand-scheduled
+     kernels of their own (csrc/asm/attn_gen.py: 256-query workgroups, 64 queries per wave; eligibility as for kernel_sel 0 below
+     with tq >= 64); everything else, and launches those kernels cannot take, run the generic kernel (f3r_attn_generic.hip). */
   int32_t head_dim;
   /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310): device uint32[4], zeroed by the caller; every wave of a launch
      that takes that kernel adds {entries into the block that moves the softmax reference (the forced first one included), 1, 64-key

@@ -70,6 +70,31 @@ def test_emulated_partial_last_workgroup(kw):
     assert err < kw.get("tol", 6e-4)
 
 
+@pytest.mark.parametrize("hd", [80, 128])
+@pytest.mark.parametrize("kw", [dict(n_tiles=1), dict(n_tiles=3), dict(n_tiles=5, spike=True), dict(dtype="bf16", n_tiles=4, spike=True, tol=5e-3),
+                                dict(n_tiles=[2, 1, 3], spike=True), dict(n_tiles=[2, 3], split_state=True), dict(tq=300, q_blocks=2, wgs=((1, 0, 0), (0, 1, 0))),
+                                dict(tq=64, wgs=((0, 0, 0),), n_tiles=2), dict(kv_shift=1, n_heads=4, batch=2, wgs=((0, 3, 1),))])
+def test_emulated_other_head_dims(hd, kw):
+    """AttnGen(head_dim=80 / 128): two query blocks per wave, D / 16 k-steps, ceil(D / 32) O^T blocks (80: the 16-column K remainder group, the mixed
+    LDS-DMA piece, the zeroed V^T padding rows); tiles, segments, the two-launch state form, partial workgroups, grouped heads + batch"""
+    import emu_attn
+    kw = dict(kw)
+    tol = kw.pop("tol", 6e-4)
+    assert emu_attn.run_case(head_dim=hd, **kw) < tol
+
+
+def test_head_dim_64_stream_is_what_it_was_before_the_other_widths():
+    """the generalisation must not move one instruction of the benchmarked kernel: a digest of the head_dim-64 program text"""
+    import hashlib
+    import attn_gen
+    gens = []
+    for dt in ("f16", "bf16"):
+        g = attn_gen.AttnGen(dt)
+        g.build()
+        gens.append(g)
+    assert hashlib.md5(attn_gen.module_text(gens).encode()).hexdigest() == "72c84f999168208f840cd8a4139b71b6"
+
+
 def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     import attn_gen
     gens = attn_gen.product_generators()

@@ -31,28 +31,29 @@ def assert_close(got, ref, tol, what=""):
     assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol:.1e})"
 
 
-def ref_prescaled(qs, k, v, H, Hkv=None):
+def ref_prescaled(qs, k, v, H, Hkv=None, hd=64):
     """qs already holds q * scale * log2(e) (rounded to lowp): softmax in base 2 over the rounded operands, fp64."""
     Hkv = Hkv or H
     Tq = qs.shape[0]
-    qh = qs.double().reshape(Tq, H, 64).transpose(0, 1)
-    kh = k.double().reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
-    vh = v.double().reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    qh = qs.double().reshape(Tq, H, hd).transpose(0, 1)
+    kh = k.double().reshape(-1, Hkv, hd).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    vh = v.double().reshape(-1, Hkv, hd).transpose(0, 1).repeat_interleave(H // Hkv, 0)
     s = (qh @ kh.transpose(1, 2)) * math.log(2.0)
-    return (s.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+    return (s.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * hd)
 
 
-def vt_of(v, Hkv):
+def vt_of(v, Hkv, hd=64):
     T = v.shape[0]
-    vt = torch.zeros((Hkv * 64, ops.vt_ld(T)), dtype=v.dtype)
+    vt = torch.zeros((Hkv * hd, ops.vt_ld(T)), dtype=v.dtype)
     vt[:, :T] = v.t()
     return vt
 
 
-def run(qs, k, v, H, Hkv=None, sel=2):
+def run(qs, k, v, H, Hkv=None, sel=2, hd=64):
     Hkv = Hkv or H
-    o = torch.full((qs.shape[0], H * 64), float("nan"), dtype=qs.dtype, device=DEV)
-    ops.attention(qs.to(DEV), o, H, 1.0, [(k.to(DEV), vt_of(v, Hkv).to(DEV), k.shape[0], 0, 0)], q_prescaled=True, kv_group=H // Hkv, kernel_sel=sel)
+    o = torch.full((qs.shape[0], H * hd), float("nan"), dtype=qs.dtype, device=DEV)
+    ops.attention(qs.to(DEV), o, H, 1.0, [(k.to(DEV), vt_of(v, Hkv, hd).to(DEV), k.shape[0], 0, 0)], q_prescaled=True, kv_group=H // Hkv, kernel_sel=sel,
+                  head_dim=hd)
     return o
 
 
@@ -193,3 +194,112 @@ def test_asm_kernel_full_size_rows_sum_to_one(built_lib):
     v = torch.full((Tk, H * 64), 0.75, dtype=dt)
     o = run(qs, k, v, H)
     assert_close(o.float(), torch.full((Tq, H * 64), 0.75), 2.0 ** -10, "rows sum to one")
+
+
+# ---- head_dim 80 / 128: the same generator with two query blocks per wave (256-query workgroups; AttnGen(head_dim=...))
+HDS = [80, 128]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd", HDS)
+@pytest.mark.parametrize("Tq,Tk,H", [(256, 64, 1), (256, 128, 2), (512, 192, 2), (256, 1024, 3), (768, 4096, 2), (64, 256, 1), (200, 192, 2), (1000, 320, 1),
+                                     (2304 + 60, 1024, 2)])
+def test_asm_kernel_other_head_dims_vs_fp64(built_lib, dt, hd, Tq, Tk, H):
+    """head_dim 80 (5 k-steps of Q K^T, a third O^T block of which 16 rows exist, the mixed LDS-DMA piece) and 128 (two 64-column K groups, four
+    O^T blocks): against fp64 on the same rounded operands and against the generic HIP kernel, incl. partial last workgroups (tq not a
+    multiple of 256) and a single-wave launch (tq = 64)"""
+    sc = hd ** -0.5 * LOG2E * 1.5
+    qs = rnd((Tq, H * hd), dt, 1, sc)
+    k, v = rnd((Tk, H * hd), dt, 2, 1.5), rnd((Tk, H * hd), dt, 3)
+    o = run(qs, k, v, H, hd=hd)
+    assert_close(o.float(), ref_prescaled(qs, k, v, H, hd=hd), 2 * lp_tol(dt), f"asm attn hd {hd} {Tq}x{Tk}")
+    gen = run(qs, k, v, H, sel=1, hd=hd)
+    assert_close(o.float(), gen.float().cpu(), 2 * lp_tol(dt), "asm vs generic kernel")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd", HDS)
+def test_asm_kernel_other_head_dims_forced_rebase(built_lib, dt, hd):
+    Tq, Tk, H = 256, 1280, 1
+    q = rnd((Tq, hd), dt, 10).float()
+    k, v = rnd((Tk, hd), dt, 11, 0.3), rnd((Tk, hd), dt, 12)
+    k[900] = (q[7] * 3.0).to(dt)
+    k[130] = (q[200] * 2.0).to(dt)
+    k[1279] = (q[255] * 4.0).to(dt)     # in the very last half tile
+    k[33] = (q[100] * 2.5).to(dt)       # second half of the first tile
+    qs = (q * (hd ** -0.5 * LOG2E)).to(dt)
+    o = run(qs, k, v, H, hd=hd)
+    assert torch.isfinite(o.float()).all()
+    assert_close(o.float(), ref_prescaled(qs, k, v, H, hd=hd), 2 * lp_tol(dt), "forced rebase")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd", HDS)
+def test_asm_kernel_other_head_dims_grouped_query_and_batch(built_lib, dt, hd):
+    nb, Tq, Tk, H, Hkv = 2, 512, 320, 4, 2
+    D, Dk = H * hd, Hkv * hd
+    qs = rnd((nb * Tq, D), dt, 20, hd ** -0.5 * LOG2E * 1.5)
+    k, v = rnd((nb * Tk, Dk), dt, 21, 1.5), rnd((nb * Tk, Dk), dt, 22)
+    ld = ops.vt_ld(Tk)
+    vt = torch.zeros((nb, Dk, ld), dtype=dt)
+    for b in range(nb):
+        vt[b, :, :Tk] = v[b * Tk:(b + 1) * Tk].t()
+    o = torch.full((nb * Tq, D), float("nan"), dtype=dt, device=DEV)
+    ops.attention(qs.to(DEV), o, H, 1.0, [(k.to(DEV), vt.to(DEV), Tk, Tk * Dk, Dk * ld)], tq=Tq, batch=nb, q_batch_stride=Tq * D, o_batch_stride=Tq * D,
+                  q_prescaled=True, kv_group=2, kernel_sel=2, head_dim=hd)
+    ref = torch.cat([ref_prescaled(qs[b * Tq:(b + 1) * Tq], k[b * Tk:(b + 1) * Tk], v[b * Tk:(b + 1) * Tk], H, Hkv, hd=hd) for b in range(nb)])
+    assert_close(o.float(), ref, 2 * lp_tol(dt), "gqa + batch")
+
+
+@pytest.mark.parametrize("Tq", [512, 512 + 200])
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd", HDS)
+def test_asm_kernel_other_head_dims_segments_and_carried_state(built_lib, dt, hd, Tq):
+    """K/V segments in one launch, and the two-launch form with the state parked in between -- by this kernel alone and with the generic HIP
+    kernel taking either launch (one state layout: st_o rows of n_heads * head_dim)"""
+    H = 2
+    lens = [192, 64, 320, 128]
+    qs = rnd((Tq, H * hd), dt, 70, hd ** -0.5 * LOG2E * 1.5)
+    ks = [rnd((n, H * hd), dt, 71 + i, 1.5) for i, n in enumerate(lens)]
+    vs = [rnd((n, H * hd), dt, 81 + i) for i, n in enumerate(lens)]
+    ld = ops.vt_ld(max(lens))
+
+    def vt_pad(v):
+        vt = torch.zeros((H * hd, ld), dtype=dt)
+        vt[:, :v.shape[0]] = v.t()
+        return vt
+    segs = [(kk.to(DEV), vt_pad(vv).to(DEV), n, 0, 0) for kk, vv, n in zip(ks, vs, lens)]
+    ref = ref_prescaled(qs, torch.cat(ks), torch.cat(vs), H, hd=hd)
+    q = qs.to(DEV)
+    one = torch.full((Tq, H * hd), float("nan"), dtype=dt, device=DEV)
+    ops.attention(q, one, H, 1.0, segs, q_prescaled=True, kernel_sel=2, head_dim=hd)
+    assert_close(one.float(), ref, 2 * lp_tol(dt), "segments, one launch")
+    for sel_local, sel_remote in ((2, 2), (2, 1), (1, 2)):
+        two = torch.full((Tq, H * hd), float("nan"), dtype=dt, device=DEV)
+        state = ops.attention_state(Tq, H, DEV, head_dim=hd)
+        ops.attention(q, two, H, 1.0, segs[:1], q_prescaled=True, state=state, state_out=True, kernel_sel=sel_local, head_dim=hd)
+        assert torch.isnan(two.float()).all()  # the first launch must not write the output
+        ops.attention(q, two, H, 1.0, segs[1:], q_prescaled=True, state=state, state_in=True, kernel_sel=sel_remote, head_dim=hd)
+        assert_close(two.float(), ref, 2 * lp_tol(dt), f"state carry, kernels {sel_local} -> {sel_remote}")
+
+
+@pytest.mark.parametrize("hd", HDS)
+def test_asm_kernel_other_head_dims_automatic_choice_and_full_size_rows(built_lib, hd):
+    """kernel_sel 0 takes the generated kernel from F3R_ATTN_ASM_MIN_KEYS keys on (bit-identical to kernel_sel 2), the generic kernel below and
+    for what the generated kernel cannot do; 65 536 keys with V = const: every output is that constant (any dropped / duplicated tile, a
+    stale LDS slot or an unzeroed V^T padding row breaks it)"""
+    dt = torch.float16
+    H, Tq, Tk = 2, 512, 65536
+    qs, k = rnd((Tq, H * hd), dt, 40, 0.3), rnd((Tk, H * hd), dt, 41)
+    v = torch.full((Tk, H * hd), 0.75, dtype=dt)
+    o = run(qs, k, v, H, hd=hd)
+    assert_close(o.float(), torch.full((Tq, H * hd), 0.75), 2.0 ** -10, "rows sum to one")
+    assert torch.equal(run(qs, k[:2048], v[:2048], H, sel=0, hd=hd), run(qs, k[:2048], v[:2048], H, sel=2, hd=hd))
+    with pytest.raises(ValueError, match="not eligible"):
+        run(qs[:40], k[:2048], v[:2048], H, sel=2, hd=hd)  # fewer than 64 query rows
+    small = run(qs[:40], k[:2048], v[:2048], H, sel=0, hd=hd)  # ... which the generic kernel takes
+    assert_close(small.float(), torch.full((40, H * hd), 0.75), 2.0 ** -10, "generic kernel")
+    with pytest.raises(ValueError, match="not eligible"):
+        o96 = torch.empty((Tq, H * 96), dtype=dt, device=DEV)
+        ops.attention(rnd((Tq, H * 96), dt, 1).to(DEV), o96, H, 1.0, [(rnd((64, H * 96), dt, 2).to(DEV), torch.zeros((H * 96, 64), dtype=dt, device=DEV), 64, 0, 0)],
+                      q_prescaled=True, kernel_sel=2, head_dim=96)   # no generated kernel for 96

@@ -33,18 +33,21 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2)"""
     rng = np.random.default_rng(seed)
+    HD = head_dim
+    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
+    WQ = g.WG_Q   # query rows of a workgroup (512 at head_dim 64, 256 otherwise)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
-    tq, tk = (512 * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
-    D = n_heads * 64
+    tq, tk = (WQ * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
+    D = n_heads * HD
     kv_heads = n_heads >> kv_shift
-    Dk = kv_heads * 64
+    Dk = kv_heads * HD
     LOG2E = 1.4426950408889634
-    scale = 0.125
+    scale = HD ** -0.5
     q = rng.standard_normal((batch, tq, D)).astype(np.float32) * 1.5
     k = rng.standard_normal((batch, tk, Dk)).astype(np.float32) * 1.5
     v = rng.standard_normal((batch, tk, Dk)).astype(np.float32)
@@ -80,7 +83,6 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
     else:
         launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
-    g = attn_gen.AttnGen(dtype, rowsum=rowsum, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
@@ -94,14 +96,14 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         og = mem.get(a_o, np.uint16, (batch, tq, D))
         x, head, b = wg
         kvh = head >> kv_shift
-        r1 = min(tq, (x + 1) * 512)
-        qf = half_to_f32(qh[b, x * 512:r1, head * 64:(head + 1) * 64], dtype).astype(np.float64)
-        kf = half_to_f32(kh[b, :, kvh * 64:(kvh + 1) * 64], dtype).astype(np.float64)
-        vf = half_to_f32(vth_all[b, kvh * 64:(kvh + 1) * 64, :], dtype).astype(np.float64).T
+        r1 = min(tq, (x + 1) * WQ)
+        qf = half_to_f32(qh[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
+        kf = half_to_f32(kh[b, :, kvh * HD:(kvh + 1) * HD], dtype).astype(np.float64)
+        vf = half_to_f32(vth_all[b, kvh * HD:(kvh + 1) * HD, :], dtype).astype(np.float64).T
         s = qf @ kf.T
         p = np.exp2(s - s.max(axis=1, keepdims=True))
         ref = (p @ vf) / p.sum(axis=1, keepdims=True)
-        got = half_to_f32(og[b, x * 512:r1, head * 64:(head + 1) * 64], dtype).astype(np.float64)
+        got = half_to_f32(og[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
         worst = max(worst, err)
         print(f"wg {wg}: {steps} instructions, rel-L2 {err:.3e}, max abs {np.abs(got - ref).max():.3e}, nan {np.isnan(got).sum()}")
@@ -120,6 +122,7 @@ if __name__ == "__main__":
     ap.add_argument("--cvt", default="rne")
     ap.add_argument("--split-state", action="store_true")
     ap.add_argument("--layout", type=int, default=2)
+    ap.add_argument("--head-dim", type=int, default=64)
     a = ap.parse_args()
     tiles = [int(x) for x in a.tiles.split(",")]
-    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout)
+    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout, head_dim=a.head_dim)

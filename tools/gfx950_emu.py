@@ -454,6 +454,16 @@ class Wave:
                 self.file(dst.kind)[dst.idx:dst.idx + 4] = data
             self.lgkm.append(land)
             return
+        if op == "ds_write_b128":
+            addr = self.rd(a[0]).astype(np.int64) + int(it.mods.get("offset", 0) or 0)
+            src = a[1]
+            assert src.n == 4 and np.all(addr % 16 == 0) and addr.max() + 16 <= len(lds), "ds_write_b128 address"
+            data = self.file(src.kind)[src.idx:src.idx + 4].copy()  # [4][64]
+            for lane in range(64):
+                if (self.exec >> lane) & 1:
+                    lds[addr[lane]:addr[lane] + 16] = data[:, lane].copy().view(np.uint8)
+            self.lgkm.append(lambda: None)
+            return
         if op == "ds_bpermute_b32":
             idx = (self.rd(a[1]) >> 2) & 63
             data = self.rd(a[2])[idx].copy()

@@ -36,6 +36,9 @@ json.dump(out, open(f"{d}/gemm_asm_pmc.json", "w"), indent=1)
 PY
       find $d/pmc -name "*kernel_trace.csv" -delete
       fi ;;
+    attnhd)     # the generated head_dim-80 / 128 attention kernels: parity tests, then TF/s beside the generic HIP kernel and the head_dim-64 kernel
+      timeout 900 python -m pytest tests/test_attn_asm_gpu.py tests/test_kernels_gpu.py -q -rA -p no:cacheprovider -k "head_dim or other_head" 2>&1 | tail -150 > $d/pytest.log; grep -E "passed|failed|FAILED|Error" $d/pytest.log | tail -20
+      timeout 600 python tools/kernel_bench.py --what attnhd --views ${ATTNHD_VIEWS:-100} --attn-dtypes ${ATTNHD_DTYPES:-fp16,bf16} > $d/attn_head_dim.jsonl 2> $d/err.log; cat $d/attn_head_dim.jsonl | cut -c1-330; tail -3 $d/err.log ;;
     attnl2)     # L2 hit / miss / fabric read requests of the fusion-attention kernel at N = 320, fp16 vs bf16 (why fp16 fetches 2-3x the tiling floor)
       rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u | tr "\n" " " > $d/tcc_counters.txt
       for V in fp16 bf16; do

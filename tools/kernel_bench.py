@@ -70,21 +70,33 @@ def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2, tokens_per_v
                           "rel_l2_asm_vs_hip": float((a - b).norm() / a.norm()), "nan": int(torch.isnan(b).sum())}), flush=True)
 
 
-def bench_attn_head_dim(dt, views, hd, H=16):
-    """f3r_attn_fwd on a fusion-shaped problem with head_dim hd (64: the tuned kernels; else attn_generic_kernel)"""
+def bench_attn_head_dim(dt, views, hd, H=16, sels=(1, 0)):
+    """f3r_attn_fwd on a fusion-shaped problem with head_dim hd per f3r_attn_args.kernel_sel: 1 = the HIP kernel (the generic one unless hd = 64),
+    0 = automatic (the generated kernel of csrc/asm/attn_gen.py at 64 / 80 / 128)"""
+    import ctypes
     T = views * 1024
     D = H * hd
     q = (torch.randn((T, D), device=DEV) * (hd ** -0.5 * 1.4426950408889634)).to(dt)
     k = torch.randn((T, D), device=DEV).to(dt)
     vt = torch.randn((D, T), device=DEV).to(dt)
-    o = torch.empty((T, D), dtype=dt, device=DEV)
+    outs = {}
+    for sel in sels:
+        o = torch.empty((T, D), dtype=dt, device=DEV)
 
-    def f():
-        ops.attention(q, o, H, hd ** -0.5, [(k, vt, T, 0, 0)], q_prescaled=True, head_dim=hd)
-    f()
-    med, mn = time_ms(f, rounds=3, inner=2)
-    print(json.dumps({"kernel": "attn_head_dim", "head_dim": hd, "dtype": str(dt).split(".")[-1], "views": views, "T": T, "ms": round(med, 3),
-                      "tflops": round(4.0 * T * T * hd * H / med / 1e9, 1)}), flush=True)
+        def f():
+            ops.attention(q, o, H, hd ** -0.5, [(k, vt, T, 0, 0)], q_prescaled=True, head_dim=hd, kernel_sel=sel)
+        ops.ATTN_TIMER = []
+        f()
+        torch.cuda.synchronize()
+        name = ops.ATTN_TIMER[0][5]
+        ops.ATTN_TIMER = None
+        med, mn = time_ms(f, rounds=3, inner=2)
+        outs[sel] = o.float()
+        print(json.dumps({"kernel": "attn_head_dim", "head_dim": hd, "kernel_sel": sel, "runs": name, "dtype": str(dt).split(".")[-1], "views": views, "T": T,
+                          "ms": round(med, 3), "tflops": round(4.0 * T * T * hd * H / med / 1e9, 1), "tflops_best": round(4.0 * T * T * hd * H / mn / 1e9, 1)}), flush=True)
+    if len(outs) == 2:
+        a, b = list(outs.values())
+        print(json.dumps({"kernel": "attn_head_dim", "head_dim": hd, "rel_l2_between_kernels": float((a - b).norm() / a.norm()), "nan": int(torch.isnan(b).sum())}), flush=True)
 
 
 def bench_gemm(dt, M, N, K, name, act=None, res=False, out="f32", sels=(1, 2, 3), split=None):
@@ -425,7 +437,8 @@ if __name__ == "__main__":
     if args.what == "attnhd":  # generic head_dim kernel next to the tuned head_dim-64 path
         for hd in (64, 80, 128):
             for nv in [int(x) for x in args.views.split(",")]:
-                bench_attn_head_dim(torch.float16, nv, hd)
+                for d in args.attn_dtypes.split(","):
+                    bench_attn_head_dim(torch.float16 if d == "fp16" else torch.bfloat16, nv, hd)
         sys.exit(0)
     if args.what == "attnsel":
         for nv in [int(x) for x in args.views.split(",")]:
