@@ -84,7 +84,8 @@ def test_emulated_other_head_dims(hd, kw):
 
 
 def test_head_dim_64_stream_is_what_it_was_before_the_other_widths():
-    """the generalisation must not move one instruction of the benchmarked kernel: a digest of the head_dim-64 program text"""
+    """the generalisation must not move one instruction of the benchmarked kernel: a digest of the head_dim-64 program text (the stream of
+    round 3 + the three EXEC resets of the state-out epilogue that test_emulated_moved_wave_parks_the_rows_it_owns asked for)"""
     import hashlib
     import attn_gen
     gens = []
@@ -92,7 +93,17 @@ def test_head_dim_64_stream_is_what_it_was_before_the_other_widths():
         g = attn_gen.AttnGen(dt)
         g.build()
         gens.append(g)
-    assert hashlib.md5(attn_gen.module_text(gens).encode()).hexdigest() == "72c84f999168208f840cd8a4139b71b6"
+    assert hashlib.md5(attn_gen.module_text(gens).encode()).hexdigest() == "a08849495860be9869bf079f13ee488e"
+
+
+@pytest.mark.parametrize("hd,tq,wg", [(64, 1000, (1, 0, 0)), (64, 600, (1, 1, 0)), (80, 700, (2, 0, 0)), (128, 696, (2, 1, 0))])
+def test_emulated_moved_wave_parks_the_rows_it_owns(hd, tq, wg):
+    """two launches with the softmax state parked in between, a query count that leaves the last wave PART of its rows: the wave is moved
+    back to end at the last query and parks only the rows it owns -- per 32-query block a lane mask that must be computed with all lanes
+    active (v_cmp writes 0 for inactive lanes; round 4 found the state-out epilogue computing block qb's mask under block qb-1's, which left
+    rows of the later blocks unparked whenever tq is not a multiple of 32 x the blocks per wave)"""
+    import emu_attn
+    assert emu_attn.run_case(head_dim=hd, n_tiles=[2, 3], split_state=True, tq=tq, q_blocks=3, wgs=(wg,)) < 6e-4
 
 
 def test_generated_text_assembles_and_has_no_hazards(tmp_path):

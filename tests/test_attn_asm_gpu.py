@@ -133,13 +133,13 @@ def test_asm_kernel_grouped_query_and_batch(built_lib, dt):
     assert_close(o.float(), ref, 2 * lp_tol(dt), "gqa + batch")
 
 
-@pytest.mark.parametrize("Tq", [1024, 1024 + 768])
+@pytest.mark.parametrize("Tq", [1024, 1024 + 768, 1024 + 200])
 @pytest.mark.parametrize("dt", DTYPES)
 def test_asm_kernel_segments_and_carried_state(built_lib, dt, Tq):
     """The view-sharded layout: K/V as segments (one launch over all of them == one launch over their concatenation), and the
     two-launch form (local segment with state_out, remote segments with state_in) == one launch -- for the hand-scheduled kernel alone
     and with the general HIP kernel taking either launch (one state layout for both).  Tq = 1792: a partial last workgroup, whose moved
-    waves read state rows that another wave owns (and must not write them)."""
+    waves read state rows that another wave owns (and must not write them); Tq = 1224: a moved wave that owns PART of its rows."""
     H = 2
     lens = [192, 64, 320, 128]
     qs = rnd((Tq, H * 64), dt, 70, 0.125 * LOG2E * 1.5)

@@ -105,7 +105,9 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         ref = (p @ vf) / p.sum(axis=1, keepdims=True)
         got = half_to_f32(og[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-        worst = max(worst, err)
+        worst = err if not np.isfinite(err) else max(worst, err)   # a NaN anywhere fails the case
+        if not np.isfinite(worst):
+            break
         print(f"wg {wg}: {steps} instructions, rel-L2 {err:.3e}, max abs {np.abs(got - ref).max():.3e}, nan {np.isnan(got).sum()}")
     if counters is not None:
         counters[:] = [int(x) for x in mem.get(a_dbg, np.uint32, (4,))]

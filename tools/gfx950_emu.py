@@ -435,7 +435,7 @@ class Wave:
                 x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
             with np.errstate(invalid="ignore"):
                 m = {"v_cmp_eq_u32": x == y, "v_cmp_lt_u32": x < y, "v_cmp_le_u32": x <= y, "v_cmp_le_i32": x <= y, "v_cmp_le_f32": x <= y, "v_cmp_ge_f32": x >= y}[op]
-            self.vcc = int(sum(1 << i for i in range(64) if m[i]))
+            self.vcc = int(sum(1 << i for i in range(64) if m[i])) & self.exec   # inactive lanes write 0
             return
         if op == "v_cndmask_b32":
             mask = self.rds64(a[3])
