@@ -39,6 +39,33 @@ PY
     attnhd)     # the generated head_dim-80 / 128 attention kernels: parity tests, then TF/s beside the generic HIP kernel and the head_dim-64 kernel
       timeout 900 python -m pytest tests/test_attn_asm_gpu.py tests/test_kernels_gpu.py -q -rA -p no:cacheprovider -k "head_dim or other_head" 2>&1 | tail -150 > $d/pytest.log; grep -E "passed|failed|FAILED|Error" $d/pytest.log | tail -20
       timeout 600 python tools/kernel_bench.py --what attnhd --views ${ATTNHD_VIEWS:-100} --attn-dtypes ${ATTNHD_DTYPES:-fp16,bf16} > $d/attn_head_dim.jsonl 2> $d/err.log; cat $d/attn_head_dim.jsonl | cut -c1-330; tail -3 $d/err.log ;;
+    attnhdpmc)  # matrix-pipe utilisation + effective clock of the generated attention kernels at head_dim 64 / 80 / 128 (one PMC pass, T = 102 400)
+      ( cd /tmp; PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $OLDPWD/$d/pmc --output-format csv -- python $OLDPWD/tools/kernel_bench.py --what attnhd --views 100 --attn-dtypes ${ATTNHD_DTYPES:-fp16} ) > $d/pmc.log 2>&1
+      python - $d <<'PY'
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{d}/pmc/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "attn" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for f in glob.glob(f"{d}/pmc/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "attn" in r["Kernel_Name"]:
+            dur[r["Kernel_Name"][:60]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+out = {}
+for k, c in acc.items():
+    v = {n: sum(x) / len(x) for n, x in c.items()}
+    cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+    t = sum(dur[k]) / max(1, len(dur[k]))
+    out[k] = {"avg_dispatch_ms": t / 1e6, "mfma_util_cycles": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), "effective_clock_ghz": cyc / t if t else None,
+              "valu_insts_per_mfma": v["SQ_INSTS_VALU"] / max(1.0, v["SQ_INSTS_MFMA"]), "lds_insts_per_mfma": v["SQ_INSTS_LDS"] / max(1.0, v["SQ_INSTS_MFMA"]),
+              "wait_inst_frac_of_wave_cycles": v.get("SQ_WAIT_INST_ANY", 0) / max(1.0, v.get("SQ_WAVE_CYCLES", 1)), "mfma_insts": v["SQ_INSTS_MFMA"]}
+    print(k, {n: (round(x, 4) if isinstance(x, float) else x) for n, x in out[k].items()})
+json.dump(out, open(f"{d}/attn_head_dim_pmc.json", "w"), indent=1)
+PY
+      find $d/pmc -name "*kernel_trace.csv" -delete; find $d/pmc -name "*counter_collection.csv" -delete; rm -rf $d/pmc/*/*.db 2>/dev/null ;;
     attnl2)     # L2 hit / miss / fabric read requests of the fusion-attention kernel at N = 320, fp16 vs bf16 (why fp16 fetches 2-3x the tiling floor)
       rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u | tr "\n" " " > $d/tcc_counters.txt
       for V in fp16 bf16; do
