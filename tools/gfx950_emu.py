@@ -92,7 +92,7 @@ class Wave:
         self.a = np.zeros((256, 64), np.uint32)
         self.s = np.zeros(128, np.uint32)
         self.vcc = 0
-        self.exec = MASK64   # honoured by the global stores only (the generators mask nothing else)
+        self.exec = MASK64   # honoured by vector register writes, v_cmp results, LDS / global stores and loads (not by MFMA: the matrix pipe ignores it)
         self.scc = 0
         self.m0 = 0
         self.pc = 0
@@ -152,12 +152,16 @@ class Wave:
     def wr(self, x, val):
         val = np.asarray(val).astype(np.uint32, copy=False) if not (isinstance(val, np.ndarray) and val.dtype == np.uint32) else val
         assert isinstance(x, Reg) and x.n == 1
-        if x.kind == "v":
-            self.v[x.idx] = val
-        elif x.kind == "a":
-            self.a[x.idx] = val
-        else:
+        if x.kind not in ("v", "a"):
             raise AssertionError("vector write to an SGPR")
+        f = self.file(x.kind)
+        if self.exec == MASK64:
+            f[x.idx] = val
+        else:   # inactive lanes keep their value (VALU, LDS and VMEM results alike)
+            f[x.idx] = np.where(self.exec_lanes(), val, f[x.idx])
+
+    def exec_lanes(self):
+        return np.array([(self.exec >> i) & 1 for i in range(64)], bool)
 
     def wrs(self, x, val):
         val &= 0xFFFFFFFF
@@ -450,8 +454,11 @@ class Wave:
             data = np.stack([lds[x:x + 16].view(np.uint32) for x in addr], axis=1).copy()  # [4][64]
             self.poison(dst)
 
-            def land(dst=dst, data=data):
-                self.file(dst.kind)[dst.idx:dst.idx + 4] = data
+            act = self.exec_lanes()
+
+            def land(dst=dst, data=data, act=act):
+                f = self.file(dst.kind)
+                f[dst.idx:dst.idx + 4] = np.where(act[None, :], data, f[dst.idx:dst.idx + 4])
             self.lgkm.append(land)
             return
         if op == "ds_write_b128":
