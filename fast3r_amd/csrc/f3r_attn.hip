@@ -388,7 +388,7 @@ extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
   const f3r_attn_args& a = *args;
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   const char* why = "";
-  if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) {
+  if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, (a.kernel_sel == 2 || hd != 64) ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) {
     if (hd == 80) return a.dtype == F3R_F16 ? "f3r_attn_asm_d80_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d80_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
     if (hd == 128) return a.dtype == F3R_F16 ? "f3r_attn_asm_d128_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d128_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
     return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
@@ -435,7 +435,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a.kernel_sel != 1) {  // the hand-scheduled one-wave-per-SIMD kernel where the launch allows it (include/f3r.h)
     const char* why = "";
-    if (f3r_attn_asm_eligible(a, a.kernel_sel == 2 ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) return f3r_attn_asm_launch(a, s);
+    if (f3r_attn_asm_eligible(a, (a.kernel_sel == 2 || hd != 64) ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) return f3r_attn_asm_launch(a, s);
     if (a.kernel_sel == 2) {
       f3r_set_error("f3r_attn_fwd: kernel_sel 2 (hand-scheduled kernel) but the launch is not eligible: %s", why);
       return F3R_ERR_UNSUPPORTED;

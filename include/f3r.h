@@ -242,7 +242,9 @@ typedef struct f3r_attn_args {
      num_heads, blocks.py:113-143; its model_scaling_huge.yaml fusion decoder has 80): same layouts with head_dim columns per head
      (q / k / o rows, head_dim V^T planes per head, st_o rows of n_heads * head_dim), no causal mask.  80 and 128 have hand-scheduled
      kernels of their own (csrc/asm/attn_gen.py: 256-query workgroups, 64 queries per wave; eligibility as for kernel_sel 0 below
-     with tq >= 64); everything else, and launches those kernels cannot take, run the generic kernel (f3r_attn_generic.hip). */
+     with tq >= 64 and NO minimum number of keys: they beat the generic kernel from 128 keys on,
+     profiles/r04_attn_head_dim_short_sequences.jsonl); everything else, and launches those kernels cannot take, run the generic kernel
+     (f3r_attn_generic.hip). */
   int32_t head_dim;
   /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310): device uint32[4], zeroed by the caller; every wave of a launch
      that takes that kernel adds {entries into the block that moves the softmax reference (the forced first one included), 1, 64-key

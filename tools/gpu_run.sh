@@ -66,6 +66,13 @@ for k, c in acc.items():
 json.dump(out, open(f"{d}/attn_head_dim_pmc.json", "w"), indent=1)
 PY
       find $d/pmc -name "*kernel_trace.csv" -delete; find $d/pmc -name "*counter_collection.csv" -delete; rm -rf $d/pmc/*/*.db 2>/dev/null ;;
+    smalln)     # small scenes (fp16 / high): latency eager vs graph, then the kernel split of N = ${SMALLN_PROFILE_VIEWS:-3} eager forwards
+      timeout 600 python tools/small_n_latency.py --dtype fp16 --precision high --views ${SMALLN_VIEWS:-2,3,8,20} > $d/latency.jsonl 2> $d/err.log; cat $d/latency.jsonl; tail -2 $d/err.log
+      ( cd /tmp; PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --stats -d $OLDPWD/$d/prof --output-format csv -- python $OLDPWD/tools/small_n_latency.py --dtype fp16 --precision high --views ${SMALLN_PROFILE_VIEWS:-3} --no-graph --iters 10 ) > $d/prof.log 2>&1
+      f=$(ls $d/prof/*/*kernel_stats.csv | head -1); cp $f $d/kernel_stats.csv; head -40 $d/kernel_stats.csv | cut -c1-200
+      find $d/prof -name "*kernel_trace.csv" -delete; rm -rf $d/prof/*/*.db 2>/dev/null ;;
+    huge)       # the reference's model_scaling_huge decoder (head_dim 80) end to end: generated kernel vs the generic one
+      for f in "" "--generic"; do timeout 600 python tools/huge_decoder_bench.py --views ${HUGE_VIEWS:-100} $f 2>> $d/err.log | tee -a $d/huge_decoder.jsonl | cut -c1-600; done; tail -2 $d/err.log ;;
     attnl2)     # L2 hit / miss / fabric read requests of the fusion-attention kernel at N = 320, fp16 vs bf16 (why fp16 fetches 2-3x the tiling floor)
       rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u | tr "\n" " " > $d/tcc_counters.txt
       for V in fp16 bf16; do

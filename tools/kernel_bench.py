@@ -52,7 +52,8 @@ def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2, tokens_per_v
     D = H * 64
     q = (torch.randn((T, D), device=DEV) * (0.160192 * 1.4426950408889634)).to(dt)
     k = torch.randn((T, D), device=DEV).to(dt)
-    vt = torch.randn((D, T), device=DEV).to(dt)
+    vt = torch.zeros((D, ops.vt_ld(T)), device=DEV, dtype=dt)
+    vt[:, :T] = torch.randn((D, T), device=DEV).to(dt)
     outs = {}
     for sel in sels:
         o = torch.empty((T, D), dtype=dt, device=DEV)
@@ -70,15 +71,15 @@ def bench_attn_sel(dt, views, sels=(1, 2), H=16, rounds=3, inner=2, tokens_per_v
                           "rel_l2_asm_vs_hip": float((a - b).norm() / a.norm()), "nan": int(torch.isnan(b).sum())}), flush=True)
 
 
-def bench_attn_head_dim(dt, views, hd, H=16, sels=(1, 0)):
+def bench_attn_head_dim(dt, views, hd, H=16, sels=(1, 0), T=None):
     """f3r_attn_fwd on a fusion-shaped problem with head_dim hd per f3r_attn_args.kernel_sel: 1 = the HIP kernel (the generic one unless hd = 64),
     0 = automatic (the generated kernel of csrc/asm/attn_gen.py at 64 / 80 / 128)"""
-    import ctypes
-    T = views * 1024
+    T = views * 1024 if T is None else T
     D = H * hd
     q = (torch.randn((T, D), device=DEV) * (hd ** -0.5 * 1.4426950408889634)).to(dt)
     k = torch.randn((T, D), device=DEV).to(dt)
-    vt = torch.randn((D, T), device=DEV).to(dt)
+    vt = torch.zeros((D, ops.vt_ld(T)), device=DEV, dtype=dt)
+    vt[:, :T] = torch.randn((D, T), device=DEV).to(dt)
     outs = {}
     for sel in sels:
         o = torch.empty((T, D), dtype=dt, device=DEV)
@@ -433,6 +434,11 @@ if __name__ == "__main__":
             bench_conv(dt, 8, 512, 512, 128, 128, "head2", sels=(4,))
         bench_gemm(torch.float16, 102400, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2", sels=(2, 5))
         bench_conv(torch.float16, 8, 128, 128, 256, 256, "refinenet1 rcu x3", split="x3", sels=(2, 5))
+        sys.exit(0)
+    if args.what == "attnhdsmall":  # where the generated head_dim-80 / 128 kernels overtake the generic one: short sequences (sel 1 = generic, 2 = generated)
+        for hd in (80, 128):
+            for T in (128, 256, 512, 1024, 2048, 4096):
+                bench_attn_head_dim(torch.float16, 0, hd, sels=(1, 2), T=T)
         sys.exit(0)
     if args.what == "attnhd":  # generic head_dim kernel next to the tuned head_dim-64 path
         for hd in (64, 80, 128):
