@@ -105,6 +105,8 @@ SYMBOLS = {
     "f3r_rope_f32": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp]),
     "f3r_silu_mul_f32": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_attn_f32_ex": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp]),
+    "f3r_attn_f32_mfma_workspace": (ctypes.c_int64, [ctypes.POINTER(AttnF32Args)]),
+    "f3r_attn_f32_mfma": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp, ctypes.c_int64, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
 }
@@ -119,7 +121,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 310  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 320  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():

@@ -24,7 +24,7 @@ int f3r_check_launch(const char* what) {
   return F3R_OK;
 }
 
-extern "C" int f3r_version(void) { return 310; /* 0.3.1: round-4 ABI (f3r_attn_args.dbg_counters appended; see f3r_sizeof) */ }
+extern "C" int f3r_version(void) { return 320; /* 0.3.2: round-4 ABI (f3r_attn_args.dbg_counters appended, see f3r_sizeof; f3r_attn_f32_mfma added) */ }
 
 extern "C" const char* f3r_last_error_string(void) { return g_err; }
 

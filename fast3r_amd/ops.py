@@ -455,6 +455,11 @@ def silu_mul_f32(ab, hidden, lp):
     return hi, lo
 
 
+# precision "exact": from this many keys per sequence on, attention_f32 runs on the matrix pipe (f3r_attn_f32_mfma: three-plane products, fp32
+# softmax) instead of the FMA pipe (f3r_attn_f32_ex, ~30 TFLOP/s: the reference implementation of the mode, and what every small fixture uses)
+ATTN_F32_MFMA_MIN_KEYS = 8192
+
+
 def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_dim=64, kv_group=1, causal=False, kv=None, q_pos0=0, k_pos0=0):
     """precision "exact": fp32 softmax attention -> (o_hi, o_lo) lowp planes [T][D] (the A operand of the X3 projection) [, o fp32 with
     want_f32].  qkv fp32 [T][Dq + 2 Dkv] = q | k | v column blocks (head_dim per head; Dkv = Dq / kv_group: grouped-query heads);
@@ -481,7 +486,12 @@ def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_
     a.o_hi, a.o_lo, a.o_f32, a.ldo = ptr(o_hi), ptr(o_lo), ptr(o32), D
     a.n_seq, a.tq, a.q_pos0, a.k_pos0 = n_seq, seq_len, int(q_pos0), int(k_pos0)
     a.n_heads, a.kv_group, a.causal, a.dtype, a.head_dim, a.scale = n_heads, max(1, int(kv_group)), int(bool(causal)), dtype_id(lp), int(head_dim), float(scale)
-    check(_lib.lib().f3r_attn_f32_ex(ctypes.byref(a), stream_ptr()), "f3r_attn_f32_ex")
+    ws_bytes = int(_lib.lib().f3r_attn_f32_mfma_workspace(ctypes.byref(a))) if a.tk >= ATTN_F32_MFMA_MIN_KEYS else 0
+    if ws_bytes > 0:  # the same attention as three-plane MFMA products (f3r_exact_mfma.hip): ~1e-6 of the FMA kernel at 10x its speed
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
+        check(_lib.lib().f3r_attn_f32_mfma(ctypes.byref(a), ptr(ws), ws_bytes, stream_ptr()), "f3r_attn_f32_mfma")
+    else:
+        check(_lib.lib().f3r_attn_f32_ex(ctypes.byref(a), stream_ptr()), "f3r_attn_f32_ex")
     return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 

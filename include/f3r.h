@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 310 = 0.3.1, round 4 (f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6); 300 = round 3; 200 = round 2 */
+int f3r_version(void);  /* 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
@@ -410,6 +410,12 @@ int f3r_rope_f32(float* qkv, int64_t rows, int64_t ld, int n_rot_heads, int64_t 
                  const float* rope_sin, f3r_stream_t stream);
 int f3r_silu_mul_f32(const float* ab, void* out_hi, void* out_lo, int64_t rows, int hidden, int dtype, f3r_stream_t stream);
 int f3r_attn_f32_ex(const f3r_attn_f32_args* args, f3r_stream_t stream);
+/* The same attention on the matrix pipe (f3r_exact_mfma.hip; ABI 320): every operand as an exact sum of two 16-bit planes (~22 significand bits),
+ * every product as three MFMAs with fp32 accumulation, softmax in fp32 -- the FMA-pipe kernel's numbers to ~1e-6 at 10x its speed, for the
+ * scenes where that kernel takes minutes (it stays the reference implementation of the mode; tests compare the two).  head_dim 64, no causal
+ * mask: f3r_attn_f32_mfma_workspace returns 0 for anything else, and the bytes of caller-owned scratch (the planes of q, k and V^T) otherwise. */
+int64_t f3r_attn_f32_mfma_workspace(const f3r_attn_f32_args* args);
+int f3r_attn_f32_mfma(const f3r_attn_f32_args* args, void* workspace, int64_t workspace_bytes, f3r_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,101 @@
+"""precision "exact": the matrix-pipe form of the fp32 attention (f3r_attn_f32_mfma, fast3r_amd/csrc/f3r_exact_mfma.hip: every operand as two
+16-bit planes, every product as three MFMAs, fp32 softmax) against the FMA-pipe kernel it stands in for at large key counts (f3r_attn_f32_ex,
+the reference implementation of the mode) and against float64 -- same inputs, through the C ABI.  Bar: 3e-6 rel-L2 (the mode's own distance to
+the reference's fp32 path is ~1e-6 on fixtures, 7.7e-6 through 48 ViT-L blocks)."""
+import math
+
+import pytest
+import torch
+
+from fast3r_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def ref64(qkv, H, Hkv, n_seq, tq, scale, kv=None, tk=None):
+    D, Dk = H * 64, Hkv * 64
+    q = qkv[:, :D].double().reshape(n_seq, tq, H, 64).permute(0, 2, 1, 3)
+    if kv is None:
+        k, v, tk = qkv[:, D:D + Dk], qkv[:, D + Dk:], tq
+    else:
+        k, v = kv
+    k = k.double().reshape(n_seq, tk, Hkv, 64).permute(0, 2, 1, 3).repeat_interleave(H // Hkv, 1)
+    v = v.double().reshape(n_seq, tk, Hkv, 64).permute(0, 2, 1, 3).repeat_interleave(H // Hkv, 1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    return (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(n_seq * tq, D)
+
+
+def run(qkv, H, n_seq, tq, scale, lp, mfma, **kw):
+    saved = ops.ATTN_F32_MFMA_MIN_KEYS
+    ops.ATTN_F32_MFMA_MIN_KEYS = 0 if mfma else 1 << 62
+    try:
+        return ops.attention_f32(qkv, H, n_seq, tq, scale, lp, want_f32=True, **kw)
+    finally:
+        ops.ATTN_F32_MFMA_MIN_KEYS = saved
+
+
+@pytest.mark.parametrize("lp", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n_seq,tq,H,Hkv,spread", [(1, 1024, 2, 2, 1.0), (2, 300, 4, 2, 1.0), (3, 1000, 2, 1, 3.0), (1, 4160, 1, 1, 6.0)])
+def test_mfma_form_matches_the_fma_kernel_and_fp64(built_lib, lp, n_seq, tq, H, Hkv, spread):
+    """self-attention over n_seq sequences (lengths that are not multiples of 64 or 128: masked key tails, partial query workgroups),
+    grouped heads, logits up to a spread of several e-folds (sharp rows); fp32 output and the hi + lo planes"""
+    g = torch.Generator().manual_seed(5)
+    D, Dk = H * 64, Hkv * 64
+    qkv = torch.randn((n_seq * tq, D + 2 * Dk), generator=g)
+    qkv[:, :D + Dk] *= spread ** 0.5 * 1.5
+    scale = 0.125
+    qd = qkv.to(DEV)
+    ref = ref64(qkv, H, Hkv, n_seq, tq, scale)
+    fma = run(qd, H, n_seq, tq, scale, lp, False, kv_group=H // Hkv)
+    mf = run(qd, H, n_seq, tq, scale, lp, True, kv_group=H // Hkv)
+    e_fma, e_mf = rel_l2(fma[2], ref), rel_l2(mf[2], ref)
+    print(f"[exact attention] {n_seq} x {tq} keys, {H} heads on {Hkv}, planes {lp}: FMA kernel {e_fma:.2e}, MFMA form {e_mf:.2e} vs fp64; between them {rel_l2(mf[2], fma[2]):.2e}")
+    tol = 3e-6 if lp == torch.float16 else 2e-4   # bf16 planes: 2 x 8 bits
+    assert e_fma <= 3e-6 and e_mf <= tol
+    planes = mf[0].float() + mf[1].float()
+    assert rel_l2(planes, mf[2]) <= (2e-6 if lp == torch.float16 else 1e-4)
+
+
+def test_mfma_form_with_gathered_keys_and_the_threshold(built_lib):
+    """the view-sharded call shape: one sequence of tq local queries over tk gathered keys (kv=...); and the default threshold: below
+    ATTN_F32_MFMA_MIN_KEYS keys attention_f32 is bit-identical to the FMA kernel, causal launches always are"""
+    g = torch.Generator().manual_seed(9)
+    H, tq, tk = 2, 512, 2112
+    qkv = (torch.randn((tq, 3 * H * 64), generator=g) * 1.5).to(DEV)
+    k, v = (torch.randn((tk, H * 64), generator=g) * 1.5).to(DEV), torch.randn((tk, H * 64), generator=g).to(DEV)
+    ref = ref64(qkv.cpu(), H, H, 1, tq, 0.125, kv=(k.cpu(), v.cpu()), tk=tk)
+    mf = run(qkv, H, 1, tq, 0.125, torch.float16, True, kv=(k, v))
+    assert rel_l2(mf[2], ref) <= 3e-6
+    fma = run(qkv, H, 1, tq, 0.125, torch.float16, False, kv=(k, v))
+    assert tk < ops.ATTN_F32_MFMA_MIN_KEYS
+    auto = ops.attention_f32(qkv, H, 1, tq, 0.125, torch.float16, want_f32=True, kv=(k, v))
+    assert torch.equal(auto[2], fma[2])
+    c_fma = run(qkv, H, 1, tq, 0.125, torch.float16, False, causal=True)
+    c_any = run(qkv, H, 1, tq, 0.125, torch.float16, True, causal=True)   # no MFMA form with a causal mask: the FMA kernel again
+    assert torch.equal(c_fma[2], c_any[2])
+
+
+def test_mfma_form_at_16k_keys_vs_fp64_on_the_device(built_lib):
+    """a size where the MFMA form is the default (>= ATTN_F32_MFMA_MIN_KEYS): 16 384 keys, 2 heads, against a float64 softmax computed on the
+    device in query chunks (torch.float64 matmul: test infrastructure) -- the error does not grow with the key count"""
+    g = torch.Generator().manual_seed(13)
+    H, T = 2, 16384
+    qkv = (torch.randn((T, 3 * H * 64), generator=g) * 1.3).to(DEV)
+    assert T >= ops.ATTN_F32_MFMA_MIN_KEYS
+    got = ops.attention_f32(qkv, H, 1, T, 0.125, torch.float16, want_f32=True)[2]
+    q = qkv[:, :H * 64].double().reshape(T, H, 64).transpose(0, 1)
+    k = qkv[:, H * 64:2 * H * 64].double().reshape(T, H, 64).transpose(0, 1)
+    v = qkv[:, 2 * H * 64:].double().reshape(T, H, 64).transpose(0, 1)
+    ref = torch.empty((H, T, 64), dtype=torch.float64, device=DEV)
+    for i in range(0, T, 2048):
+        ref[:, i:i + 2048] = ((q[:, i:i + 2048] @ k.transpose(1, 2)) * 0.125).softmax(-1) @ v
+    ref = ref.transpose(0, 1).reshape(T, H * 64)
+    err = rel_l2(got, ref)
+    print(f"[exact attention] 16384 keys, MFMA form (default above {ops.ATTN_F32_MFMA_MIN_KEYS} keys) vs fp64: {err:.2e}")
+    assert err <= 3e-6

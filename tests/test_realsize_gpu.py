@@ -1,7 +1,8 @@
 """Parity at the sizes BASELINE.json names, on the GPU, where the CPU oracle cannot run inside a test budget.
 
 The checker is the product's own fp32-equivalent path (precision="exact": every GEMM / conv operand as an fp16 hi + lo pair, the
-attention core in plain fp32 -- f3r_exact.hip), which is itself pinned on the reference: to 3e-7 on the reference's golden outputs
+attention core in plain fp32 -- f3r_exact.hip -- or, from 8192 keys on, as three-plane MFMA products with an fp32 softmax --
+f3r_exact_mfma.hip, tied to the plain form and to float64 by tests/test_exact_mfma_gpu.py), which is itself pinned on the reference: to 3e-7 on the reference's golden outputs
 (test_e2e_gpu.py::test_exact_mode_matches_reference_golden_to_fp32_noise), to 6e-7 on ViT-L at N=3 vs the CPU oracle, and
 (test_e2e_gpu.py::test_exact_mode_is_anchored_on_the_oracle_at_20k_tokens) at 20 480 tokens of the fusion decoder vs the CPU oracle.
 

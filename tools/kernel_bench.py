@@ -435,6 +435,22 @@ if __name__ == "__main__":
         bench_gemm(torch.float16, 102400, 4096, 1024, "fc1+gelu w2", act="gelu", out="lp", split="w2", sels=(2, 5))
         bench_conv(torch.float16, 8, 128, 128, 256, 256, "refinenet1 rcu x3", split="x3", sels=(2, 5))
         sys.exit(0)
+    if args.what == "exactattn":  # precision "exact": the FMA-pipe fp32 attention against its matrix-pipe form (three-plane products)
+        for T in [int(x) * 1024 for x in args.views.split(",")]:
+            H = 16
+            qkv = (torch.randn((T, 3 * H * 64), device=DEV) * 1.2)
+            res = {}
+            for name, thr in (("fma", 1 << 62), ("mfma", 0)):
+                if name == "fma" and T > 40960:
+                    continue  # minutes
+                ops.ATTN_F32_MFMA_MIN_KEYS = thr
+                f = lambda: ops.attention_f32(qkv, H, 1, T, 0.125, torch.float16, want_f32=True)  # noqa: E731
+                res[name] = f()[2]
+                med, mn = time_ms(f, rounds=2, inner=1)
+                print(json.dumps({"kernel": "attention_f32", "form": name, "T": T, "heads": H, "ms": round(med, 2), "tflops_algorithmic": round(4.0 * T * T * 64 * H / med / 1e9, 1)}), flush=True)
+            if len(res) == 2:
+                print(json.dumps({"kernel": "attention_f32", "T": T, "rel_l2_between_forms": float((res["mfma"] - res["fma"]).norm() / res["fma"].norm())}), flush=True)
+        sys.exit(0)
     if args.what == "attnhdsmall":  # where the generated head_dim-80 / 128 kernels overtake the generic one: short sequences (sel 1 = generic, 2 = generated)
         for hd in (80, 128):
             for T in (128, 256, 512, 1024, 2048, 4096):
