@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--no-hot", action="store_true", help="skip the short second measurement on the hot weights (default-weights runs only)")
     ap.add_argument("--parity-exact", action="store_true",
                     help="also run the same views through precision='exact' (the on-device fp32-equivalent path) and report the rel-L2 of the timed format "
-                         "against it (any N on one GPU: from 8192 keys on the exact attention runs on the matrix pipe, ~40 s at N = 320)")
+                         "against it (any N on one GPU: from 8192 keys on the exact attention runs on the matrix pipe, 36 s at N = 320)")
     ap.add_argument("--no-inference", action="store_true", help="skip timing the same forward through fast3r_amd.inference() (host in, host out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")

@@ -11,7 +11,7 @@ selects the operand format of the HIP kernels:
                                                                    hi + lo planes (~22 significand bits), attention in fp32 (FMA pipe;
                                                                    from 8192 keys on as three-plane MFMA products with an fp32
                                                                    softmax) -- ~1e-6 of the reference's fp32 path; 3 x the matrix
-                                                                   work of the 16-bit modes everywhere (N = 320: ~40 s); every model
+                                                                   work of the 16-bit modes everywhere (N = 320: 36 s); every model
                                                                    this package builds, view-sharded ones included (one-GPU rank
                                                                    emulation excepted)
     torch.float32                                                  (in the reference: NOT fp32 but the default autocast dtype, SURVEY.md
@@ -75,7 +75,7 @@ def check_if_same_size(imgs):
 
 _warned_fp32 = False
 _warned_exact_size = False
-EXACT_WARN_VIEWS = 48  # above this the "exact" mode costs seconds: every product is three MFMAs and the attention is O(T^2) (N = 100: ~8 s, N = 320: ~40 s)
+EXACT_WARN_VIEWS = 48  # above this the "exact" mode costs seconds: every product is three MFMAs and the attention is O(T^2) (N = 100: 4 s, N = 320: 36 s)
 
 
 def _operand_format(precision, model, n_views=0):
@@ -90,8 +90,8 @@ def _operand_format(precision, model, n_views=0):
         if precision is not torch.float32:
             if n_views > EXACT_WARN_VIEWS and not _warned_exact_size:
                 warnings.warn(f"fast3r_amd.inference(dtype='32') on {n_views} views: the fp32-equivalent mode multiplies every operand as two "
-                              "16-bit planes (three MFMAs per product, attention included: quadratic in the number of views, ~8 s at 100 views and "
-                              "~40 s at 320); it is meant for validation.  Build the model with precision='high' and pass dtype='16-mixed' for the "
+                              "16-bit planes (three MFMAs per product, attention included: quadratic in the number of views, 4 s at 100 views and "
+                              "36 s at 320); it is meant for validation.  Build the model with precision='high' and pass dtype='16-mixed' for the "
                               "parity-green production format.", stacklevel=3)
                 _warned_exact_size = True
             return torch.float16, "exact"
