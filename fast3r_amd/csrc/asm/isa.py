@@ -178,12 +178,22 @@ class Program:
         last_valu_sgpr_write = {}  # SGPRs / VCC written by a VALU: a VALU reader needs two wait states
         last_m0_write = -10
         last_dot_write = {}
+        exec_full = True       # False after `s_mov_b64 exec, <a mask>` until `s_mov_b64 exec, -1`
         n = 0
         problems = []
         for it in items:
             if isinstance(it, Label):
+                exec_full = True   # (a join: every branch in these kernels is taken with all lanes active)
                 continue
             op = it.op
+            if op in ("s_branch", "s_endpgm"):
+                exec_full = True
+            # a lane mask computed under a narrowed EXEC is narrower than its compare says (v_cmp writes 0 for inactive lanes): the generators
+            # always mean "all lanes" when they compare, so a v_cmp while EXEC is narrowed is a bug (round 4: the state-out epilogue)
+            if op == "s_mov_b64" and it.args and isinstance(it.args[0], Special) and it.args[0].name == "exec":
+                exec_full = isinstance(it.args[1], int) and it.args[1] == -1
+            elif op.startswith("v_cmp") and not exec_full:
+                problems.append(f"{tag}{n}: {it.text()} computes a lane mask while EXEC is narrowed (inactive lanes read as 0)")
             if op in ("s_branch", "s_endpgm") and branch_resets:
                 last_mfma_write, last_valu_write, last_m0_write = {}, {}, -10
                 last_trans_write, last_valu_sgpr_write, last_dot_write = {}, {}, {}

@@ -106,6 +106,19 @@ def test_emulated_moved_wave_parks_the_rows_it_owns(hd, tq, wg):
     assert emu_attn.run_case(head_dim=hd, n_tiles=[2, 3], split_state=True, tq=tq, q_blocks=3, wgs=(wg,)) < 6e-4
 
 
+def test_hazard_walk_flags_a_lane_mask_computed_under_a_narrowed_exec():
+    """the static walk (isa.Program.check_hazards) knows the bug the moved-wave test above found: remove the EXEC resets of the state-out
+    epilogue again and it names the three compares that would run with inactive lanes"""
+    import attn_gen
+    import isa
+    g = attn_gen.AttnGen("f16")
+    p = g.build()
+    assert p.check_hazards() == []
+    p.items = [it for it in p.items if not (isinstance(it, isa.Ins) and it.op == "s_mov_b64" and "mask of block qb" in (it.comment or ""))]
+    found = p.check_hazards()
+    assert len(found) == 3 and all("EXEC is narrowed" in f for f in found), found
+
+
 def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     import attn_gen
     gens = attn_gen.product_generators()
