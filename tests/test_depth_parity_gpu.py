@@ -123,6 +123,40 @@ def test_vit_large_n320_stress_weights_vs_fp32_equivalent_path(built_lib):
     assert max(w.values()) <= TOL, w
 
 
+def test_model_scaling_huge_decoder_stress_weights_vs_fp32_equivalent_path(built_lib):
+    """(e) the one reference configuration whose heads are not 64 wide (configs/experiment/model_scaling/model_scaling_huge.yaml:12-15: fusion
+    decoder 1280 / 16 heads = head_dim 80, depth 32) behind the ViT-L encoder, 40 views of 512^2 (40 960 fusion tokens), stress weights:
+    fp16 / high -- whose fusion attention is the generated kernel f3r_attn_asm_d80_f16, asserted from the launch records -- against the
+    fp32-equivalent mode (head_dim 80 there: the FMA-pipe attention), every output <= 1e-3."""
+    enc, dec, head = vit_large_args()
+    dec = dict(dec, embed_dim=1280, num_heads=16, depth=32)
+    shapes = {k: tuple(v.shape) for k, v in Fast3R(enc, dec, head).state_dict().items()}
+    sd = synth_state_dict(shapes, 1, dist="hot")
+    views = views_to(make_views(40, 512, 512), DEV)
+
+    def run(precision):
+        m = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision=precision).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV)
+        ops.ATTN_TIMER = []
+        try:
+            with torch.no_grad():
+                torch.manual_seed(99)
+                out = [{k: v.cpu() for k, v in o.items()} for o in m(views)]
+            names = {rec[5] for rec in ops.ATTN_TIMER}
+        finally:
+            ops.ATTN_TIMER = None
+        del m
+        torch.cuda.empty_cache()
+        return out, names
+    ref, _ = run("exact")
+    out, names = run("high")
+    assert any("f3r_attn_asm_d80_f16" in n for n in names), names
+    w = _worst(out, ref)
+    print("[parity] ViT-L encoder + model_scaling_huge decoder, HOT, N=40 512^2 fp16 high vs exact: " + ", ".join(f"{k}={v:.2e}" for k, v in w.items()))
+    assert max(w.values()) <= TOL, w
+
+
 # ------------------------------------------------------------------------------------------------ (c) GEMM / conv roles at N = 320 shapes
 M320 = 327680
 NS = 4096
