@@ -24,8 +24,11 @@ Extra objects in the JSON line:
   roofline     fusion-attention kernel (the dominant kernel: 94.7 % of all FLOPs at N=320): algorithmic FLOPs per launch
                4*Tq*Tk*64*heads divided by the average launch duration measured live with events on the launch stream,
                against the dense 16-bit MFMA peak of 2.5 PFLOP/s (MI355X_MICROARCH.md).  `e2e` = all algorithmic FLOPs of the
-               forward pass / step time / peak.  `traffic` / `pmc` are NOT measured in this run: they are read from the committed
-               rocprofv3 PMC summaries under profiles/ and carry their `source` file and shape.
+               forward pass / step time / peak.  `live` IS measured in this run: every wave of the timed fusion-attention launches
+               brackets itself with s_memtime / s_memrealtime and counts its tiles (effective shader clock, matrix-pipe utilisation in
+               cycles, cycles per launch), a sampler thread reads socket power and sclk at 2 Hz.  `traffic` / `reference_pmc` are NOT
+               measured in this run: they are read from the committed rocprofv3 PMC summaries under profiles/ and carry their `source`.
+  n100, fusion_only_n20   BASELINE configs[2] / configs[1] measured right after the headline (1 warm-up + 2 steps each).
   parity       rel-L2 of this dtype / precision on the stress fixture tests/golden/tiny_hot_3x64.pt (reference outputs), run
                through the same model class right here.
   cpu_baseline the CPU oracle (oracle/fast3r_oracle.py, a port of the reference's torch-CPU fp32 path, SDPA attention) on this
@@ -66,6 +69,9 @@ def parse(argv=None):
                     help="also run the same views through precision='exact' (the on-device fp32-equivalent path) and report the rel-L2 of the timed format "
                          "against it (any N on one GPU: from 8192 keys on the exact attention runs on the matrix pipe, 36 s at N = 320)")
     ap.add_argument("--no-inference", action="store_true", help="skip timing the same forward through fast3r_amd.inference() (host in, host out)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the two bounded extra objects of the default line: n100 (BASELINE configs[2]: N = 100 end to end) and fusion_only_n20 "
+                         "(configs[1]: N = 20, fusion transformer only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=3)
@@ -80,6 +86,98 @@ def parse(argv=None):
                          "forward, then the one that exposed less (fast3r_amd/dist.py; the per-peer form has only ever run over gloo)")
     ap.add_argument("--p2p-channels", type=int, default=3)
     return ap.parse_args(argv)
+
+
+class PowerSampler:
+    """Socket power and shader clock of one GPU, sampled at ~2 Hz by a thread while the timed steps run (roofline.live): amdsmi when the
+    module initialises, else `rocm-smi --json`.  Never raises: a box without either reports {"source": None}."""
+
+    def __init__(self, index=0, period=0.5):
+        import threading
+        self.index, self.period = index, period
+        self.samples, self.source, self.error = [], None, None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._smi = None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self._handle = amdsmi.amdsmi_get_processor_handles()[index]
+            self._smi, self.source = amdsmi, "amdsmi"
+        except Exception as exc:  # noqa: BLE001
+            self.error = f"amdsmi: {type(exc).__name__}"
+
+    @staticmethod
+    def _num(x):
+        try:
+            v = float(x)
+            return v if v == v and v > 0 and v < 1e7 else None   # amdsmi marks absent fields with N/A or 0xFFFF...
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _read(self):
+        if self._smi is not None:
+            p = clk = None
+            try:
+                m = self._smi.amdsmi_get_gpu_metrics_info(self._handle)
+                p = self._num(m.get("current_socket_power")) or self._num(m.get("average_socket_power"))
+                cl = m.get("current_gfxclks") or []
+                cl = [self._num(c) for c in (cl if isinstance(cl, (list, tuple)) else [cl])]
+                cl = [c for c in cl if c]
+                clk = sum(cl) / len(cl) if cl else self._num(m.get("current_gfxclk"))
+            except Exception:  # noqa: BLE001
+                pass
+            if p is None:
+                try:
+                    pi = self._smi.amdsmi_get_power_info(self._handle)
+                    p = self._num(pi.get("current_socket_power")) or self._num(pi.get("average_socket_power")) or self._num(pi.get("socket_power"))
+                except Exception:  # noqa: BLE001
+                    pass
+            if clk is None:
+                try:
+                    clk = self._num(self._smi.amdsmi_get_clock_info(self._handle, self._smi.AmdSmiClkType.GFX).get("clk"))
+                except Exception:  # noqa: BLE001
+                    pass
+            return p, clk
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            card = next(iter(json.loads(txt).values()))
+            p = clk = None
+            for k, v in card.items():
+                kl = k.lower()
+                if "power" in kl and "socket" in kl and p is None:
+                    p = self._num(v)
+                if "sclk" in kl and "clock" in kl and clk is None:
+                    clk = self._num(str(v).strip("()").lower().replace("mhz", ""))
+            self.source = "rocm-smi"
+            return p, clk
+        except Exception as exc:  # noqa: BLE001
+            self.error = (self.error or "") + f"; rocm-smi: {type(exc).__name__}"
+            return None, None
+
+    def _run(self):
+        while not self._stop.is_set():
+            p, clk = self._read()
+            if p is not None or clk is not None:
+                self.samples.append((p, clk))
+            elif self._smi is None and self.source is None:
+                return   # neither source works on this box
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self):
+        ps = [p for p, _ in self.samples if p is not None]
+        cs = [c for _, c in self.samples if c is not None]
+        return {"source": self.source if self.samples else None, "samples": len(self.samples), "period_s": self.period,
+                "power_w_mean": sum(ps) / len(ps) if ps else None, "power_w_max": max(ps) if ps else None,
+                "sclk_mhz_mean": sum(cs) / len(cs) if cs else None, "error": None if self.samples else self.error}
 
 
 def flops_forward(V, P=1024, D=1024, L_enc=24, L_dec=24, heads=2):
@@ -212,8 +310,13 @@ def main():
     placeholder = {"img": views[lo]["img"]}
     views = [v if v is not None else placeholder for v in views]  # never read outside [lo, hi)
 
-    def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False, time_inference=False):
-        """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line."""
+    def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False, time_inference=False, n_views=None, fusion_only=None,
+                parity=True):
+        """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line.  n_views / fusion_only: the bounded extra
+        objects of the default line (the first n_views of the resident views; BASELINE configs[1] / [2]) -- single-GPU runs only."""
+        V = args.views if n_views is None else n_views
+        fo = args.fusion_only if fusion_only is None else fusion_only
+        vlist = views if V == args.views else views[:V]
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
         weights = args.weights if weights is None else weights
@@ -225,29 +328,33 @@ def main():
             model.shard_views(exchange=args.exchange, p2p_channels=args.p2p_channels)
         if emu:
             model.emulate_rank(args.emulate_rank, args.of, exchange="allgather" if args.exchange == "auto" else args.exchange)
-        if args.fusion_only:
+        if fo:
             step_fn = make_fusion_only_step(model, V, lp, dev)
         else:
             def step_fn():
                 torch.manual_seed(1234)
-                return model(views)
+                return model(vlist)
         with torch.no_grad():
             for _ in range(warmup):
                 step_fn()
             ops.ATTN_TIMER = []
-            ops.ATTN_COUNTERS = torch.zeros(4, dtype=torch.int32, device=dev)
+            ops.ATTN_COUNTERS = torch.zeros(8, dtype=torch.int32, device=dev)
+            sampler = PowerSampler(local_rank)
             if distributed:  # exposed exchange per layer over the timed steps (events on the compute stream, read after the last barrier)
                 model.sharding.time_exchange = True
                 for kvx in model.sharding._kvx_cache.values():
                     kvx.timing = []
             barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                last_out = step_fn()
-            barrier()
-            dt = time.perf_counter() - t0
+            with sampler:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    last_out = step_fn()
+                barrier()
+                dt = time.perf_counter() - t0
             timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
-            counters, ops.ATTN_COUNTERS = [int(c) & 0xFFFFFFFF for c in ops.ATTN_COUNTERS.tolist()], None
+            u32, ops.ATTN_COUNTERS = [int(c) & 0xFFFFFFFF for c in ops.ATTN_COUNTERS.tolist()], None
+            # f3r_attn_args.dbg_counters (ABI 330): u32 entries, u32 waves, u64 tiles, u64 shader-clock cycles, u64 constant-clock ticks
+            counters = [u32[0], u32[1], u32[2] | (u32[3] << 32), u32[4] | (u32[5] << 32), u32[6] | (u32[7] << 32)]
         dt = max_over_ranks(dt)
         exch = None
         if distributed:
@@ -275,7 +382,7 @@ def main():
             avg_ms = sum(ms for ms, _ in fus) / len(fus)
         achieved = big / (avg_ms * 1e-3) / 1e12
         prec = "" if precision == "fast" else "; split-precision GEMM operands (weights hi+lo in the transformer, both operands hi+lo in the heads)"
-        e2e = None if (args.fusion_only or emu) else flops_forward(V) / (dt / steps) / 1e12 / world
+        e2e = None if (fo or emu) else flops_forward(V) / (dt / steps) / 1e12 / world
         if emu:
             kvx = model.sharding.last_exchange
             res_emu = {"comm_bytes_per_layer_into_this_gpu": kvx.comm_bytes_per_layer, "fusion_layers": int(dec["depth"]),
@@ -286,23 +393,24 @@ def main():
         # how often the lazy softmax reference of the hand-scheduled kernel moved (f3r_attn_args.dbg_counters, summed over every launch of
         # the timed steps that took that kernel): per wave and 64-key tile, the forced first re-base of each wave not counted
         entries, waves = counters[0], counters[1]
-        tiles_per_wave = None if (distributed or emu) else V * 1024 // 64   # every asm launch of the unsharded forward walks all keys
+        tiles_per_wave = None if waves == 0 else counters[2] / waves   # counted by the kernel (64-bit sum, ABI 330)
         rebase = None if waves == 0 else {"rebases_per_wave": (entries - waves) / waves,
                                           "rebases_per_tile": None if tiles_per_wave is None else (entries - waves) / waves / tiles_per_wave,
                                           "waves": waves, "tiles_per_wave": tiles_per_wave,
                                           "note": "summed over the timed steps; the forced first re-base of each wave is excluded"}
+        live = live_roofline(counters, avg_ms, achieved, int(dec["embed_dim"]) // int(dec["num_heads"]), sampler.summary())
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "weights": weights, "attn_rebase": rebase,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
                "roofline": {"bound": "mfma", "kernel": " / ".join(kname) + " -- the fusion self-attention launches of f3r_attn_fwd",
                             "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                            "flops_per_launch": big, "avg_launch_ms": avg_ms, "launches_timed": len(fus),
+                            "flops_per_launch": big, "avg_launch_ms": avg_ms, "launches_timed": len(fus), "live": live,
                             "e2e": None if e2e is None else {"flops_per_forward": flops_forward(V), "achieved_per_gpu": e2e, "frac": e2e / MFMA_PEAK_TFLOPS}}}
         if emu:
             res["emulation"] = res_emu
         if exch is not None:
             res["exchange"] = exch
-        if time_inference and not (emu or distributed or args.fusion_only):
+        if time_inference and not (emu or distributed or fo):
             # the function users call (fast3r/dust3r/inference_multiview.py:70-99): host images in, everything back on the host.  Same model,
             # same views (as host tensors, like load_images returns them); 1 warm-up (pinned buffers of the output leg) + 2 timed calls.
             # A failure here (e.g. no pinned memory left on the host) must not cost the headline measurement: it is reported instead.
@@ -312,7 +420,7 @@ def main():
                 last_out = None
             try:
                 from fast3r_amd import inference as f3r_inference
-                host_views = [dict(v, img=v["img"].cpu()) for v in views]
+                host_views = [dict(v, img=v["img"].cpu()) for v in vlist]
                 times = []
                 for it in range(3):
                     torch.cuda.synchronize()
@@ -332,9 +440,9 @@ def main():
                 del host_views
             except Exception as exc:  # noqa: BLE001
                 res["inference"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if rank == 0 and not args.no_parity and not emu:
+        if rank == 0 and not args.no_parity and not emu and parity:
             res["parity"] = parity_on_stress_fixture(lp, precision, dev)
-        if parity_exact and not (emu or distributed or args.fusion_only):
+        if parity_exact and not (emu or distributed or fo):
             keep = [{k: v.float().cpu() for k, v in o.items()} for o in last_out]  # (.cpu() of a host tensor is the tensor itself)
             del model, last_out
             torch.cuda.empty_cache()
@@ -343,7 +451,7 @@ def main():
             mx = mx.to(dev)
             with torch.no_grad():
                 torch.manual_seed(1234)
-                ref = mx(views)
+                ref = mx(vlist)
             worst = {}
             for o, g in zip(keep, ref):
                 for k in g:
@@ -390,6 +498,24 @@ def main():
         except Exception as exc:  # noqa: BLE001  (an extra: never at the price of the headline line)
             print(f"hot-weights measurement failed: {type(exc).__name__}: {exc}", file=sys.stderr)
 
+    # BASELINE configs[2] and configs[1] in the same line: the sizes where the non-attention work shows.  Bounded
+    # (1 warm-up + 2 steps each, ~10 s together), single-GPU default runs only, never at the price of the headline line.
+    extra = {}
+    if world == 1 and not distributed and not emu and not args.fusion_only and not args.no_extra_configs and V >= 100:
+        for key, kw in (("n100", dict(n_views=100)), ("fusion_only_n20", dict(n_views=20, fusion_only=True))):
+            try:
+                r = measure(args.dtype, args.precision, steps=2, warmup=1, parity=False, **kw)
+                extra[key] = {"what": "BASELINE configs[2]: N = 100 views 512x512, full encoder + fusion + heads" if key == "n100" else
+                                      "BASELINE configs[1]: N = 20 views 512x512, fusion transformer only on frozen random encoder features",
+                              "value": r["value"], "unit": "views/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                              "dtype": r["dtype"], "precision": r["precision"],
+                              "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "e2e")}}
+                extra[key]["roofline"]["live"] = {k: v for k, v in r["roofline"]["live"].items() if k not in ("source", "power")}
+                extra[key]["attention_share_of_step"] = r["roofline"]["avg_launch_ms"] * int(dec["depth"]) / r["ms_per_step"]
+            except Exception as exc:  # noqa: BLE001
+                print(f"{key} measurement failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+                extra[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         out = {
             "metric": "views/sec (512^2, ViT-L) single forward pass at N=%d" % V,
@@ -399,8 +525,11 @@ def main():
             "config": {"workload": workload, "views": V, "views_per_gpu": views_per_gpu,
                        "tokens": V * 1024, "image": "512x512", "parallelism": f"view-sharded x{world}, K/V all-gather per fusion layer" if world > 1 else "single GPU",
                        "operands": main_res["operands"]},
-            "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), pmc=load_pmc(main_res["dtype"])),
+            # `live` = this run's own clock / utilisation / power record; `traffic` and `reference_pmc` are read from committed rocprofv3
+            # PMC passes of other runs (they carry their source file) and are there to be compared with `live`, not to stand in for it
+            "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), reference_pmc=load_pmc(main_res["dtype"])),
         }
+        out.update(extra)
         if "exchange" in main_res:
             out["exchange"] = main_res["exchange"]
         out["weights"] = main_res["weights"]
@@ -422,6 +551,29 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
+
+
+def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
+    """What the timed fusion-attention launches THEMSELVES recorded (f3r_attn_args.dbg_counters, ABI 330): every wave of the hand-scheduled
+    kernel brackets its life with s_memtime (shader clock) and s_memrealtime (constant clock), and counts the 64-key tiles it walked.  One wave
+    per SIMD, so a wave's cycles are its SIMD's cycles: matrix-pipe utilisation = 32 cycles x MFMAs issued / cycles lived; the effective shader
+    clock = cycles / (ticks / clock rate).  util x clock x (256 CUs x 4 SIMDs x 1024 FLOP per cycle) is the rate the counters imply; `achieved`
+    (events around the launches) sits just below it by the launch overhead and the idle tail of the last round of workgroups."""
+    entries, waves, tiles, cycles, ticks = counters
+    if waves == 0 or cycles == 0 or ticks == 0:
+        return {"note": "no launch of the hand-scheduled attention kernel in the timed steps", "power": power}
+    from fast3r_amd import _lib
+    khz = int(_lib.lib().f3r_wall_clock_khz()) or 100000
+    qpw = 4 if head_dim == 64 else 2
+    mfma_per_tile = qpw * (2 * (head_dim // 16) + 4 * ((head_dim + 31) // 32))   # Q K^T k-steps + P V blocks of one 64-key tile, per wave
+    clock_ghz = cycles / (ticks / (khz * 1e3)) / 1e9
+    util = 32.0 * mfma_per_tile * tiles / cycles
+    implied = util * clock_ghz * 256 * 4 * 1024 / 1e3   # TFLOP/s
+    return {"source": "s_memtime / s_memrealtime brackets + tile counts written by every wave of the timed launches (f3r_attn_args.dbg_counters)",
+            "effective_clock_ghz": clock_ghz, "mfma_util_cycles": util, "cycles_per_launch": avg_launch_ms * 1e-3 * clock_ghz * 1e9,
+            "wave_cycles_mean": cycles / waves, "waves": waves, "mfma_per_wave_mean": mfma_per_tile * tiles / waves, "wall_clock_khz": khz,
+            "implied_tflops": implied, "implied_frac": implied / MFMA_PEAK_TFLOPS, "achieved_over_implied": achieved_tflops / implied,
+            "power": power}
 
 
 def make_fusion_only_step(model, V, lp, dev):

@@ -79,6 +79,7 @@ SYMBOLS = {
     "f3r_version": (ctypes.c_int, []),
     "f3r_last_error_string": (ctypes.c_char_p, []),
     "f3r_sizeof": (ctypes.c_size_t, [ctypes.c_int]),
+    "f3r_wall_clock_khz": (ctypes.c_int, []),
     "f3r_patchify": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_interp_bilinear": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp] + [ctypes.c_int] * 9 + [_c_vp]),
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
@@ -121,7 +122,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 320  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 330  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():

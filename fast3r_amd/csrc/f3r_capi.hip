@@ -24,7 +24,16 @@ int f3r_check_launch(const char* what) {
   return F3R_OK;
 }
 
-extern "C" int f3r_version(void) { return 320; /* 0.3.2: round-4 ABI (f3r_attn_args.dbg_counters appended, see f3r_sizeof; f3r_attn_f32_mfma added) */ }
+extern "C" int f3r_version(void) { return 330; /* 0.3.3: round-5 ABI (dbg_counters widened to uint32[8] with two clock sums, f3r_wall_clock_khz) */ }
+
+extern "C" int f3r_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return khz;
+}
 
 extern "C" const char* f3r_last_error_string(void) { return g_err; }
 

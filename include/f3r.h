@@ -46,11 +46,13 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
+int f3r_version(void);  /* 330 = 0.3.3, round 5 (f3r_attn_args.dbg_counters is uint32[8] incl. two clock sums; f3r_wall_clock_khz); 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
 size_t f3r_sizeof(int what);
+/* rate of the constant clock s_memrealtime counts on the current device, in kHz (hipDeviceAttributeWallClockRate; 100 000 on MI355X); 0 on failure */
+int f3r_wall_clock_khz(void);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_patchify: fp32 NCHW image -> lowp im2col rows for the k=s=ps patch-embedding convolution.
@@ -246,9 +248,12 @@ typedef struct f3r_attn_args {
      profiles/r04_attn_head_dim_short_sequences.jsonl); everything else, and launches those kernels cannot take, run the generic kernel
      (f3r_attn_generic.hip). */
   int32_t head_dim;
-  /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310): device uint32[4], zeroed by the caller; every wave of a launch
-     that takes that kernel adds {entries into the block that moves the softmax reference (the forced first one included), 1, 64-key
-     tiles it walked, 0}.  bench.py --weights hot reports (entries - waves) / waves: how often the lazy reference really moved. */
+  /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310, widened in ABI 330): device uint32[8], 8-byte aligned, zeroed by the
+     caller; every wave of a launch that takes that kernel adds {entries into the block that moves the softmax reference (the forced first
+     one included), 1} and, as three uint64 at bytes 8, 16 and 24, {64-key tiles it walked, shader-clock cycles (s_memtime) the wave lived,
+     ticks of the constant-rate clock (s_memrealtime, f3r_wall_clock_khz) over the same span}.  bench.py reports (entries - waves) / waves
+     (how often the lazy reference really moved) and, from the clocks, the effective shader clock and the matrix-pipe utilisation of the
+     timed launches themselves (roofline.live). */
   uint32_t* dbg_counters;
 } f3r_attn_args;
 #define F3R_ATTN_ASM_MIN_KEYS 2048

@@ -73,7 +73,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     a_o = mem.alloc(o)
     st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
     st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
-    a_dbg = mem.alloc(np.zeros(4, np.uint32)) if counters is not None else 0
+    a_dbg = mem.alloc(np.zeros(8, np.uint32)) if counters is not None else 0
     common = dict(dbg=a_dbg, q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
                   st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq)
     launches = []
@@ -110,7 +110,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
             break
         print(f"wg {wg}: {steps} instructions, rel-L2 {err:.3e}, max abs {np.abs(got - ref).max():.3e}, nan {np.isnan(got).sum()}")
     if counters is not None:
-        counters[:] = [int(x) for x in mem.get(a_dbg, np.uint32, (4,))]
+        raw = mem.get(a_dbg, np.uint32, (8,))
+        counters[:] = [int(raw[0]), int(raw[1])] + [int(raw[2 * i]) | (int(raw[2 * i + 1]) << 32) for i in (1, 2, 3)]   # entries, waves, tiles, cycles, ticks
     return worst
 
 

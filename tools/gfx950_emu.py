@@ -258,6 +258,18 @@ class Wave:
                 self.s[dst.idx:dst.idx + n] = data
             self.lgkm.append(land)
             return
+        if op in ("s_memtime", "s_memrealtime"):
+            # the shader clock / the constant-rate wall clock: the emulator's stand-ins are the wave's instruction count x 4 (an issue slot
+            # is ~4 cycles) and that count / 16 -- monotonic, so differences are meaningful to the kernels' own bookkeeping tests
+            dst = a[0]
+            t = self.n_exec * 4 if op == "s_memtime" else self.n_exec // 4
+            data = np.array([t & 0xFFFFFFFF, t >> 32], np.uint32)
+            self.s[dst.idx:dst.idx + 2] = 0xDEADBEEF
+
+            def land(dst=dst, data=data):
+                self.s[dst.idx:dst.idx + 2] = data
+            self.lgkm.append(land)
+            return
         if op == "s_mov_b32":
             self.wrs(a[0], self.rds(a[1]))
             return
@@ -525,6 +537,18 @@ class Wave:
                 if (self.exec >> lane) & 1:
                     cur = mem.read(base + off[lane], 4).view(np.uint32)[0]
                     mem.write(base + off[lane], np.array([(int(cur) + int(vals[lane])) & 0xFFFFFFFF], np.uint32).view(np.uint8))
+            self.vm.append(lambda: None)
+            return
+        if op == "global_atomic_add_x2":
+            voff, src, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            vals = self.tuple_read(src)
+            for lane in range(64):
+                if (self.exec >> lane) & 1:
+                    cur = int(mem.read(base + off[lane], 8).view(np.uint64)[0])
+                    add = int(vals[0, lane]) | (int(vals[1, lane]) << 32)
+                    mem.write(base + off[lane], np.array([(cur + add) & 0xFFFFFFFFFFFFFFFF], np.uint64).view(np.uint8))
             self.vm.append(lambda: None)
             return
         if op == "global_store_dwordx2":

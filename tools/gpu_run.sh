@@ -102,6 +102,47 @@ PY
       find $d -name "*kernel_trace.csv" -delete ;;
     attnpmc)    # matrix-pipe utilisation + effective clock + FETCH / WRITE of the fusion attention at N = 320, both formats (tools/pmc_attn_util.sh)
       timeout 900 bash tools/pmc_attn_util.sh 2 320 > $d/pmc.log 2>&1; tail -3 $d/pmc.log | cut -c1-600; cp gpurun_out/pmc_attn/attn_mfma_util.json gpurun_out/pmc_attn/attn_traffic_new.json $d/ 2>/dev/null ;;
+    ubench8)    # go / no-go for block-scaled fp8 / fp6 correction planes: the matrix pipe under the power cap on mixed fp16 + f8f6f4 streams
+      timeout 300 tools/ubench/mfma_mixed ${UBENCH_SECONDS:-1.0} > $d/mfma_mixed.jsonl 2> $d/err.log; cat $d/mfma_mixed.jsonl | cut -c1-400; tail -3 $d/err.log ;;
+    convpmc)    # matrix-pipe utilisation + instruction mix of the conv / QKV instantiations of the compiler-scheduled kernels (no PMC pass of them existed)
+      ( cd /tmp; PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $OLDPWD/$d/pmc --output-format csv -- python $OLDPWD/tools/kernel_bench.py --what convheads > $OLDPWD/$d/pmc.log 2>&1 )
+      grep tflops $d/pmc.log | cut -c1-300
+      python - $d <<'PY'
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{d}/pmc/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "gemm" in r["Kernel_Name"]:
+            key = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(f3r_gemm_args")[0] + f" grid={r.get('Grid_Size', '?')}"
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for f in glob.glob(f"{d}/pmc/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "gemm" in r["Kernel_Name"]:
+            key = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(f3r_gemm_args")[0] + f" grid={r.get('Grid_Size', '?')}"
+            dur[key].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+out = {}
+for k, c in acc.items():
+    v = {n: sum(x) / len(x) for n, x in c.items()}
+    cyc = v.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    t = sum(dur[k]) / max(1, len(dur[k]))
+    if cyc:
+        v["mfma_util_cycles"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024)
+        v["effective_clock_ghz"] = cyc / t if t else None
+        v["avg_dispatch_ms"] = t / 1e6
+        if v.get("SQ_INSTS_MFMA"):
+            v["lds_insts_per_mfma"] = v.get("SQ_INSTS_LDS", 0) / v["SQ_INSTS_MFMA"]
+            v["valu_insts_per_mfma"] = v.get("SQ_INSTS_VALU", 0) / v["SQ_INSTS_MFMA"]
+    out[k] = v
+    print(k, {n: (round(x, 4) if x < 100 else int(x)) for n, x in v.items() if n in ("mfma_util_cycles", "effective_clock_ghz", "avg_dispatch_ms", "lds_insts_per_mfma", "valu_insts_per_mfma")})
+json.dump(out, open(f"{d}/conv_pmc.json", "w"), indent=1)
+PY
+      find $d/pmc -name "*kernel_trace.csv" -delete ;;
+    benchquick) # the default line, short: live roofline + power sampler + n100 / fusion_only_n20 objects (no alt format, no CPU baseline, no hot weights)
+      timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 --no-alt --no-cpu-baseline --no-hot ${BENCH_EXTRA:-} > $d/bench_quick.json 2> $d/err.log; tail -c 5000 $d/bench_quick.json; tail -5 $d/err.log ;;
+    attnasm)    # the generated attention kernels (the clock bracket of round 5 touched prologue + epilogue)
+      timeout 900 python -m pytest tests/test_attn_asm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -15 > $d/pytest.log; tail -4 $d/pytest.log ;;
     gputests)   # the whole GPU suite + smoke
       timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;

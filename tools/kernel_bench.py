@@ -29,6 +29,10 @@ def time_ms(fn, rounds=5, inner=3):
     return best[len(best) // 2], best[0]
 
 
+SEL_NAME = {0: "automatic", 1: "128-tile", 2: "256-tile persistent", 3: "256-tile lock-step", 4: "256x128-tile", 5: "256-tile one tile per workgroup",
+            6: "hand-scheduled (asm)", 7: "compiler-scheduled kernels only"}
+
+
 def bench_attn_product(dt, views, H=16):
     """The product attention kernel (no variant knob in the product library) on the fusion shape."""
     T = views * 1024
@@ -421,6 +425,15 @@ if __name__ == "__main__":
         for M in [int(v) * 1024 for v in args.views.split(",")]:
             bench_gemm(torch.float16, M, 4096, 1024, f"fc1+gelu w2 M={M}", act="gelu", out="lp", split="w2", sels=sels)
             bench_gemm(torch.float16, M, 1024, 4096, f"fc2+res w2 M={M}", res=True, split="w2", sels=sels)
+        sys.exit(0)
+    if args.what == "convheads":  # the DPT-head convolutions and the encoder's QKV + RoPE-2D as the N = 320 forward runs them (fp16, X3 / W2; 25-view head chunks)
+        f16 = torch.float16
+        bench_conv(f16, 25, 256, 256, 256, 128, "head0 x3", split="x3", sels=(0,))
+        bench_conv(f16, 25, 512, 512, 128, 128, "head2 x3", split="x3", sels=(0,))
+        bench_conv(f16, 25, 256, 256, 256, 256, "refinenet1 rcu x3", split="x3", sels=(0,))
+        bench_conv(f16, 25, 128, 128, 256, 256, "refinenet2 rcu x3", split="x3", sels=(0,))
+        bench_conv(f16, 25, 64, 64, 256, 256, "refinenet3 rcu x3", split="x3", sels=(0,))
+        bench_qkv(f16, 128 * 1024, 1024, 1024, sels=(0,))
         sys.exit(0)
     if args.what == "gemmpersist":  # persistent grid (kernel_sel 2) next to one tile per workgroup (5) on the model's shapes
         for dt in (torch.bfloat16, torch.float16):
