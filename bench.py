@@ -338,7 +338,7 @@ def main():
             for _ in range(warmup):
                 step_fn()
             ops.ATTN_TIMER = []
-            ops.ATTN_COUNTERS = torch.zeros(8, dtype=torch.int32, device=dev)
+            ops.ATTN_COUNTERS = torch.zeros(56, dtype=torch.int32, device=dev)
             sampler = PowerSampler(local_rank)
             if distributed:  # exposed exchange per layer over the timed steps (events on the compute stream, read after the last barrier)
                 model.sharding.time_exchange = True
@@ -355,6 +355,7 @@ def main():
             u32, ops.ATTN_COUNTERS = [int(c) & 0xFFFFFFFF for c in ops.ATTN_COUNTERS.tolist()], None
             # f3r_attn_args.dbg_counters (ABI 330): u32 entries, u32 waves, u64 tiles, u64 shader-clock cycles, u64 constant-clock ticks
             counters = [u32[0], u32[1], u32[2] | (u32[3] << 32), u32[4] | (u32[5] << 32), u32[6] | (u32[7] << 32)]
+            counters.append([[u32[8 + 6 * x + 2 * i] | (u32[9 + 6 * x + 2 * i] << 32) for i in range(3)] for x in range(8)])  # per XCD: cycles, ticks, waves
         dt = max_over_ranks(dt)
         exch = None
         if distributed:
@@ -510,7 +511,7 @@ def main():
                               "value": r["value"], "unit": "views/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
                               "dtype": r["dtype"], "precision": r["precision"],
                               "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "e2e")}}
-                extra[key]["roofline"]["live"] = {k: v for k, v in r["roofline"]["live"].items() if k not in ("source", "power")}
+                extra[key]["roofline"]["live"] = {k: v for k, v in r["roofline"]["live"].items() if k not in ("source", "power", "per_xcd")}
                 extra[key]["attention_share_of_step"] = r["roofline"]["avg_launch_ms"] * int(dec["depth"]) / r["ms_per_step"]
             except Exception as exc:  # noqa: BLE001
                 print(f"{key} measurement failed: {type(exc).__name__}: {exc}", file=sys.stderr)
@@ -559,7 +560,7 @@ def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
     per SIMD, so a wave's cycles are its SIMD's cycles: matrix-pipe utilisation = 32 cycles x MFMAs issued / cycles lived; the effective shader
     clock = cycles / (ticks / clock rate).  util x clock x (256 CUs x 4 SIMDs x 1024 FLOP per cycle) is the rate the counters imply; `achieved`
     (events around the launches) sits just below it by the launch overhead and the idle tail of the last round of workgroups."""
-    entries, waves, tiles, cycles, ticks = counters
+    entries, waves, tiles, cycles, ticks, per_xcd = counters
     if waves == 0 or cycles == 0 or ticks == 0:
         return {"note": "no launch of the hand-scheduled attention kernel in the timed steps", "power": power}
     from fast3r_amd import _lib
@@ -569,11 +570,19 @@ def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
     clock_ghz = cycles / (ticks / (khz * 1e3)) / 1e9
     util = 32.0 * mfma_per_tile * tiles / cycles
     implied = util * clock_ghz * 256 * 4 * 1024 / 1e3   # TFLOP/s
+    # per XCD: workgroup ids are dealt round-robin over the 8 XCDs (equal work each), so the launch lasts as long as the slowest XCD needs
+    xcd = None
+    if all(w > 0 and t > 0 for _, t, w in per_xcd):
+        mean_us = [t / w / (khz * 1e3) * 1e6 for _, t, w in per_xcd]
+        xcd = {"wave_time_us_mean": mean_us, "clock_ghz": [c / (t / (khz * 1e3)) / 1e9 for c, t, _ in per_xcd], "waves": [w for _, _, w in per_xcd],
+               "slowest_over_mean": max(mean_us) / (sum(mean_us) / 8),
+               "note": "equal work per XCD (static round-robin of workgroup ids): the slowest XCD bounds the launch; achieved_over_implied below "
+                       "1 / slowest_over_mean is idle time inside the XCDs (tail of the last round, dispatch gaps)"}
     return {"source": "s_memtime / s_memrealtime brackets + tile counts written by every wave of the timed launches (f3r_attn_args.dbg_counters)",
             "effective_clock_ghz": clock_ghz, "mfma_util_cycles": util, "cycles_per_launch": avg_launch_ms * 1e-3 * clock_ghz * 1e9,
             "wave_cycles_mean": cycles / waves, "waves": waves, "mfma_per_wave_mean": mfma_per_tile * tiles / waves, "wall_clock_khz": khz,
             "implied_tflops": implied, "implied_frac": implied / MFMA_PEAK_TFLOPS, "achieved_over_implied": achieved_tflops / implied,
-            "power": power}
+            "per_xcd": xcd, "power": power}
 
 
 def make_fusion_only_step(model, V, lp, dev):

@@ -70,6 +70,15 @@ int num_cus() {
 
 }  // namespace
 
+// The kernel's tile map divides a tile position by pg = gm x (n tiles) and an n tile index by tps (n tiles per output segment) through
+// floor(x * ceil(2^32 / d) / 2^32), which is exact only while x * d < 2^32 (gemm_gen.pack_args): both products must stay below that.
+static bool tile_map_exact(int64_t ntm, int64_t ntn, int64_t tps) {
+  int gsh = 3;
+  while (ntm % (1ll << gsh)) --gsh;
+  const int64_t n_wg = ntm * ntn, pg = (1ll << gsh) * ntn;
+  return n_wg * pg < (1ll << 32) && ntn * (tps > 0 ? tps : 1) < (1ll << 32);
+}
+
 // Is a launch of `tiles` 256 x 256 tiles worth the persistent one-workgroup-per-CU grid?  At least one full round, and the last round of
 // the tile walk at least 80 % full (320 tiles on 256 CUs would leave three quarters of the chip idle for half of the launch; the 8-wave
 // kernel scores its three tile forms for such launches, f3r_gemm256_impl.h tile_score).
@@ -104,6 +113,7 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
   if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 2 >= (1ll << 32)) { *why = "operand row strides too large for 32-bit lane offsets"; return false; }
   const int64_t tiles = (a.M / 256) * (a.N / 256);
   if (tiles >= (1ll << 24)) { *why = "grid too large"; return false; }
+  if (!tile_map_exact(a.M / 256, a.N / 256, a.N / 256)) { *why = "tile map: position x period reaches 2^32 (the kernel divides by multiplying with ceil(2^32 / period))"; return false; }
   if (get_fn(role_of(a), a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }
@@ -187,6 +197,14 @@ bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why) {
   if ((((uintptr_t)a.q) & 15) || (((uintptr_t)a.k) & 15) || (((uintptr_t)a.vt) & 15) || (a.ldvt * 2) % 16 != 0) { *why = "outputs not 16-byte aligned"; return false; }
   if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 2 >= (1ll << 32) || (int64_t)256 * a.ldvt * 2 >= (1ll << 32)) { *why = "row strides too large"; return false; }
   if ((a.M / 256) * (int64_t)(a.N / 256) >= (1ll << 24)) { *why = "grid too large"; return false; }
+  {
+    const int64_t Dq256 = (a.qkv_dq ? a.qkv_dq : a.N / 3) / 256;
+    // launch 1: M/256 x 2D/256 tiles in segments of D/256; launch 2 (V^T, operands swapped): D/256 x M/256 tiles in segments of seq_len/256
+    if (!tile_map_exact(a.M / 256, 2 * Dq256, Dq256) || !tile_map_exact(Dq256, a.M / 256, a.seq_len / 256)) {
+      *why = "tile map: position x period reaches 2^32";
+      return false;
+    }
+  }
   if (get_fn(ROLE_LP, a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }

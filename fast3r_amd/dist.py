@@ -238,13 +238,17 @@ class KVExchange:
 
 
 class ViewSharding:
-    PROBE_LAYERS = 3   # exchange="auto": this many fusion layers with each form on the first forward, then the one that exposed less
+    PROBE_LAYERS = 3   # exchange="auto": this many TIMED fusion layers with each form, then the one that exposed less
+    PROBE_WARM = 2     # before them: one untimed layer with each form (lazy communicator start-up, first launches); then the forms alternate
 
     def __init__(self, process_group=None, gather_outputs=False, exchange="allgather", p2p_channels=3):
-        """exchange: "allgather" | "p2p" (KVExchange.mode) | "auto" (the first forward runs PROBE_LAYERS layers with each form, every rank
-        measures how long its compute stream sat between the local and the first remote attention launch, the maxima over ranks are compared
-        and the cheaper form is used from then on).  p2p_channels: process groups (RCCL: communicators = streams) the per-peer rounds are
-        dealt onto, so that consecutive rounds overlap instead of queueing on one stream."""
+        """exchange: "allgather" | "p2p" (KVExchange.mode) | "auto" (the first forward of a geometry runs one untimed layer with each form,
+        then PROBE_LAYERS timed layers with each, alternating; every rank measures how long its compute stream sat between the local and the
+        first remote attention launch, the maxima over ranks are compared and the cheaper form is used from then on; a new geometry --
+        another scene size -- probes again).  p2p_channels: process groups (RCCL: communicators = streams) the per-peer rounds are dealt
+        onto, so that consecutive rounds overlap instead of queueing on one stream.
+        torch.distributed.new_group is a collective over the DEFAULT group: with p2p channels, EVERY rank of the job must construct its
+        ViewSharding (with the same arguments), not only the members of `process_group`."""
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("ViewSharding needs an initialised torch.distributed process group (RCCL: backend 'nccl')")
         if exchange not in ("allgather", "p2p", "auto"):
@@ -261,7 +265,7 @@ class ViewSharding:
         self.p2p_groups = [process_group]
         if exchange in ("p2p", "auto") and self.world > 2 and p2p_channels > 1:
             ranks = [dist.get_global_rank(process_group, r) for r in range(self.world)] if process_group is not None else list(range(self.world))
-            # (a collective call: every rank of the group constructs its ViewSharding with the same arguments)
+            # (dist.new_group must be entered by every rank of the default world, members of process_group or not: see the docstring)
             self.p2p_groups = [dist.new_group(ranks) for _ in range(min(p2p_channels, self.world - 1))]
         self._probe = {"layer": 0, "allgather": [], "p2p": [], "choice": None if exchange == "auto" else exchange}
 
@@ -275,7 +279,7 @@ class ViewSharding:
             kvx.mode = pr["choice"]
             return
         n = pr["layer"]
-        kvx.mode = "allgather" if n < self.PROBE_LAYERS else "p2p"
+        kvx.mode = "allgather" if n % 2 == 0 else "p2p"   # layers 0, 1 warm each form up; 2, 4, 6 time the all-gather, 3, 5, 7 the rounds
         if kvx.timing is None:
             kvx.timing = []
         pr["layer"] = n + 1
@@ -286,12 +290,14 @@ class ViewSharding:
         if self.exchange != "auto" or self._probe["choice"] is not None:
             return
         pr = self._probe
-        if pr["layer"] < 2 * self.PROBE_LAYERS:
+        n_probe = self.PROBE_WARM + 2 * self.PROBE_LAYERS
+        if pr["layer"] < n_probe:
             return
-        ms = kvx.exposed_ms()
+        ms = kvx.exposed_ms()[-n_probe:]   # (bench.py's own timing of earlier layers may precede the probe's in the same list)
         if not self.time_exchange:
             kvx.timing = None
-        sums = [sum(ms[:self.PROBE_LAYERS]), sum(ms[self.PROBE_LAYERS:2 * self.PROBE_LAYERS])]
+        ms = ms[self.PROBE_WARM:]
+        sums = [sum(ms[0::2]), sum(ms[1::2])]
         cd = self._comm_device(kvx.k_all.device)
         t = torch.tensor(sums, dtype=torch.float64, device=cd)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -332,6 +338,8 @@ class ViewSharding:
         cache = self._kvx_cache
         if key not in cache:
             cache.clear()  # one geometry at a time: a different scene releases the previous buffers
+            if self.exchange == "auto":   # ... and is probed afresh (the balance of the two forms depends on the shard sizes)
+                self._probe = {"layer": 0, "allgather": [], "p2p": [], "choice": None}
             cache[key] = KVExchange(self.group, self.world, self.rank, t_loc, t_all, D, dtype, dev, n_heads, q_dim, mode=self.exchange,
                                     p2p_groups=self.p2p_groups)
         kvx = cache[key]

@@ -455,7 +455,7 @@ class _GraphCache:
         self.entries.clear()
         self.seen.clear()
 
-    def run(self, model, views):
+    def run(self, model, views, host_outputs=False):
         imgs = [v["img"] for v in views]
         dev = imgs[0].device
         shapes = {tuple(i.shape) for i in imgs}
@@ -490,6 +490,11 @@ class _GraphCache:
         ids = dec.draw_image_ids(B, len(views))
         static_emb.copy_(dec.image_idx_emb.to(dev)[ids.to(dev)])
         graph.replay()
+        if host_outputs:  # inference(): the replayed (static) outputs go to the host through the same sink as the eager path's head chunks
+            sink = _HostSink(dev, B)
+            sink.push([(i, slice(None), k, v) for i, r in enumerate(outs) for k, v in r.items()], [])
+            sink.finish()   # before the next replay may overwrite the static outputs
+            return [{k: sink.result(i, k) for k in r} for i, r in enumerate(outs)]
         return [{k: v.clone() for k, v in r.items()} for r in outs]
 
 
@@ -506,12 +511,33 @@ class _HostSink:
     """Device -> host leg of `inference()` (fast3r/dust3r/inference_multiview.py:92-93 + utils/device.py:17-53 `to_cpu`): one pinned host
     tensor per (view, output) -- torch's caching host allocator recycles them between calls, and a tensor the caller still holds is
     never handed out again -- filled by non_blocking copies on a side stream that waits for the event recorded behind the head chunk that
-    produced the data.  The copies of chunk c overlap the heads of chunk c + 1; finish() waits for the last one."""
+    produced the data.  The copies of chunk c overlap the heads of chunk c + 1; finish() waits for the last one.
+
+    The returned tensors are PAGE-LOCKED for as long as the caller holds them (~8.4 MB per view: 2.7 GB at N = 320).  PINNED_LIMIT_BYTES
+    bounds what one call locks (default 8 GiB; 0 = never pin); past the limit, or when the host refuses a page-locked allocation, the
+    remaining outputs land in ordinary pageable tensors (the copy is then synchronous, as the reference's `to_cpu` is) -- never an error."""
+    PINNED_LIMIT_BYTES = 8 << 30
 
     def __init__(self, dev, batch):
         self.dev, self.B = dev, batch
         self.stream = torch.cuda.Stream(device=dev)
         self.bufs = {}
+        self.pinned_bytes = 0
+        self.pageable = 0   # outputs that fell back to pageable memory
+
+    def _alloc(self, shape, dtype):
+        nbytes = int(torch.empty((), dtype=dtype).element_size())
+        for s_ in shape:
+            nbytes *= int(s_)
+        if self.pinned_bytes + nbytes <= self.PINNED_LIMIT_BYTES:
+            try:
+                t = torch.empty(shape, dtype=dtype, pin_memory=True)
+                self.pinned_bytes += nbytes
+                return t
+            except RuntimeError:   # hipHostMalloc refused (locked-memory limit of the host / container): from here on, pageable
+                self.PINNED_LIMIT_BYTES = 0
+        self.pageable += 1
+        return torch.empty(shape, dtype=dtype)
 
     def push(self, items, keep_alive):
         ev = torch.cuda.Event()
@@ -524,8 +550,9 @@ class _HostSink:
             for i, b, name, src in items:
                 key = (i, name)
                 if key not in self.bufs:
-                    self.bufs[key] = torch.empty((self.B,) + tuple(src.shape), dtype=src.dtype, pin_memory=True)
-                self.bufs[key][b].copy_(src, non_blocking=True)
+                    shape = tuple(src.shape) if isinstance(b, slice) else (self.B,) + tuple(src.shape)
+                    self.bufs[key] = self._alloc(shape, src.dtype)
+                self.bufs[key][b].copy_(src, non_blocking=True)   # (a pageable destination makes this copy synchronous: still correct)
 
     def result(self, i, name):
         return self.bufs[(i, name)]
@@ -1173,12 +1200,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         of the next chunk (what the reference does after the forward with a blocking `to_cpu`, dust3r/inference_multiview.py:92-93)."""
         if len(views) == 0:
             return ([], {}) if profiling else []
-        if (self.use_graphs and not profiling and not host_outputs and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
+        if (self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
                 and self.precision != "exact"):  # (the validation mode allocates per layer: it always runs eagerly)
             dev = views[0]["img"].device
             if dev.type == "cuda":  # (anything else: the eager path raises its F3RError)
                 with torch.cuda.device(dev):  # capture and replay on the tensors' device, whatever the caller's current device is
-                    out = self._graphs.run(self, views)
+                    out = self._graphs.run(self, views, host_outputs=host_outputs)
                 if out is not None:
                     return out
         return self._forward_eager(views, profiling, host_outputs=host_outputs)

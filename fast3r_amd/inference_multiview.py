@@ -48,7 +48,9 @@ def collate_with_cat(whatever, lists=False):
             return {k: collate_with_cat([e[k] for e in whatever], lists=lists) for k in elem}
         if isinstance(elem, torch.Tensor):
             if not lists and len(whatever) == 1:
-                return elem  # torch.cat of one tensor: the same values without the copy (N x 8.4 MB of outputs per call otherwise)
+                # torch.cat of one tensor: the same values without the copy (N x 8.4 MB of outputs per call otherwise).  The element is
+                # returned as it is: for the predictions that is the tensor this call produced; for the views' own fields see ALIAS_HOST_INPUTS
+                return elem
             return [x for e in whatever for x in e] if lists else torch.cat(whatever)
         if isinstance(elem, np.ndarray):
             return [x for e in whatever for x in e] if lists else torch.cat([torch.from_numpy(x) for x in whatever])
@@ -73,6 +75,10 @@ def check_if_same_size(imgs):
     return all(s == shapes[0] for s in shapes)
 
 
+# Deviation from the reference, on purpose: inference() returns result["views"][i][name] as THE CALLER'S OWN host tensor when the view came
+# from the host (the reference uploads it and `to_cpu` brings back a fresh copy, inference_multiview.py:92-93) -- an in-place edit of the
+# result then edits the input.  Set to False to get the reference's fresh copies (one host memcpy of the images: ~1 GB at N = 320).
+ALIAS_HOST_INPUTS = True
 _warned_fp32 = False
 _warned_exact_size = False
 EXACT_WARN_VIEWS = 48  # above this the "exact" mode costs seconds: every product is three MFMAs and the attention is O(T^2) (N = 100: 4 s, N = 320: 36 s)
@@ -126,7 +132,7 @@ def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_bat
         net.compute_dtype, net.precision = saved
     if host_outputs:
         for view, name, t in host_side:
-            view[name] = t
+            view[name] = t if ALIAS_HOST_INPUTS else t.clone()
     preds, profiling_info = out if profiling else (out, None)
     loss = criterion(batch, preds) if criterion is not None else None
     result = dict(views=batch, preds=preds, loss=loss)

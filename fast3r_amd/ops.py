@@ -17,7 +17,7 @@ ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F
 # Optional per-launch timing of the attention kernel (bench.py's live roofline): when set to a list, every
 # f3r_attn_fwd launch is bracketed by events on the launch stream and (start, end, flops) is appended.
 ATTN_TIMER = None
-# Optional device int32[8] that the hand-scheduled attention kernel adds its counters to (f3r_attn_args.dbg_counters: entries into the
+# Optional device int32[56] that the hand-scheduled attention kernel adds its counters to (f3r_attn_args.dbg_counters: entries into the
 # re-base block, waves, tiles walked, -, and two 64-bit sums: shader-clock cycles and constant-clock ticks the waves lived); bench.py sets
 # it around the timed steps (attn_rebase, roofline.live).
 ATTN_COUNTERS = None
@@ -362,7 +362,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
         for i, v in enumerate(pos):
             a.seg_pos0[i] = v
     if ATTN_COUNTERS is not None:
-        assert ATTN_COUNTERS.dtype == torch.int32 and ATTN_COUNTERS.numel() >= 8 and ATTN_COUNTERS.data_ptr() % 8 == 0 and ATTN_COUNTERS.device == q.device
+        assert ATTN_COUNTERS.dtype == torch.int32 and ATTN_COUNTERS.numel() >= 56 and ATTN_COUNTERS.data_ptr() % 8 == 0 and ATTN_COUNTERS.device == q.device
         a.dbg_counters = ptr(ATTN_COUNTERS)
     if state is not None:
         a.st_o, a.st_ml = ptr(state[0]), ptr(state[1])

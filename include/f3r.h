@@ -248,10 +248,11 @@ typedef struct f3r_attn_args {
      profiles/r04_attn_head_dim_short_sequences.jsonl); everything else, and launches those kernels cannot take, run the generic kernel
      (f3r_attn_generic.hip). */
   int32_t head_dim;
-  /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310, widened in ABI 330): device uint32[8], 8-byte aligned, zeroed by the
+  /* Optional counters of the hand-scheduled kernel (NULL = none; ABI 310, widened in ABI 330): device uint32[56], 8-byte aligned, zeroed by the
      caller; every wave of a launch that takes that kernel adds {entries into the block that moves the softmax reference (the forced first
      one included), 1} and, as three uint64 at bytes 8, 16 and 24, {64-key tiles it walked, shader-clock cycles (s_memtime) the wave lived,
-     ticks of the constant-rate clock (s_memrealtime, f3r_wall_clock_khz) over the same span}.  bench.py reports (entries - waves) / waves
+     ticks of the constant-rate clock (s_memrealtime, f3r_wall_clock_khz) over the same span}, followed from byte 32 on by the
+     same sums per XCD (8 records of three uint64: cycles, ticks, waves; the XCD is read from HW_REG_XCC_ID).  bench.py reports (entries - waves) / waves
      (how often the lazy reference really moved) and, from the clocks, the effective shader clock and the matrix-pipe utilisation of the
      timed launches themselves (roofline.live). */
   uint32_t* dbg_counters;

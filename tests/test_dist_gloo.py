@@ -140,12 +140,14 @@ def _worker_p2p(rank, world, port, ret):
             full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
             assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
             assert [s[2] for s in kvx.finish()] == [t for r, t in enumerate(kvx.t_all) if r != rank]  # everything at once still works
-        # ---- exchange="auto": PROBE_LAYERS layers with each form, every rank times what the local launch did not hide, the maxima over
-        # ranks pick the winner -- the same one on every rank -- and later layers use it
+        # ---- exchange="auto": one untimed warm-up layer with each form, then PROBE_LAYERS timed layers with each (alternating), every rank
+        # times what the local launch did not hide, the maxima over ranks pick the winner -- the same one on every rank -- and later
+        # layers use it; a new geometry probes again
         sa = ViewSharding(exchange="auto", p2p_channels=2)
         kva = sa.make_kv_exchange(t_loc, D, torch.float32, torch.device("cpu"), n_heads=2)
         used = []
-        for layer in range(2 * sa.PROBE_LAYERS + 2):
+        n_probe = sa.PROBE_WARM + 2 * sa.PROBE_LAYERS
+        for layer in range(n_probe + 2):
             kva.k_loc[:t_loc] = kf[r0:r0 + t_loc] + layer
             kva.vt_loc[0, :, :t_loc] = (vf[r0:r0 + t_loc] + layer).t()
             sa.begin_layer(kva)
@@ -164,10 +166,13 @@ def _worker_p2p(rank, world, port, ret):
             out = _segment_attention(qf[r0:r0 + t_loc], arrived, 0.16)
             full = _segment_attention(qf, [(kf + layer, (vf + layer).t().contiguous(), T, 0, 0)], 0.16)
             assert torch.allclose(out, full[r0:r0 + t_loc], atol=1e-5)
-        assert used[:6] == ["allgather"] * 3 + ["p2p"] * 3 and sa.exchange_in_use in ("allgather", "p2p") and used[6] == used[7] == sa.exchange_in_use
+        assert used[:n_probe] == ["allgather", "p2p"] * (n_probe // 2) and sa.exchange_in_use in ("allgather", "p2p")
+        assert used[n_probe] == used[n_probe + 1] == sa.exchange_in_use
         votes = [None] * world
         dist.all_gather_object(votes, sa.exchange_in_use)
         assert len(set(votes)) == 1
+        kvb = sa.make_kv_exchange(t_loc, 2 * D, torch.float32, torch.device("cpu"), n_heads=4)   # another geometry: the choice is open again
+        assert sa.exchange_in_use == "auto (probing)" and kvb is not kva
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

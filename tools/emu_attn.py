@@ -73,7 +73,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     a_o = mem.alloc(o)
     st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
     st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
-    a_dbg = mem.alloc(np.zeros(8, np.uint32)) if counters is not None else 0
+    a_dbg = mem.alloc(np.zeros(56, np.uint32)) if counters is not None else 0
     common = dict(dbg=a_dbg, q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
                   st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq)
     launches = []

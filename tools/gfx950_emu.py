@@ -258,6 +258,9 @@ class Wave:
                 self.s[dst.idx:dst.idx + n] = data
             self.lgkm.append(land)
             return
+        if op == "s_getreg_b32":
+            self.wrs(a[0], 0)   # (HW_REG_XCC_ID: the emulated workgroup runs on XCD 0)
+            return
         if op in ("s_memtime", "s_memrealtime"):
             # the shader clock / the constant-rate wall clock: the emulator's stand-ins are the wave's instruction count x 4 (an issue slot
             # is ~4 cycles) and that count / 16 -- monotonic, so differences are meaningful to the kernels' own bookkeeping tests
