@@ -88,6 +88,41 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+class Watchdog:
+    """`with Watchdog(what, seconds):` -- if the block has not finished after `seconds`, every thread's Python stack and the tail of this
+    rank's RCCL log (NCCL_DEBUG_FILE, set by main() for multi-rank runs) go to stderr, once.  It does not kill anything: the process-group
+    timeout (F3R_BENCH_PG_TIMEOUT_S) turns a hung collective into an exception, which the exchange fallback below handles."""
+
+    def __init__(self, what, seconds=120.0, rank=0):
+        import threading
+        self.what, self.seconds, self.rank = what, seconds, rank
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self.fired = False
+
+    def _run(self):
+        if self._done.wait(self.seconds):
+            return
+        self.fired = True
+        import faulthandler
+        print(f"[bench watchdog] rank {self.rank}: '{self.what}' still running after {self.seconds:.0f} s; Python stacks:", file=sys.stderr, flush=True)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        log = os.environ.get("NCCL_DEBUG_FILE", "").replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)
+        if log and os.path.exists(log):
+            try:
+                tail = open(log, errors="replace").read()[-4000:]
+                print(f"[bench watchdog] rank {self.rank}: tail of {log}:\n{tail}", file=sys.stderr, flush=True)
+            except OSError:
+                pass
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+
+
 class PowerSampler:
     """Socket power and shader clock of one GPU, sampled at ~2 Hz by a thread while the timed steps run (roofline.live): amdsmi when the
     module initialises, else `rocm-smi --json`.  Never raises: a box without either reports {"source": None}."""
@@ -180,6 +215,13 @@ class PowerSampler:
                 "sclk_mhz_mean": sum(cs) / len(cs) if cs else None, "error": None if self.samples else self.error}
 
 
+def fail_line(fd, args, world, ranks_seen, exchange_state, exc):
+    out = {"metric": "views/sec (512^2, ViT-L) single forward pass at N=%d" % args.views, "value": None, "unit": "views/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "error": f"{type(exc).__name__}: {exc}"[:2000], "rccl_ranks_seen": ranks_seen,
+           "exchange": dict(exchange_state)}
+    os.write(fd, (json.dumps(out) + "\n").encode())
+
+
 def flops_forward(V, P=1024, D=1024, L_enc=24, L_dec=24, heads=2):
     """Algorithmic FLOPs of one forward pass at 512x512: GEMMs 2mnk, attention 4 T^2 D per layer, DPT heads."""
     T = V * P
@@ -230,16 +272,37 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("F3R_BENCH_PG_TIMEOUT_S", "300")))
+    wd_seconds = float(os.environ.get("F3R_BENCH_WATCHDOG_S", "120"))
+    ctl = {"group": None}   # gloo control plane beside RCCL: failure flags and per-rank timings travel here, so a broken communicator cannot hide them
+
+    def init_groups(attempt=0):
+        # a restart (attempt > 0) must not meet the first start's rendezvous keys in the launcher's store (same group names -> stale socket
+        # addresses): it brings its own TCPStore, hosted by rank 0 on the next port
+        kw = {}
+        if attempt > 0:
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + attempt, world, rank == 0,
+                                  timeout=pg_timeout + datetime.timedelta(seconds=60))
+            kw = dict(store=store, rank=rank, world_size=world)
+        if dry:
+            dist.init_process_group("gloo", timeout=pg_timeout, **kw)
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout, **kw)
+        # (three times the data plane's timeout: a rank that failed at once waits here for the ranks that first have to run into theirs)
+        ctl["group"] = dist.new_group(backend="gloo", timeout=3 * pg_timeout + datetime.timedelta(seconds=30))
+
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if force_dist:
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if dry:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        if world > 1 and not dry:   # the first multi-GPU run must explain itself if it stalls: RCCL's own log per rank, read back by the watchdog
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/f3r_bench_rccl_rank{rank}_%p.log")
+        with Watchdog("process-group start-up + first collective", wd_seconds, rank):
+            init_groups()
 
     V = args.views
     emu = args.emulate_rank is not None
@@ -261,6 +324,75 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def per_rank(x):
+        """[x of rank 0, x of rank 1, ...] over the gloo control group (a list of one without ranks)"""
+        if not distributed:
+            return [float(x)]
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([float(x)], dtype=torch.float64), group=ctl["group"])
+        return [float(t.item()) for t in out]
+
+    def shutdown():
+        """leave the process groups behind without letting a destructor hang the job: after a fallback the first set of communicators was
+        abandoned mid-collective (their threads may never join), so the process ends right after its output is flushed; otherwise a normal
+        destroy, bounded by a timer"""
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if not distributed:
+            return
+        if exchange_state["fallback_reason"]:
+            os._exit(0)
+        import threading
+        t = threading.Timer(30.0, lambda: os._exit(0))
+        t.daemon = True
+        t.start()
+        try:
+            dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] destroy_process_group: {exc}", file=sys.stderr)
+        t.cancel()
+
+    exchange_state = {"requested": args.exchange, "in_use": args.exchange, "fallback_reason": None}
+
+    def with_exchange_fallback(setup_and_warm):
+        """setup_and_warm(exchange) builds the sharded path with that exchange form and runs the warm-up steps.  An exception on ANY rank
+        (also: a collective that ran into the process-group timeout) is agreed on through the gloo control group; if the form was "auto" or
+        "p2p" -- the forms that have never met RCCL with more than one rank -- every rank tears the process groups down, starts them
+        again and retries ONCE with "allgather"; the JSON line then carries exchange.fallback_reason.  A failure of "allgather" itself is fatal
+        (rank 0 still prints one line, with `error`)."""
+        for attempt in range(2):
+            exc_txt = None
+            try:
+                with Watchdog(f"warm-up with exchange={exchange_state['in_use']}", wd_seconds, rank):
+                    setup_and_warm(exchange_state["in_use"])
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+                exc_txt = f"rank {rank}: {type(exc).__name__}: {exc}"
+                traceback.print_exc(file=sys.stderr)
+            if not distributed:
+                if exc_txt:
+                    raise RuntimeError(exc_txt)
+                return
+            flags = [None] * world
+            try:
+                dist.all_gather_object(flags, exc_txt, group=ctl["group"])
+            except Exception as exc:  # noqa: BLE001  (the control plane itself is gone: nothing left to agree on)
+                raise RuntimeError(f"control group failed after: {exc_txt}: {exc}")
+            bad = [f for f in flags if f]
+            if not bad:
+                return
+            if exchange_state["in_use"] == "allgather" or attempt == 1:
+                raise RuntimeError("; ".join(bad))
+            exchange_state["fallback_reason"] = f"exchange={exchange_state['in_use']} failed during warm-up ({'; '.join(bad)[:600]}): retried with allgather"
+            print("[bench] " + exchange_state["fallback_reason"], file=sys.stderr, flush=True)
+            exchange_state["in_use"] = "allgather"
+            try:
+                dist.destroy_process_group()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] destroy_process_group: {exc}", file=sys.stderr)
+            with Watchdog("process-group restart for the allgather retry", wd_seconds, rank):
+                init_groups(attempt + 1)
+
     ranks_seen = 1
     if distributed:  # every rank adds 1: the sum is the number of ranks that really took part in a collective
         t = torch.ones(1, dtype=torch.float64, device=dev)
@@ -268,23 +400,41 @@ def main():
         ranks_seen = int(t.item())
 
     if dry:
-        # launcher / plumbing check only: no kernels (the product path has no CPU fallback), no measurement claimed
+        # launcher / plumbing check only: no kernels (the product path has no CPU fallback), no measurement claimed.  The exchange fallback is
+        # the real code: F3R_BENCH_INJECT_FAULT="<rank>:<exchange>" makes that rank's warm-up raise while that exchange form is in use.
+        inject = os.environ.get("F3R_BENCH_INJECT_FAULT", "")
+
+        def dry_setup_and_warm(exchange):
+            if inject and inject.split(":") == [str(rank), exchange]:
+                raise RuntimeError(f"injected fault (F3R_BENCH_INJECT_FAULT={inject})")
+            t = torch.ones(1)
+            dist.all_reduce(t) if distributed else None   # the form's first collective
+        try:
+            with_exchange_fallback(dry_setup_and_warm)
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            if rank == 0:
+                fail_line(real_stdout, args, world, ranks_seen, exchange_state, exc)
+            os._exit(1)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             time.sleep(0.01 * (hi - lo))
+        mine = time.perf_counter() - t0
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        ms_ranks = [x / args.steps * 1e3 for x in per_rank(mine)]
         if rank == 0:
             out = {"metric": "DRY RUN (no GPU work)", "dry_run": True, "value": None, "unit": "views/s", "n_gpus": world, "steps": args.steps,
-                   "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "rccl_ranks_seen": ranks_seen, "backend": "gloo",
+                   "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_per_rank": ms_ranks, "rccl_ranks_seen": ranks_seen, "backend": "gloo",
                    "config": {"views": V, "views_per_gpu": views_per_gpu},
-                   "exchange": {"requested": args.exchange, "p2p_channels": args.p2p_channels, "in_use": None, "exposed_ms_per_layer": None,
+                   "exchange": {"requested": args.exchange, "p2p_channels": args.p2p_channels, "in_use": exchange_state["in_use"] if distributed else None,
+                                "fallback_reason": exchange_state["fallback_reason"], "exposed_ms_per_layer": None,
                                 "note": "filled by a real run: the form the start-up probe chose and, per fusion layer, how long the compute stream sat "
                                         "between the local and the first remote attention launch (max over ranks)"}}
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
-        if distributed:
-            dist.destroy_process_group()
+        shutdown()
         return
 
     from fast3r_amd import Fast3R, ops
@@ -324,8 +474,6 @@ def main():
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
         model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
-        if distributed:
-            model.shard_views(exchange=args.exchange, p2p_channels=args.p2p_channels)
         if emu:
             model.emulate_rank(args.emulate_rank, args.of, exchange="allgather" if args.exchange == "auto" else args.exchange)
         if fo:
@@ -334,9 +482,16 @@ def main():
             def step_fn():
                 torch.manual_seed(1234)
                 return model(vlist)
+        def setup_and_warm(exchange):
+            if distributed:
+                model.shard_views(exchange=exchange, p2p_channels=args.p2p_channels)
+            with torch.no_grad():
+                for _ in range(warmup):
+                    step_fn()
+                if distributed and not dry:
+                    torch.cuda.synchronize()   # a device-side failure of the exchange surfaces here, inside the guarded region
+        with_exchange_fallback(setup_and_warm)
         with torch.no_grad():
-            for _ in range(warmup):
-                step_fn()
             ops.ATTN_TIMER = []
             ops.ATTN_COUNTERS = torch.zeros(56, dtype=torch.int32, device=dev)
             sampler = PowerSampler(local_rank)
@@ -349,6 +504,9 @@ def main():
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     last_out = step_fn()
+                if not dry:
+                    torch.cuda.synchronize()
+                mine = time.perf_counter() - t0
                 barrier()
                 dt = time.perf_counter() - t0
             timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
@@ -361,7 +519,8 @@ def main():
         if distributed:
             ms = [x for kvx in model.sharding._kvx_cache.values() for x in kvx.exposed_ms()]
             per_layer = max_over_ranks(sum(ms) / max(1, len(ms)))
-            exch = {"requested": args.exchange, "in_use": model.sharding.exchange_in_use, "p2p_channels": args.p2p_channels,
+            exch = {"requested": args.exchange, "in_use": model.sharding.exchange_in_use, "fallback_reason": exchange_state["fallback_reason"],
+                    "p2p_channels": args.p2p_channels,
                     "exposed_ms_per_layer": per_layer, "layers_timed_on_rank0": len(ms), "probe": {k: v for k, v in model.sharding._probe.items() if k != "layer"},
                     "what": "mean gap on the compute stream between the end of the local-shard attention launch and the start of the first remote one "
                             "(max over ranks): the part of the K / V^T exchange the local launch did not hide"}
@@ -400,7 +559,7 @@ def main():
                                           "waves": waves, "tiles_per_wave": tiles_per_wave,
                                           "note": "summed over the timed steps; the forced first re-base of each wave is excluded"}
         live = live_roofline(counters, avg_ms, achieved, int(dec["embed_dim"]) // int(dec["num_heads"]), sampler.summary())
-        res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
+        res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "ms_per_step_per_rank": [x / steps * 1e3 for x in per_rank(mine)], "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "weights": weights, "attn_rebase": rebase,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
                "roofline": {"bound": "mfma", "kernel": " / ".join(kname) + " -- the fusion self-attention launches of f3r_attn_fwd",
@@ -472,7 +631,14 @@ def main():
     else:
         workload = f"Fast3R ViT-L 512x512 end-to-end single forward pass (encoder + fusion decoder + 2 DPT heads), N={V} views"
 
-    main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact, time_inference=not args.no_inference)
+    try:
+        main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact, time_inference=not args.no_inference)
+    except Exception as exc:  # noqa: BLE001  -- a failed run still ends with ONE line on rank 0's stdout, and a non-zero exit code
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            fail_line(real_stdout, args, world, ranks_seen, exchange_state, exc)
+        os._exit(1)   # (not sys.exit: a rank stuck in a collective's destructor must not keep the job alive)
     if emu:
         out = {"metric": "EMULATED per-rank step: ONE GPU runs rank %d of %d of the view-sharded forward at N=%d (no collectives, remote K/V segments "
                          "pre-filled) -- NOT a multi-GPU measurement" % (args.emulate_rank, args.of, V),
@@ -521,7 +687,8 @@ def main():
         out = {
             "metric": "views/sec (512^2, ViT-L) single forward pass at N=%d" % V,
             "value": main_res["value"], "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": main_res["ms_per_step"], "ms_per_step_per_rank": main_res["ms_per_step_per_rank"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None,
             "dtype": main_res["dtype"], "precision": main_res["precision"], "data": "synthetic", "rccl_ranks_seen": ranks_seen,
             "config": {"workload": workload, "views": V, "views_per_gpu": views_per_gpu,
                        "tokens": V * 1024, "image": "512x512", "parallelism": f"view-sharded x{world}, K/V all-gather per fusion layer" if world > 1 else "single GPU",
@@ -550,8 +717,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, enc, dec, head, args.cpu_views)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if distributed:
-        dist.destroy_process_group()
+    shutdown()
 
 
 def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
