@@ -61,6 +61,7 @@ class AttnArgs(ctypes.Structure):
         ("kv_group", _c_i32), ("causal", _c_i32), ("q_pos0", _c_i64), ("seg_pos0", _c_i64 * F3R_MAX_SEG),
         ("kernel_sel", _c_i32), ("head_dim", _c_i32),
         ("dbg_counters", _c_vp),
+        ("sched_counter", _c_vp),
     ]
 
 

@@ -35,9 +35,12 @@ struct f3r_attn_asm_args {
   uint32_t tq, pad;                      // query rows (the last workgroup may be partial: ARG_TQ)
   f3r_attn_asm_seg seg[8];
   uint32_t* dbg;                         // ARG_DBG: optional counters (f3r_attn_args.dbg_counters)
+  uint32_t* sched;                       // ARG_SCHED: {next, done} of the work-stealing form, or NULL = one work item per workgroup id
+  uint32_t n_work, nx, nxy, nx_magic, nxy_magic, grid;   // items, q blocks, q blocks x heads, ceil(2^32 / nx), ceil(2^32 / nxy), workgroups launched
 };
-static_assert(sizeof(f3r_attn_asm_args) == 312 && offsetof(f3r_attn_asm_args, seg) == 112 && offsetof(f3r_attn_asm_args, dbg) == 304,
-              "must match ARG_SIZE / ARG_SEG / ARG_DBG of attn_gen.py");
+static_assert(sizeof(f3r_attn_asm_args) == 344 && offsetof(f3r_attn_asm_args, seg) == 112 && offsetof(f3r_attn_asm_args, dbg) == 304 &&
+              offsetof(f3r_attn_asm_args, sched) == 312 && offsetof(f3r_attn_asm_args, n_work) == 320,
+              "must match ARG_SIZE / ARG_SEG / ARG_DBG / ARG_SCHED of attn_gen.py");
 
 // The code object is loaded once per DEVICE (hipModule handles are per device context): the only process-wide state of the library
 // besides the per-thread error string.  Any device index: the table grows on demand.
@@ -84,6 +87,12 @@ hipFunction_t get_fn(int dtype, int hd) {
 }
 
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+int num_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  return cus;
+}
 
 }  // namespace
 
@@ -164,9 +173,27 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
     k.k_bs = (uint64_t)a.k_batch_stride[s] * 2;
     k.vt_bs = (uint64_t)a.vt_batch_stride[s] * 2;
   }
+  // Work stealing (f3r_attn_args.sched_counter): one persistent workgroup per CU takes (q block, head, batch) items from a shared counter, so
+  // the XCDs -- which the hardware feeds round-robin by workgroup id whatever their clocks -- finish together.  Worth it from two rounds of
+  // workgroups on; the kernel's magic-number division needs item x period < 2^32.
+  const unsigned nx = (unsigned)((a.tq + 4 * wave_rows(hd) - 1) / (4 * wave_rows(hd)));
+  unsigned gx = nx, gy = (unsigned)a.n_heads, gz = (unsigned)a.batch;
+  const uint64_t n_work = (uint64_t)nx * gy * gz, nxy = (uint64_t)nx * gy;
+  const unsigned cus = (unsigned)num_cus();
+  if (a.sched_counter && n_work >= 2ull * cus && n_work * nxy < (1ull << 32)) {
+    k.sched = a.sched_counter;
+    k.n_work = (uint32_t)n_work;
+    k.nx = nx;
+    k.nxy = (uint32_t)nxy;
+    k.nx_magic = nx > 1 ? (uint32_t)(((1ull << 32) + nx - 1) / nx) : 0;
+    k.nxy_magic = nxy > 1 ? (uint32_t)(((1ull << 32) + nxy - 1) / nxy) : 0;
+    k.grid = cus;
+    gx = cus;
+    gy = gz = 1;
+  }
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((a.tq + 4 * wave_rows(hd) - 1) / (4 * wave_rows(hd))), (unsigned)a.n_heads, (unsigned)a.batch, 256, 1, 1, 0, stream, nullptr, config);
+  hipError_t e = hipModuleLaunchKernel(fn, gx, gy, gz, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
     f3r_set_error("f3r_attn_fwd: hipModuleLaunchKernel failed: %s", hipGetErrorString(e));
     return F3R_ERR_LAUNCH;

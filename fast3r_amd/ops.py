@@ -21,6 +21,18 @@ ATTN_TIMER = None
 # re-base block, waves, tiles walked, -, and two 64-bit sums: shader-clock cycles and constant-clock ticks the waves lived); bench.py sets
 # it around the timed steps (attn_rebase, roofline.live).
 ATTN_COUNTERS = None
+# Work stealing of the hand-scheduled attention kernels (f3r_attn_args.sched_counter): True = hand every launch a zeroed {next, done} pair
+# (one per device and stream, kept here: the kernel leaves it zero); the library uses it for launches of at least two rounds of workgroups.
+ATTN_WORK_STEALING = True
+_SCHED = {}
+
+
+def _sched_counter(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _SCHED.get(key)
+    if t is None:
+        t = _SCHED[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return t
 
 
 def round_up(x: int, m: int) -> int:
@@ -367,6 +379,8 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     if state is not None:
         a.st_o, a.st_ml = ptr(state[0]), ptr(state[1])
         a.state_in, a.state_out = int(state_in), int(state_out)
+    if ATTN_WORK_STEALING:
+        a.sched_counter = ptr(_sched_counter(q.device))
     if ATTN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -88,7 +88,7 @@ def test_emulated_other_head_dims(hd, kw):
 def test_head_dim_64_stream_is_what_it_was_before_the_other_widths():
     """the generalisation must not move one instruction of the benchmarked kernel: a digest of the head_dim-64 program text (the stream of
     round 3 + the three EXEC resets of the state-out epilogue that test_emulated_moved_wave_parks_the_rows_it_owns asked for + round 5's clock
-    bracket: five scalar instructions in the prologue, the 64-bit sums in the optional counter block of the epilogue; the main loop is untouched)"""
+    bracket: five scalar instructions in the prologue, the 64-bit sums in the optional counter block of the epilogue; the work-stealing entry / FETCH block around the unchanged prologue; the main loop is untouched)"""
     import hashlib
     import attn_gen
     gens = []
@@ -96,7 +96,7 @@ def test_head_dim_64_stream_is_what_it_was_before_the_other_widths():
         g = attn_gen.AttnGen(dt)
         g.build()
         gens.append(g)
-    assert hashlib.md5(attn_gen.module_text(gens).encode()).hexdigest() == "a780c4aaec823759168b6a67a8c5f51b"
+    assert hashlib.md5(attn_gen.module_text(gens).encode()).hexdigest() == "8d0cba09028fe0b883145107f2f1dc3b"
 
 
 @pytest.mark.parametrize("hd,tq,wg", [(64, 1000, (1, 0, 0)), (64, 600, (1, 1, 0)), (80, 700, (2, 0, 0)), (128, 696, (2, 1, 0))])
@@ -133,3 +133,16 @@ def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     src = tmp_path / "attn.s"
     src.write_text(attn_gen.module_text(gens))
     subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "attn.o")], check=True)
+
+
+@pytest.mark.parametrize("kw", [dict(tq=1024, n_heads=2, tiles=2, wgs=((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)), steal=2),
+                                dict(tq=700, n_heads=1, tiles=[1, 1], split=True, wgs=((0, 0, 0), (1, 0, 0)), steal=3),
+                                dict(tq=256, n_heads=2, tiles=2, wgs=((0, 0, 0), (0, 1, 0)), steal=2, head_dim=80)])
+def test_emulated_work_stealing_form_computes_every_item_and_leaves_the_counter_zero(kw):
+    """f3r_attn_args.sched_counter (round 5): persistent workgroups fetch (query block, head, batch) items from a shared counter -- wave 0's
+    atomic, the LDS word behind the ring, two barriers -- decode them with the magic-number divisions, re-enter the prologue per item (partial
+    last query block, two-launch state form included) and the last workgroup to leave zeroes {next, done} for the next launch"""
+    import emu_attn
+    err = emu_attn.run_case(kw.get("dtype", "f16"), kw["tiles"], n_heads=kw["n_heads"], wgs=kw["wgs"], tq=kw["tq"], split_state=kw.get("split", False),
+                            steal=kw["steal"], head_dim=kw.get("head_dim", 64))
+    assert err < 6e-4

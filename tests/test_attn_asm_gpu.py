@@ -303,3 +303,37 @@ def test_asm_kernel_other_head_dims_automatic_choice_and_full_size_rows(built_li
         o96 = torch.empty((Tq, H * 96), dtype=dt, device=DEV)
         ops.attention(rnd((Tq, H * 96), dt, 1).to(DEV), o96, H, 1.0, [(rnd((64, H * 96), dt, 2).to(DEV), torch.zeros((H * 96, 64), dtype=dt, device=DEV), 64, 0, 0)],
                       q_prescaled=True, kernel_sel=2, head_dim=96)   # no generated kernel for 96
+
+
+@pytest.mark.parametrize("dt,hd,Tq,H", [(torch.float16, 64, 16384 + 200, 16), (torch.bfloat16, 64, 20480, 13), (torch.float16, 80, 8192 + 64, 16),
+                                        (torch.float16, 128, 8192, 17)])
+def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_lib, dt, hd, Tq, H):
+    """f3r_attn_args.sched_counter (round 5): launches of at least two rounds of workgroups run as one persistent workgroup per CU taking
+    (query block, head) items from a shared counter.  Every item is computed by the same instruction stream as in the one-item-per-workgroup
+    form, so the outputs must be BIT-identical, item numbers that are no multiples of anything included; the kernel must leave {next, done}
+    at zero (the next launch starts from it), three launches in a row; and the per-XCD wave counts of the debug block must add up."""
+    Tk = 512
+    qs = rnd((Tq, H * hd), dt, 1, hd ** -0.5 * LOG2E * 1.5)
+    k, v = rnd((Tk, H * hd), dt, 2, 1.5), rnd((Tk, H * hd), dt, 3)
+    saved = ops.ATTN_WORK_STEALING
+    try:
+        ops.ATTN_WORK_STEALING = False
+        plain = run(qs, k, v, H, hd=hd)
+        ops.ATTN_WORK_STEALING = True
+        ctr = ops._sched_counter(torch.device(DEV, torch.cuda.current_device()))
+        assert ctr.tolist() == [0, 0]
+        ops.ATTN_COUNTERS = torch.zeros(56, dtype=torch.int32, device=DEV)
+        for _ in range(3):
+            stolen = run(qs, k, v, H, hd=hd)
+            torch.cuda.synchronize()
+            assert ctr.tolist() == [0, 0]
+            assert torch.equal(stolen.view(torch.int16), plain.view(torch.int16))
+        c = [int(x) & 0xFFFFFFFF for x in ops.ATTN_COUNTERS.tolist()]
+        wq = 512 if hd == 64 else 256
+        waves = 3 * 4 * (-(-Tq // wq)) * H
+        per_xcd = [c[8 + 6 * x + 4] | (c[8 + 6 * x + 5] << 32) for x in range(8)]
+        assert c[1] == waves and sum(per_xcd) == waves and all(w > 0 for w in per_xcd), (c[:4], per_xcd)
+    finally:
+        ops.ATTN_WORK_STEALING = saved
+        ops.ATTN_COUNTERS = None
+    assert_close(stolen.float()[:1024], ref_prescaled(qs[:1024], k, v, H, hd=hd), 2 * lp_tol(dt), "work-stealing attention vs fp64")

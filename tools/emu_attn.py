@@ -18,7 +18,7 @@ import attn_gen  # noqa: E402
 from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
 
 
-def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0, dbg=0):
+def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0, dbg=0, sched=0, n_work=0, nx=0, nxy=0, grid=0):
     """segs: [(k address, vt address, tiles)] -> the kernel argument block (byte strides)"""
     nt = sum(t for _, _, t in segs)
     b = struct.pack("<QQIIIIIIQQIIQQQQIIII", q, o, ldq, ldk, ldvt, ldo, nt, len(segs), q_bs, o_bs, kv_shift, flags, st_o, st_ml, k_bs, vt_bs,
@@ -28,15 +28,19 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
         k, vt, t = segs[i] if i < len(segs) else (0, 0, 0)
         b += struct.pack("<QQII", k, vt, t, 0)
     b += struct.pack("<Q", dbg)
+    magic = lambda d: -(-(1 << 32) // d) if d > 1 else 0   # noqa: E731
+    b += struct.pack("<QIIIIII", sched, n_work, nx, nxy, magic(nx), magic(nxy), grid)
     assert len(b) == attn_gen.ARG_SIZE
     return b
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
-    {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2)"""
+    {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2).  steal = G > 0: the work-stealing form -- G
+    persistent workgroups share the launch's {next, done} counter (emulated one after the other: the first one takes every item, the others
+    find the counter exhausted, the last one to leave zeroes it); `wgs` then lists the work items whose output is compared."""
     rng = np.random.default_rng(seed)
     HD = head_dim
     g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
@@ -74,8 +78,11 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
     st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
     a_dbg = mem.alloc(np.zeros(56, np.uint32)) if counters is not None else 0
+    nx = -(-tq // WQ)
+    a_sched = mem.alloc(np.zeros(2, np.uint32)) if steal else 0
+    sched_kw = dict(sched=a_sched, n_work=nx * n_heads * batch, nx=nx, nxy=nx * n_heads, grid=steal) if steal else {}
     common = dict(dbg=a_dbg, q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
-                  st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq)
+                  st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq, **sched_kw)
     launches = []
     if split_state:
         assert len(segs) >= 2 and batch == 1
@@ -87,9 +94,17 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
     worst = 0.0
+    if steal:
+        for karg in launches:
+            a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
+            for gidx in range(steal):
+                Workgroup(prog, mem, a_arg, (gidx, 0, 0), 4, g.lds_bytes, dtype).run(max_steps=100_000_000)
+                nxt, done = (int(v) for v in mem.get(a_sched, np.uint32, (2,)))
+                last = gidx == steal - 1
+                assert (nxt, done) == ((0, 0) if last else (nx * n_heads * batch + gidx + 1, gidx + 1)), (gidx, nxt, done)
     for wg in wgs:
         steps = 0
-        for karg in launches:
+        for karg in ([] if steal else launches):
             a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
             w = Workgroup(prog, mem, a_arg, wg, 4, g.lds_bytes, dtype)
             steps += w.run()

@@ -486,6 +486,27 @@ class Wave:
                     lds[addr[lane]:addr[lane] + 16] = data[:, lane].copy().view(np.uint8)
             self.lgkm.append(lambda: None)
             return
+        if op == "ds_write_b32":
+            addr = self.rd(a[0]).astype(np.int64) + int(it.mods.get("offset", 0) or 0)
+            data = self.rd(a[1]).copy()
+            for lane in range(64):
+                if (self.exec >> lane) & 1:
+                    assert addr[lane] % 4 == 0 and addr[lane] + 4 <= len(lds), "ds_write_b32 address"
+                    lds[addr[lane]:addr[lane] + 4] = np.array([data[lane]], np.uint32).view(np.uint8)
+            self.lgkm.append(lambda: None)
+            return
+        if op == "ds_read_b32":
+            dst, addr = a[0], self.rd(a[1]).astype(np.int64) + int(it.mods.get("offset", 0) or 0)
+            assert np.all(addr % 4 == 0) and addr.max() + 4 <= len(lds), "ds_read_b32 address"
+            data = np.array([lds[x:x + 4].view(np.uint32)[0] for x in addr], np.uint32)
+            self.poison(dst)
+            act = self.exec_lanes()
+
+            def land(dst=dst, data=data, act=act):
+                f = self.file(dst.kind)
+                f[dst.idx] = np.where(act, data, f[dst.idx])
+            self.lgkm.append(land)
+            return
         if op == "ds_bpermute_b32":
             idx = (self.rd(a[1]) >> 2) & 63
             data = self.rd(a[2])[idx].copy()
@@ -530,6 +551,23 @@ class Wave:
                 if (self.exec >> lane) & 1:
                     mem.write(base + off[lane], vals[:, lane].copy().view(np.uint8))
             self.vm.append(lambda: None)
+            return
+        if op == "global_atomic_add" and len(a) == 4:   # returning form (sc0): dst = the value before the add
+            dst, voff, src, sbase = a
+            base = self.rds64(sbase) + int(it.mods.get("offset", 0) or 0)
+            off = self.rd(voff).astype(np.int64)
+            vals = self.rd(src)
+            old = self.rd(dst).copy()
+            for lane in range(64):
+                if (self.exec >> lane) & 1:
+                    cur = mem.read(base + off[lane], 4).view(np.uint32)[0]
+                    old[lane] = cur
+                    mem.write(base + off[lane], np.array([(int(cur) + int(vals[lane])) & 0xFFFFFFFF], np.uint32).view(np.uint8))
+            self.poison(dst)
+
+            def land(dst=dst, old=old):
+                self.wr(dst, old)
+            self.vm.append(land)
             return
         if op == "global_atomic_add":
             voff, src, sbase = a

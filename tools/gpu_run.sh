@@ -142,7 +142,9 @@ PY
     benchquick) # the default line, short: live roofline + power sampler + n100 / fusion_only_n20 objects (no alt format, no CPU baseline, no hot weights)
       timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 --no-alt --no-cpu-baseline --no-hot ${BENCH_EXTRA:-} > $d/bench_quick.json 2> $d/err.log; tail -c 5000 $d/bench_quick.json; tail -5 $d/err.log ;;
     attnasm)    # the generated attention kernels (the clock bracket of round 5 touched prologue + epilogue)
-      timeout 900 python -m pytest tests/test_attn_asm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -15 > $d/pytest.log; tail -4 $d/pytest.log ;;
+      timeout 900 python -m pytest tests/test_attn_asm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -40 > $d/pytest.log; tail -12 $d/pytest.log ;;
+    steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
+      timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gputests)   # the whole GPU suite + smoke
       timeout 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider 2>&1 | tail -150 > $d/pytest.log; tail -5 $d/pytest.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;

@@ -426,6 +426,29 @@ if __name__ == "__main__":
             bench_gemm(torch.float16, M, 4096, 1024, f"fc1+gelu w2 M={M}", act="gelu", out="lp", split="w2", sels=sels)
             bench_gemm(torch.float16, M, 1024, 4096, f"fc2+res w2 M={M}", res=True, split="w2", sels=sels)
         sys.exit(0)
+    if args.what == "attnsteal":  # the fusion attention (T = 1024 x views, 16 heads, fp16) with f3r_attn_args.sched_counter off / on, interleaved
+        for nv in [int(x) for x in args.views.split(",")]:
+            T, H = nv * 1024, 16
+            q = (torch.randn((T, H * 64), device=DEV) * 0.2).half()
+            k = torch.randn((T, H * 64), device=DEV).half()
+            vt = torch.randn((H * 64, ops.vt_ld(T)), device=DEV).half()
+            o = torch.empty_like(q)
+            res = {False: [], True: []}
+            ops.ATTN_COUNTERS = None
+            for rnd_ in range(4):
+                for steal in (False, True):
+                    ops.ATTN_WORK_STEALING = steal
+                    f = lambda: ops.attention(q, o, H, 1.0, [(k, vt, T, 0, 0)], q_prescaled=True, kernel_sel=2)  # noqa: E731
+                    if rnd_ == 0:
+                        f()
+                    res[steal].append(time_ms(f, rounds=3, inner=1 if nv >= 100 else 8)[0])
+            fl = 4.0 * T * T * 64 * H
+            for steal in (False, True):
+                ms = sorted(res[steal])[len(res[steal]) // 2]
+                print(json.dumps({"kernel": "f3r_attn_asm_f16", "work_stealing": steal, "views": nv, "T": T, "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1),
+                                  "frac_of_peak": round(fl / ms / 1e9 / 2500.0, 4), "rounds_ms": [round(x, 3) for x in res[steal]]}), flush=True)
+            ops.ATTN_WORK_STEALING = True
+        sys.exit(0)
     if args.what == "convheads":  # the DPT-head convolutions and the encoder's QKV + RoPE-2D as the N = 320 forward runs them (fp16, X3 / W2; 25-view head chunks)
         f16 = torch.float16
         bench_conv(f16, 25, 256, 256, 256, 128, "head0 x3", split="x3", sels=(0,))
