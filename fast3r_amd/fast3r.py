@@ -1399,7 +1399,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 i0 = i1
         for i in range(n_loc):
             for name in per_view[i][0]:
-                results[i][name] = sink.result(i, name) if sink is not None else torch.stack([per_view[i][b][name] for b in range(B)], dim=0)
+                if sink is not None:
+                    results[i][name] = sink.result(i, name)
+                elif B == 1:   # one sample: the (1, H, W[, 3]) result IS the head chunk's row (no copy: 4 N device-to-device copies per forward otherwise)
+                    results[i][name] = per_view[i][0][name].unsqueeze(0)
+                else:
+                    results[i][name] = torch.stack([per_view[i][b][name] for b in range(B)], dim=0)
         if sink is not None:
             sink.finish()
         if sh is not None:

@@ -70,7 +70,10 @@ def synth_tensor(key: str, shape, seed: int = 0, dist: str = "default") -> torch
         This is the protocol of BASELINE.md section 3 / SURVEY.md section 8c (the 1e-3 rel-L2 yardstick).
     dist="hot": weights ~ N(0, 1/fan_in) (3x the variance): attention logits have std ~1.3 instead of ~0.15, so the
         softmax is far from uniform and rounding noise is amplified instead of averaged away -- a stress distribution.
-    LayerNorm gamma ~ 1 + 0.1 N(0,1), beta ~ 0.02 N(0,1) in both (so gamma/beta mistakes cannot hide).
+    dist="heavy" (round 5, a second stress distribution): weights ~ Student-t with 4 degrees of freedom scaled to variance 1/fan_in
+        (outlier weights: a few products dominate a dot product, which is where 16-bit operand rounding shows), LayerNorm gains
+        log-uniform in [0.2, 5] per channel (channels of very different scale in every GEMM operand).
+    LayerNorm gamma ~ 1 + 0.1 N(0,1), beta ~ 0.02 N(0,1) in the first two (so gamma/beta mistakes cannot hide).
     """
     g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) & 0x7FFFFFFF)
     shape = tuple(shape)
@@ -79,6 +82,8 @@ def synth_tensor(key: str, shape, seed: int = 0, dist: str = "default") -> torch
         return 0.5 * torch.randn(shape, generator=g)
     if is_norm:
         if key.endswith("weight"):
+            if dist == "heavy" and not key.endswith(".gamma"):
+                return torch.exp((torch.rand(shape, generator=g) * 2 - 1) * math.log(5.0))
             return 1.0 + 0.1 * torch.randn(shape, generator=g)
         return 0.02 * torch.randn(shape, generator=g)
     if len(shape) >= 2:
@@ -90,9 +95,15 @@ def synth_tensor(key: str, shape, seed: int = 0, dist: str = "default") -> torch
         if dist == "hot":
             gain = 0.1 if key.endswith("dpt.head.4.weight") else 1.0  # keeps |xyz| = O(1) ahead of expm1 / exp
             return torch.randn(shape, generator=g) * (gain / math.sqrt(eff))
+        if dist == "heavy":
+            gain = 0.1 if key.endswith("dpt.head.4.weight") else 1.0
+            z = torch.randn(shape, generator=g)
+            chi2 = sum(torch.randn(shape, generator=g) ** 2 for _ in range(4))
+            t4 = z / torch.sqrt(chi2 / 4.0)                  # Student-t, nu = 4: variance nu / (nu - 2) = 2
+            return t4 * (gain / math.sqrt(2.0 * eff))
         bound = 1.0 / math.sqrt(fan_in)
         return (torch.rand(shape, generator=g) * 2 - 1) * bound
-    if dist == "hot":
+    if dist in ("hot", "heavy"):
         return 0.02 * torch.randn(shape, generator=g)
     # bias: U(+-1/sqrt(fan_in)); fan_in is not recoverable from the bias shape alone, use the layer width as proxy
     return (torch.rand(shape, generator=g) * 2 - 1) * (1.0 / math.sqrt(max(shape[0], 1)))
