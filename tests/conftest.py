@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: GPU tests kept out of `-m gpu` to hold the driver's suite under 10 minutes (run with -m gpu_slow; "
+                                       "tools/gpu_run.sh gpuslow); every one has a faster sibling in `-m gpu`")
     # The CPU oracle (torch fp32) is the checker of most GPU tests.  On the GPU boxes torch defaults to one thread per hardware thread
     # (256): the ViT-L oracle then runs ~100x SLOWER than at 32 threads (measured: 239 s vs 2.2 s per 512x512 view), which turned the
     # GPU suite into 15 minutes of CPU oversubscription.  Cap it at the count bench.py's cpu_baseline sweep finds fastest on those boxes
@@ -26,3 +28,13 @@ def built_lib():
         import __graft_entry__
         __graft_entry__.build()
     return _lib.lib()
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu_slow` tests also carry their module's `gpu` marker: keep them out of a plain `-m gpu` run (the driver's), in unless asked for"""
+    if "gpu_slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="gpu_slow: run with -m gpu_slow (tools/gpu_run.sh gpuslow)")
+    for it in items:
+        if it.get_closest_marker("gpu_slow"):
+            it.add_marker(skip)

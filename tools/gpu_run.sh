@@ -145,8 +145,12 @@ PY
       timeout 900 python -m pytest tests/test_attn_asm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -40 > $d/pytest.log; tail -12 $d/pytest.log ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
+    gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)
+      timeout 1800 python -m pytest tests -m gpu_slow -q -rA -s -p no:cacheprovider 2>&1 | tail -40 > $d/pytest.log; grep -E "passed|failed|\[parity" $d/pytest.log | tail -12 ;;
+    two)        # selected tests, verbose
+      timeout 900 python -m pytest ${TWO_TESTS} -q -x -s -rA -p no:cacheprovider > $d/pytest.log 2>&1; grep -E "\[parity\]|\[exact|passed|failed|Error|assert" $d/pytest.log | cut -c1-400 | tail -30 ;;
     gputests)   # the whole GPU suite + smoke
-      timeout 2400 python -m pytest tests -m gpu -q -rA -s --durations=70 -p no:cacheprovider > $d/pytest_full.log 2>&1; grep -E "^\[parity\]|^\[exact" $d/pytest_full.log > $d/parity_lines.txt; sed -n '/slowest/,/short test summary/p' $d/pytest_full.log > $d/durations.txt; grep -E "passed|failed" $d/pytest_full.log | tail -3; grep -E "^(FAILED|ERROR)" $d/pytest_full.log | head -20; tail -150 $d/pytest_full.log > $d/pytest.log; rm -f $d/pytest_full.log
+      timeout 2400 python -m pytest tests -m gpu -q -rA -s --durations=70 -p no:cacheprovider > $d/pytest_full.log 2>&1; grep -E "^\[parity\]|^\[exact" $d/pytest_full.log > $d/parity_lines.txt; sed -n '/slowest/,/short test summary/p' $d/pytest_full.log > $d/durations.txt; grep -E "passed|failed" $d/pytest_full.log | tail -3; grep -E "^(FAILED|ERROR)" $d/pytest_full.log | head -20; sed -n '/=== FAILURES ===/,/=== short test summary/p' $d/pytest_full.log | tail -400 > $d/failures.txt; grep -E "\[parity\]|\[exact" $d/pytest_full.log | sed 's/^[.sF]*//' > $d/parity_lines.txt; tail -150 $d/pytest_full.log > $d/pytest.log; rm -f $d/pytest_full.log
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $d/smoke.log 2>&1; tail -2 $d/smoke.log ;;
     hot100)     # N = 100 on the hot weights: views/s, attention frac, re-base rate, parity vs the exact mode -- and the default weights beside it
       timeout 900 python bench.py --views 100 --weights hot --steps 3 --warmup 1 --no-alt --no-cpu-baseline --parity-exact > $d/bench_n100_hot.json 2> $d/hot.err; tail -c 1500 $d/bench_n100_hot.json
