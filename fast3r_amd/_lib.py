@@ -13,7 +13,7 @@ F3R_F16, F3R_BF16 = 0, 1
 F3R_A_PLAIN, F3R_A_CONV3X3 = 0, 1
 F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_EPI_CONVT = 0, 1, 2
 F3R_ACT_NONE, F3R_ACT_GELU, F3R_ACT_RELU = 0, 1, 2
-F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3 = 0, 1, 2
+F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3, F3R_SPLIT_W2F8 = 0, 1, 2, 3
 F3R_MAX_SEG = 8
 
 _c_i64, _c_i32, _c_f32, _c_vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
@@ -41,6 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("split", _c_i32), ("kernel_sel", _c_i32), ("A_lo", _c_vp),
         ("out_lp_lo", _c_vp), ("res_lp_lo", _c_vp), ("res_lp2_lo", _c_vp), ("out_relu", _c_vp), ("out_relu_lo", _c_vp),
         ("qkv_dq", _c_i32), ("reserved1", _c_i32),
+        ("w_scale", _c_vp),
     ]
 
 
@@ -84,6 +85,7 @@ SYMBOLS = {
     "f3r_patchify": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_interp_bilinear": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp] + [ctypes.c_int] * 9 + [_c_vp]),
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
+    "f3r_layernorm_f8": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
     "f3r_attn_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(AttnArgs)]),

@@ -100,6 +100,8 @@ int f3r_gemm256_lab(const f3r_gemm_args& a, hipStream_t stream);  // -DF3R_GEMM_
 bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why);
 bool f3r_gemm_asm_preferred(int64_t tiles);  // does a launch of that many 256 x 256 tiles fill the persistent grid well enough?
 int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream);
+bool f3r_gemm_asm_f8_eligible(const f3r_gemm_args& a, const char** why);   // F3R_SPLIT_W2F8: the kernels with the low plane in fp8
+int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream);
 bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why);  // the QKV projection without rotary embedding, as two launches
 int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream);
 

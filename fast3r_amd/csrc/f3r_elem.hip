@@ -65,10 +65,12 @@ __global__ void patchify_any_kernel(const float* __restrict__ img, uint16_t* __r
 // ------------------------------------------------------------------------------------------ layernorm
 // one wave per row; D % 4 == 0; float4 loads; two-pass (mean, then centred variance) from registers when
 // D <= 2048 (8 float4 per lane), otherwise re-reads the row.
-template <class T, int MAXV>
+// ld_lp: row stride of out_lp in elements (D for the plain form).  F8: every row also gets an fp8 (e4m3) copy of the same values, clamped to
+// +-448 (v_cvt_pk_fp8_f32 turns anything larger into NaN: tools/ubench/mfma_scale_probe.py), D elements behind its start (f3r_split W2F8).
+template <class T, int MAXV, bool F8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, uint16_t* __restrict__ out_lp,
-                                                        float* __restrict__ out_f32, int64_t rows, int D, float eps, int rms) {
+                                                        float* __restrict__ out_f32, int64_t rows, int D, float eps, int rms, int64_t ld_lp = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -113,7 +115,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         u32x2 o;
         o[0] = pack2<T>(y[0], y[1]);
         o[1] = pack2<T>(y[2], y[3]);
-        *(u32x2*)(out_lp + row * D + idx * 4) = o;
+        if (F8) {
+          uint16_t* r16 = out_lp + row * ld_lp;
+          *(u32x2*)(r16 + idx * 4) = o;
+          float4v c;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) c[t] = fminf(fmaxf(y[t], -448.f), 448.f);
+          int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w8, true);
+          *(int*)((uint8_t*)(r16 + D) + idx * 4) = w8;
+        } else {
+          *(u32x2*)(out_lp + row * D + idx * 4) = o;
+        }
       }
     }
   }
@@ -429,6 +442,22 @@ extern "C" int f3r_layernorm(const float* x, const float* gamma, const float* be
   }
 #undef LN_LAUNCH
   return f3r_check_launch("f3r_layernorm");
+}
+
+extern "C" int f3r_layernorm_f8(const float* x, const float* gamma, const float* beta, void* out_rows, int64_t ld_out, int64_t rows, int D, float eps, int rms,
+                                f3r_stream_t stream) {
+  F3R_REQUIRE(x && gamma && out_rows && al16(x) && al16(gamma) && al16(beta) && al16(out_rows), "f3r_layernorm_f8: null/misaligned pointer");
+  F3R_REQUIRE(D > 0 && D % 8 == 0 && D <= 8192, "f3r_layernorm_f8: D %d must be a multiple of 8, <= 8192", D);
+  F3R_REQUIRE(ld_out % 8 == 0 && ld_out * 2 >= (int64_t)D * 3, "f3r_layernorm_f8: ld_out %lld must be a multiple of 8 and >= 3 D / 2", (long long)ld_out);
+  if (rows <= 0) return F3R_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = nblk(rows, 4);
+#define LN8_LAUNCH(MV) \
+  hipLaunchKernelGGL((layernorm_kernel<F16, MV, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, (uint16_t*)out_rows, (float*)nullptr, rows, D, eps, rms, ld_out)
+  const int nv = (D / 4 + 63) / 64;
+  if (nv <= 4) LN8_LAUNCH(4); else if (nv <= 8) LN8_LAUNCH(8); else LN8_LAUNCH(32);
+#undef LN8_LAUNCH
+  return f3r_check_launch("f3r_layernorm_f8");
 }
 
 extern "C" int f3r_interp_bilinear(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int full_h,

@@ -310,7 +310,19 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   const f3r_gemm_args& a = *args;
   F3R_REQUIRE(a.A && a.W, "f3r_gemm: null operand");
   F3R_REQUIRE(a.M >= 0 && a.N > 0, "f3r_gemm: bad M/N (%lld, %d)", (long long)a.M, a.N);
-  F3R_REQUIRE(a.split >= F3R_SPLIT_NONE && a.split <= F3R_SPLIT_X3, "f3r_gemm: bad split %d", a.split);
+  F3R_REQUIRE(a.split >= F3R_SPLIT_NONE && a.split <= F3R_SPLIT_W2F8, "f3r_gemm: bad split %d", a.split);
+  if (a.split == F3R_SPLIT_W2F8) {  // rows of [K fp16 | K fp8] on both operands: one kernel family takes them (f3r_gemm_asm.hip), nothing else does
+    F3R_REQUIRE(al16(a.A) && al16(a.W) && a.w_scale && (((uintptr_t)a.w_scale) & 3) == 0, "f3r_gemm: W2F8 needs 16-byte aligned A / W and w_scale");
+    F3R_REQUIRE(a.K > 0 && a.K % 128 == 0 && a.Kpad == a.K, "f3r_gemm: W2F8 needs K = Kpad, a multiple of 128 (got %d / %d)", a.K, a.Kpad);
+    F3R_REQUIRE(a.lda % 8 == 0 && a.lda * 2 >= (int64_t)a.K * 3, "f3r_gemm: W2F8 rows are [K fp16 | K fp8]: lda %lld must be >= 3 K / 2", (long long)a.lda);
+    F3R_REQUIRE(a.epi != F3R_EPI_GENERIC || a.out_f32 || a.out_lp, "f3r_gemm: no output");
+    const char* why = "";
+    if (!f3r_gemm_asm_f8_eligible(a, &why)) {
+      f3r_set_error("f3r_gemm: split W2F8 (fp8 low plane) but the launch is not eligible for the hand-scheduled kernel: %s", why);
+      return F3R_ERR_UNSUPPORTED;
+    }
+    return f3r_gemm_asm_f8_launch(a, (hipStream_t)stream);
+  }
   const int planes = a.split ? 2 : 1;
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;

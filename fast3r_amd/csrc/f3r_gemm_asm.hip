@@ -28,8 +28,11 @@ struct f3r_gemm_asm_args {
   uint32_t tps, tps_magic;              // n tiles per segment, ceil(2^32 / tps)
   float scale;                          // ACT_SCALE: segment 0 is multiplied by it
   uint32_t flags, nk1_w, pad;           // FLAG_BIAS_ON_M = 1; wrap period of the W stream
+  // ---- ARG_F8: read by the f8 kernels only (their kernarg segment is 144 bytes, the others' 128)
+  const uint32_t* w_scale;              // E8M0 scale words of the weight rows' fp8 plane
+  uint32_t nk8, pad8;                   // fp8 K-tiles ([256][128 k]) at the end of every output tile's K loop
 };
-static_assert(sizeof(f3r_gemm_asm_args) == 128 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
+static_assert(sizeof(f3r_gemm_asm_args) == 144 && offsetof(f3r_gemm_asm_args, w_scale) == 128 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
               offsetof(f3r_gemm_asm_args, seg_stride) == 96 && offsetof(f3r_gemm_asm_args, nk1_w) == 120, "must match ARG_* of gemm_gen.py");
 enum { ACT_SCALE = 3, FLAG_BIAS_ON_M = 1 };
 
@@ -38,13 +41,14 @@ struct DevKernels {
   bool tried = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [role][F3R_F16 | F3R_BF16]
+  hipFunction_t fn8[2] = {nullptr, nullptr};                          // [role]: the fp16 kernels with the low plane in fp8
 };
 std::map<int, DevKernels> g_dev;  // one code-object handle per device (see f3r_attn_asm.hip)
 std::mutex g_mu;
 
-hipFunction_t get_fn(int role, int dtype) {
+hipFunction_t get_fn(int role, int dtype, bool f8 = false) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1 || (f8 && dtype != F3R_F16)) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevKernels& d = g_dev[dev];
   if (!d.tried) {
@@ -54,10 +58,13 @@ hipFunction_t get_fn(int role, int dtype) {
       for (int r = 0; r < 2; ++r)
         for (int t = 0; t < 2; ++t)
           if (hipModuleGetFunction(&d.fn[r][t], d.mod, names[r][t]) != hipSuccess) d.fn[r][t] = nullptr;
+      static const char* names8[2] = {"f3r_gemm_asm_f328_f16", "f3r_gemm_asm_lp8_f16"};
+      for (int r = 0; r < 2; ++r)
+        if (hipModuleGetFunction(&d.fn8[r], d.mod, names8[r]) != hipSuccess) d.fn8[r] = nullptr;
     }
     (void)hipGetLastError();
   }
-  return d.fn[role][dtype];
+  return f8 ? d.fn8[role] : d.fn[role][dtype];
 }
 
 int role_of(const f3r_gemm_args& a) { return a.out_f32 ? ROLE_F32 : ROLE_LP; }
@@ -139,7 +146,7 @@ int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, h
   const int cus = num_cus();
   k.n_wg = n_wg;
   k.grid = n_wg < (uint32_t)cus ? n_wg : (uint32_t)cus;
-  size_t size = sizeof(k);
+  size_t size = k.w_scale ? sizeof(k) : offsetof(f3r_gemm_asm_args, w_scale);   // the kernarg segment of the kernel taking the launch
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   hipError_t e = hipModuleLaunchKernel(fn, k.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
@@ -176,6 +183,58 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.nk1_w = k.nk;  // the weight row holds its planes back to back: that stream never wraps
   k.act = (uint32_t)a.act;
   k.scale = 1.0f;
+  return launch_tiles(fn, k, a.M, a.N, stream);
+}
+
+// ---- F3R_SPLIT_W2F8: rows [K fp16 | K fp8] on both operands, the K loop runs on from K / 64 fp16 K-tiles into K / 128 fp8 ones
+bool f3r_gemm_asm_f8_eligible(const f3r_gemm_args& a, const char** why) {
+  *why = "";
+  if (a.dtype != F3R_F16) { *why = "the fp8 low plane corrects fp16 planes only"; return false; }
+  if (a.a_mode != F3R_A_PLAIN || a.epi != F3R_EPI_GENERIC) { *why = "not a plain GEMM with the generic epilogue"; return false; }
+  if (a.M <= 0 || a.M % 256 != 0 || a.N % 256 != 0) { *why = "M or N not a multiple of 256"; return false; }
+  if (a.K % 128 != 0 || a.K / 64 + a.K / 128 < 4) { *why = "K not a multiple of 128, or fewer than 4 K-tiles"; return false; }
+  if (a.rowadd || a.res_lp || a.res_lp2 || a.out_lp_lo || a.out_relu || a.out_relu_lo || a.A_lo) { *why = "additive rows / lowp residuals / second outputs / A_lo"; return false; }
+  if (a.out_f32 && a.out_lp) { *why = "both an fp32 and a lowp output"; return false; }
+  if (a.out_f32) {
+    if (a.act != F3R_ACT_NONE) { *why = "activation on the fp32 role"; return false; }
+    if ((a.ldo_f32 * 4) % 16 != 0 || (a.res_f32 && (a.ldr_f32 * 4) % 16 != 0)) { *why = "fp32 row strides not multiples of 16 bytes"; return false; }
+    if ((int64_t)256 * a.ldo_f32 * 4 >= (1ll << 32) || (a.res_f32 && (int64_t)256 * a.ldr_f32 * 4 >= (1ll << 32))) { *why = "fp32 row strides too large"; return false; }
+  } else {
+    if (a.res_f32) { *why = "fp32 residual with a lowp output"; return false; }
+    if ((((uintptr_t)a.out_lp) & 15) != 0 || (a.ldo_lp * 2) % 16 != 0) { *why = "lowp output not 16-byte aligned"; return false; }
+    if ((int64_t)256 * a.ldo_lp * 2 >= (1ll << 32)) { *why = "lowp row stride too large"; return false; }
+  }
+  if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.K * 3 >= (1ll << 32)) { *why = "operand row strides too large for 32-bit lane offsets"; return false; }
+  if ((a.M / 256) * (int64_t)(a.N / 256) >= (1ll << 24) || !tile_map_exact(a.M / 256, a.N / 256, a.N / 256)) { *why = "grid too large"; return false; }
+  if (get_fn(role_of(a), a.dtype, true) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  return true;
+}
+
+int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream) {
+  const int role = role_of(a);
+  hipFunction_t fn = get_fn(role, a.dtype, true);
+  if (!fn) {
+    f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
+    return F3R_ERR_LAUNCH;
+  }
+  f3r_gemm_asm_args k;
+  memset(&k, 0, sizeof(k));
+  k.A = a.A;
+  k.W = a.W;
+  k.bias = a.bias;
+  k.res = role == ROLE_F32 ? a.res_f32 : nullptr;
+  k.out = role == ROLE_F32 ? (void*)a.out_f32 : a.out_lp;
+  k.lda_b = (uint32_t)(a.lda * 2);
+  k.ldw_b = (uint32_t)((int64_t)a.K * 3);
+  k.ldr_b = (uint32_t)(a.ldr_f32 * 4);
+  k.ldo_b = role == ROLE_F32 ? (uint32_t)(a.ldo_f32 * 4) : (uint32_t)(a.ldo_lp * 2);
+  k.nk8 = (uint32_t)(a.K / 128);
+  k.nk = (uint32_t)(a.K / 64) + k.nk8;
+  k.nk1 = k.nk;     // neither stream wraps: both rows hold the fp8 plane behind the fp16 one
+  k.nk1_w = k.nk;
+  k.act = (uint32_t)a.act;
+  k.scale = 1.0f;
+  k.w_scale = a.w_scale;
   return launch_tiles(fn, k, a.M, a.N, stream);
 }
 

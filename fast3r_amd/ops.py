@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (AttnArgs, F3R_A_CONV3X3, F3R_A_PLAIN, F3R_ACT_GELU, F3R_ACT_NONE, F3R_ACT_RELU, F3R_EPI_CONVT,
-                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3, GemmArgs, check, dtype_id,
+                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_W2F8, F3R_SPLIT_X3, GemmArgs, check, dtype_id,
                    ptr, require_gpu, stream_ptr)
 
 ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F3R_ACT_RELU}
@@ -40,7 +40,7 @@ def round_up(x: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------------------- weight packing (host, once)
-SPLIT = {None: F3R_SPLIT_NONE, 0: F3R_SPLIT_NONE, "none": F3R_SPLIT_NONE, "w2": F3R_SPLIT_W2, "x3": F3R_SPLIT_X3}
+SPLIT = {None: F3R_SPLIT_NONE, 0: F3R_SPLIT_NONE, "none": F3R_SPLIT_NONE, "w2": F3R_SPLIT_W2, "x3": F3R_SPLIT_X3, "w2f8": F3R_SPLIT_W2F8}
 
 
 def split_planes(w: torch.Tensor, lp: torch.dtype):
@@ -61,6 +61,27 @@ def pack_linear_weight(w: torch.Tensor, lp: torch.dtype, split: bool = False) ->
     else:
         out[:, :k] = w.to(lp)
     return out
+
+
+def pack_linear_weight_f8(w: torch.Tensor):
+    """nn.Linear weight (N, K) fp32 -> the operand of f3r_gemm split "w2f8" (include/f3r.h F3R_SPLIT_W2F8): rows [K fp16 hi | K fp8 e4m3((W - hi)
+    2^s_n)] as a float16-typed [N][3 K / 2] tensor, and the [N] int32 scale words (E8M0 byte 127 - s_n in all four bytes): one power-of-two
+    scale per output channel brings the largest |W - hi| of the row to [112, 224] (e4m3 tops out at 448; what falls below its 2^-9 subnormals
+    is 2^-17 of that and contributes nothing).  K must be a multiple of 128."""
+    w = w.reshape(w.shape[0], -1).float()
+    n, k = w.shape
+    assert k % 128 == 0, "w2f8: K must be a multiple of 128"
+    hi = w.to(torch.float16)
+    lo = w - hi.float()
+    amax = lo.abs().amax(dim=1).clamp_min(2.0 ** -100)
+    s = torch.floor(torch.log2(224.0 / amax)).clamp(-100, 120)
+    lo8 = (lo * torch.exp2(s)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    out = torch.empty((n, 3 * k), dtype=torch.uint8, device=w.device)
+    out[:, :2 * k] = hi.contiguous().view(torch.uint8).view(n, 2 * k)
+    out[:, 2 * k:] = lo8.view(torch.uint8)
+    e8 = (127 - s).to(torch.int64)
+    words = (e8 | (e8 << 8) | (e8 << 16) | (e8 << 24)).to(torch.int32)   # (e8 < 256: fits)
+    return out.view(torch.float16).view(n, 3 * k // 2), words.contiguous()
 
 
 def pack_conv3x3_weight(w: torch.Tensor, lp: torch.dtype, split: bool = False) -> torch.Tensor:
@@ -122,6 +143,21 @@ def layernorm(x, gamma, beta, eps, lp, out_lp=None, out_f32=None, want_lp=True, 
     return out_lp, out_f32
 
 
+def layernorm_f8(x, gamma, beta, eps, out_rows=None, rms=False):
+    """LayerNorm / RMSNorm -> rows [D fp16 | D fp8] (float16-typed [rows][3 D / 2]): the A operand of gemm(split="w2f8"); out_rows[:, :D] is the
+    plain fp16 output (any GEMM reads it with its row stride)."""
+    require_gpu(x, "x")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if out_rows is None:
+        out_rows = torch.empty((rows, 3 * D // 2), dtype=torch.float16, device=x.device)
+    assert out_rows.dtype == torch.float16 and out_rows.stride(1) == 1 and out_rows.shape[1] == 3 * D // 2
+    check(_lib.lib().f3r_layernorm_f8(ptr(x), ptr(gamma), ptr(beta), ptr(out_rows), out_rows.stride(0), rows, D, float(eps), int(rms), stream_ptr()),
+          "f3r_layernorm_f8")
+    return out_rows
+
+
 def _split_operand(g, a, split, a_lo):
     """Common split-precision plumbing: g.split and, for "x3", the low plane of A (same shape / strides as A)."""
     g.split = SPLIT[split]
@@ -132,8 +168,9 @@ def _split_operand(g, a, split, a_lo):
 
 def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f32=None, res_lp=None, res_lp2=None,
          out_f32=None, out_lp=None, want_f32=False, want_lp=False, split=None, a_lo=None, res_lp_lo=None, res_lp2_lo=None,
-         out_lp_lo=None, want_lo=False, kernel_sel=0):
+         out_lp_lo=None, want_lo=False, kernel_sel=0, w_scale=None):
     """out = act(A W^T + bias) [+ rowadd[m//div]] [+ residuals].  a: lowp [M][lda>=K]; w: packed lowp [N][Kpad].
+    split "w2f8" (+ w_scale): a = rows [K fp16 | K fp8] (layernorm_f8), w / w_scale from pack_linear_weight_f8.
     split "w2" / "x3": w packed with split=True ([hi | lo] planes), "x3" also takes a_lo (f3r.h f3r_split); *_lo: low planes of the lowp
     residuals / output.  Returns (out_f32, out_lp) or, with want_lo / out_lp_lo, (out_f32, out_lp, out_lp_lo)."""
     require_gpu(a, "a")
@@ -142,6 +179,10 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
     M = a.shape[0]
     N, Kpad = w.shape
     K = a.shape[1] if K is None else K
+    if split == "w2f8":
+        assert w_scale is not None and w_scale.dtype == torch.int32 and w_scale.numel() == N and lp == torch.float16
+        K = Kpad = 2 * w.shape[1] // 3
+        assert a.shape[1] * 2 >= 3 * K
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if (want_lp or want_lo) and out_lp is None:
@@ -176,6 +217,8 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
         assert res_lp2 is not None and res_lp2_lo.stride(0) == res_lp2.stride(0)
         g.res_lp2_lo = ptr(res_lp2_lo)
     g.dtype = dtype_id(lp)
+    if w_scale is not None:
+        g.w_scale = ptr(w_scale)
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
     if out_lp_lo is not None:
         return out_f32, out_lp, out_lp_lo

@@ -73,6 +73,10 @@ int f3r_patchify(const float* img, void* out, int batch, int H, int W, int ps, i
  */
 int f3r_layernorm(const float* x, const float* gamma, const float* beta, void* out_lp, float* out_f32,
                   int64_t rows, int D, float eps, int rms, int dtype, f3r_stream_t stream);
+/* the same LayerNorm / RMSNorm writing the operand rows of F3R_SPLIT_W2F8 (f3r_split): out row r = [D fp16 | D fp8 e4m3 of the same values
+   clamped to +-448], ld_out sixteen-bit elements apart (>= 3 D / 2, a multiple of 8).  fp16 only; D % 8 == 0. */
+int f3r_layernorm_f8(const float* x, const float* gamma, const float* beta, void* out_rows, int64_t ld_out, int64_t rows, int D, float eps, int rms,
+                     f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_gemm: out = epilogue( A(M,K) * W(N,K)^T ) on MFMA, fp32 accumulate.
@@ -163,9 +167,18 @@ typedef struct f3r_gemm_args {
      0 = three equal thirds (N / 3 each).  Both widths must be multiples of 64 (whole heads). */
   int32_t qkv_dq;
   int32_t reserved1;
+  const uint32_t* w_scale; /* F3R_SPLIT_W2F8: [N] scale words of the weight rows' fp8 plane (see f3r_split); NULL otherwise (ABI 330) */
 } f3r_gemm_args;
 
-typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2 } f3r_split;
+/* F3R_SPLIT_W2F8 (ABI 330): W2 with the LOW plane of the weights, and the copy of the activations it multiplies, in fp8 (OCP e4m3) on the
+   block-scaled MFMA of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4: 1.40x the matrix-pipe rate of the two-fp16-plane form under the power cap,
+   profiles/r05_ubench_mfma_mixed_fp16_fp8_fp6.jsonl): A(M, K) rows are [K fp16 | K fp8] (lda >= 3 K / 2 sixteen-bit elements; the fp8 copy holds
+   the same numbers clamped to +-448: f3r_layernorm_f8 writes such rows), W rows are [K fp16 hi | K fp8 e4m3((W - hi) 2^s_n)] (row stride 3 K
+   bytes: Kpad = K, a multiple of 128) with one power-of-two scale per output channel in w_scale (E8M0 byte 127 - s_n replicated into the four
+   bytes of a word).  The correction term A W_lo is 2^-11 of the product and tolerates the 2^-4 relative error of both fp8 operands: the
+   weight's rounding error drops ~24x instead of vanishing (tools/emu_gemm.py run_case_f8).  fp16 operands, plain A, GENERIC epilogue with ONE
+   output (as kernel_sel 6), M and N multiples of 256 -- anything else is F3R_ERR_UNSUPPORTED (there is no second kernel for this layout). */
+typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2, F3R_SPLIT_W2F8 = 3 } f3r_split;
 
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 

@@ -154,3 +154,79 @@ def test_gemm_asm_at_the_n100_shapes_matches_the_compiler_scheduled_kernel(built
                 outs.append(x)
         d = float((outs[0] - outs[1]).abs().max())
         assert d <= (lp_tol(dt) if act else 3e-5) * float(outs[1].abs().max()), d
+
+
+def _f8_operands(M, K, N, seed, outliers=True):
+    """activation rows [K fp16 | K fp8] as f3r_layernorm_f8 writes them, weight rows + scale words from pack_linear_weight_f8, and the planes decoded"""
+    g = torch.Generator().manual_seed(seed)
+    a32 = torch.randn((M, K), generator=g) * 2.0
+    if outliers:
+        a32.view(-1)[torch.randint(0, M * K, (60,), generator=g)] *= 300.0      # beyond +-448: clamped in the fp8 copy
+    w32 = torch.randn((N, K), generator=g) * K ** -0.5 * torch.exp2(torch.randint(-6, 3, (N, 1), generator=g).float())
+    a16 = a32.to(torch.float16)
+    a8 = a16.float().clamp(-448, 448).to(torch.float8_e4m3fn)
+    rows = torch.empty((M, 3 * K), dtype=torch.uint8)
+    rows[:, :2 * K] = a16.contiguous().view(torch.uint8).view(M, 2 * K)
+    rows[:, 2 * K:] = a8.view(torch.uint8)
+    wp, ws = ops.pack_linear_weight_f8(w32)
+    wb = wp.view(torch.uint8).view(N, 3 * K)
+    w_hi = wb[:, :2 * K].contiguous().view(torch.float16).view(N, K).double()
+    w_lo = wb[:, 2 * K:].contiguous().view(torch.float8_e4m3fn).double() * torch.exp2((ws & 0xFF).double() - 127.0)[:, None]
+    planes = a16.double() @ w_hi.t() + a8.double() @ w_lo.t()
+    return rows.view(torch.float16).view(M, 3 * K // 2), wp, ws, planes, a16.double() @ w32.double().t(), a16.double() @ w_hi.t()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (768, 512, 384), (2048, 1024, 1024), (2304, 256, 4096), (70 * 256, 1024, 512), (300 * 256, 256, 640)])
+def test_gemm_asm_fp8_low_plane(built_lib, M, N, K):
+    """F3R_SPLIT_W2F8 (round 5): the K loop runs on from K / 64 fp16 K-tiles into K / 128 fp8 K-tiles of the same two operand streams (block-scaled
+    v_mfma_scale_f32_32x32x64_f8f6f4, one power-of-two scale per output channel).  (a) the kernel computes exactly its planes: fp64 on the decoded
+    fp16 + fp8 operands, both roles, bias / residual / GELU, persistent workgroups crossing output tiles; (b) what the format is for: the distance
+    to the product with the UNROUNDED weight is several times smaller than with a single fp16 plane."""
+    rows, wp, ws, planes, exact_w, single = _f8_operands(M, K, N, 11 + K)
+    bias, x = torch.randn(N), torch.randn(M, N)
+    base = planes + bias.double()
+    rd, wd, sd = rows.to(DEV), wp.to(DEV), ws.to(DEV)
+    f32, _ = ops.gemm(rd, wd, bias=bias.to(DEV), want_f32=True, split="w2f8", w_scale=sd)
+    assert_close(f32, base, 2e-5, "w2f8 f32")
+    xg = x.clone().to(DEV)
+    ops.gemm(rd, wd, bias=bias.to(DEV), res_f32=xg, out_f32=xg, split="w2f8", w_scale=sd)
+    assert_close(xg, base + x.double(), 2e-5, "w2f8 residual in place")
+    f32n, _ = ops.gemm(rd, wd, want_f32=True, split="w2f8", w_scale=sd)
+    assert_close(f32n, planes, 2e-5, "w2f8 no bias")
+    _, y = ops.gemm(rd, wd, bias=bias.to(DEV), act="gelu", want_lp=True, split="w2f8", w_scale=sd)
+    assert_close(y.float(), F.gelu(base), lp_tol(torch.float16), "w2f8 gelu")
+    _, y = ops.gemm(rd, wd, bias=bias.to(DEV), want_lp=True, split="w2f8", w_scale=sd)
+    assert_close(y.float(), base, lp_tol(torch.float16), "w2f8 lowp")
+    # (b) on operands without out-of-range activations (the clamp is a property of the fp8 copy, not of the weight planes)
+    rows, wp, ws, planes, exact_w, single = _f8_operands(M, K, N, 12 + K, outliers=False)
+    got, _ = ops.gemm(rows.to(DEV), wp.to(DEV), want_f32=True, split="w2f8", w_scale=ws.to(DEV))
+    e8 = float((got.double().cpu() - exact_w).abs().max() / exact_w.abs().max())
+    e1 = float((single - exact_w).abs().max() / exact_w.abs().max())
+    print(f"[w2f8] {M}x{N}x{K}: weight rounding left {e8:.2e} (single fp16 plane {e1:.2e})")
+    assert e8 <= e1 / 6.0
+
+
+def test_gemm_fp8_low_plane_refuses_what_it_cannot_take(built_lib):
+    """no second kernel reads the [fp16 | fp8] rows: an ineligible launch is an error, never a wrong answer"""
+    rows, wp, ws, *_ = _f8_operands(256, 256, 256, 3)
+    with pytest.raises(Exception):
+        ops.gemm(rows[:200].to(DEV), wp.to(DEV), want_f32=True, split="w2f8", w_scale=ws.to(DEV))       # M not a multiple of 256
+
+
+def test_layernorm_f8_rows(built_lib):
+    """f3r_layernorm_f8: the fp16 part of a row is bit-identical to f3r_layernorm's output, the fp8 part is e4m3(clamp(y, +-448)) of the fp32 result"""
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn((777, 1024), generator=g) * 3.0)
+    x[5, 17] = 4000.0
+    gamma, beta = 1 + 0.1 * torch.randn(1024, generator=g), 0.1 * torch.randn(1024, generator=g)
+    gamma[40] = 300.0   # a channel whose output leaves the fp8 range
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    plain, y32 = ops.layernorm(xd, gd, bd, 1e-6, torch.float16, want_f32=True)
+    rows = ops.layernorm_f8(xd, gd, bd, 1e-6)
+    assert rows.shape == (777, 1536) and torch.equal(rows[:, :1024], plain)
+    got8 = rows.view(torch.uint8).view(777, 3072)[:, 2048:].contiguous()
+    want8 = y32.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (got8 != want8).float().mean() < 1e-4     # (an fp32 tie may round the other way in the fused kernel's own y)
+    assert not ((got8 & 0x7F) == 0x7F).any()          # no NaN codes: the clamp came before the conversion
+    rms = ops.layernorm_f8(xd, gd, None, 1e-5, rms=True)
+    assert torch.equal(rms[:, :1024], ops.layernorm(xd, gd, None, 1e-5, torch.float16, rms=True)[0])

@@ -13,7 +13,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(here, "..", "fast3r_amd", "csrc", "asm"))
 sys.path.insert(0, here)
 import gemm_gen  # noqa: E402
-from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
+from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32, fp8_e4m3_to_f64, f64_to_fp8_e4m3  # noqa: E402
 
 ACTS = {"none": gemm_gen.ACT_NONE, "gelu": gemm_gen.ACT_GELU, "relu": gemm_gen.ACT_RELU}
 
@@ -82,6 +82,82 @@ def run_case(dtype="f16", role="f32", ntm=1, ntn=1, nk1=4, segs=1, act="none", b
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max()) / scale
     print(f"{g.name}: {ntm}x{ntn} tiles, K = {segs} x {K1}, act {act}, bias {bias}, res {res}: {steps} instructions, max err / scale = {err:.3e}, nan {int(np.isnan(got).sum())}")
+    return err
+
+
+def pack_rows_f8(x16, x8):
+    """rows [K fp16 | K fp8] (3 K bytes) as the f8 kernels stream them"""
+    M, K = x16.shape
+    out = np.zeros((M, 3 * K), np.uint8)
+    out[:, :2 * K] = np.ascontiguousarray(x16).view(np.uint8).reshape(M, 2 * K)
+    out[:, 2 * K:] = x8
+    return out
+
+
+def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=True, wgs=None, seed=0, grid=None, outliers=True):
+    """the split-precision GEMM with its low plane in fp8 (GemmGen(f8=True), F3R_SPLIT_W2F8): out = epilogue(A16 W_hi^T + A8 (W_lo8 2^-s_n)^T),
+    A rows = [K fp16 | K fp8 (e4m3 of the same numbers, clamped to +-448)], W rows = [K fp16 hi | K fp8 e4m3((W - hi) 2^s_n)], one power-of-two
+    scale per output channel handed to the kernel as E8M0 words.  Reference: float64 on exactly these planes."""
+    rng = np.random.default_rng(seed)
+    M, N, K = 256 * ntm, 256 * ntn, 64 * nk16
+    assert K % 128 == 0
+    nk8 = K // 128
+    a = (rng.standard_normal((M, K)) * 2.0).astype(np.float32)
+    if outliers:
+        a[rng.integers(0, M, 40), rng.integers(0, K, 40)] *= 400.0      # beyond the fp8 range: clamped in the fp8 copy
+    w = (rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)
+    w *= np.exp2(rng.integers(-6, 3, size=(N, 1))).astype(np.float32)      # rows of very different scale: one scale per output channel
+    a16, w16 = f32_to_half(a, "f16"), f32_to_half(w, "f16")
+    a8 = f64_to_fp8_e4m3(half_to_f32(a16, "f16").astype(np.float64))
+    wlo = w.astype(np.float64) - half_to_f32(w16, "f16").astype(np.float64)
+    amax = np.maximum(np.abs(wlo).max(axis=1), 1e-30)
+    s = np.floor(np.log2(224.0 / amax)).astype(np.int64)                   # max |lo| 2^s in [112, 224]
+    s = np.clip(s, -100, 120)
+    w8 = f64_to_fp8_e4m3(wlo * np.exp2(s)[:, None])
+    e8m0 = (127 - s).astype(np.uint32)
+    wsc = (e8m0 | (e8m0 << 8) | (e8m0 << 16) | (e8m0 << 24)).astype(np.uint32)
+    bvec = (rng.standard_normal(N) * 0.7).astype(np.float32) if bias else None
+    x = (rng.standard_normal((M, N)) * 2.0).astype(np.float32)
+    mem = Memory()
+    a_a, a_w, a_s = mem.alloc(pack_rows_f8(a16, a8)), mem.alloc(pack_rows_f8(w16, w8)), mem.alloc(wsc)
+    a_b = mem.alloc(bvec) if bias else 0
+    esize = 4 if role == "f32" else 2
+    if role == "f32":
+        a_o = mem.alloc(x.copy() if res else np.full((M, N), np.nan, np.float32))
+        a_r = a_o if res else 0
+    else:
+        a_o = mem.alloc(np.full((M, N), 0x7E00, np.uint16))
+        a_r = 0
+    nk = nk16 + nk8
+    karg, grid = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, 3 * K, 3 * K, N * 4, N * esize, nk, nk, ntm, ntn, ACTS[act], grid=grid, wscale=a_s, nk8=nk8)
+    g = gemm_gen.GemmGen("f16", role, f8=True)
+    prog = g.build()
+    problems = prog.check_hazards()
+    assert not problems, "\n".join(problems[:20])
+    a_arg = mem.alloc(np.frombuffer(karg, np.uint8))
+    steps = 0
+    for wg in (range(grid) if wgs is None else wgs):
+        steps += Workgroup(prog, mem, a_arg, (wg, 0, 0), 4, g.lds_bytes, "f16").run(max_steps=40_000_000)
+    ref = half_to_f32(a16, "f16").astype(np.float64) @ half_to_f32(w16, "f16").astype(np.float64).T
+    ref += fp8_e4m3_to_f64(a8) @ (fp8_e4m3_to_f64(w8) * np.exp2(-s.astype(np.float64))[:, None]).T
+    exact = a.astype(np.float64) @ w.astype(np.float64).T
+    single = half_to_f32(a16, "f16").astype(np.float64) @ half_to_f32(w16, "f16").astype(np.float64).T
+    if bias:
+        ref += bvec.astype(np.float64)
+    if role == "f32":
+        if res:
+            ref += x.astype(np.float64)
+        got = mem.get(a_o, np.float32, (M, N)).astype(np.float64)
+    else:
+        ref = {"none": lambda v: v, "relu": lambda v: np.maximum(v, 0.0), "gelu": gelu64}[act](ref)
+        got = half_to_f32(mem.get(a_o, np.uint16, (M, N)), "f16").astype(np.float64)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(got - ref).max()) / scale
+    a_exact = half_to_f32(a16, "f16").astype(np.float64) @ w.astype(np.float64).T   # what W2 is after: the weight's rounding removed
+    w_err = float(np.abs((ref - (bvec.astype(np.float64) if bias else 0) - (x if (role == "f32" and res) else 0)) - a_exact).max() / np.abs(a_exact).max()) if act == "none" else None
+    w_err1 = float(np.abs(single - a_exact).max() / np.abs(a_exact).max())
+    print(f"{g.name}: {ntm}x{ntn} tiles, K = {K} (fp16) + {K} (fp8), act {act}, bias {bias}, res {res}: {steps} instructions, max err / scale = {err:.3e}; "
+          f"weight-rounding error left {w_err if w_err is None else format(w_err, '.2e')} (single fp16 plane: {w_err1:.2e})")
     return err
 
 

@@ -211,6 +211,43 @@ class Wave:
             out[r] = (prod[rows, lanes % 32] + c[r].astype(np.float64)).astype(np.float32)
         self.file(D.kind)[D.idx:D.idx + 16] = out.view(np.uint32)
 
+    def mfma_scale_fp8(self, ins):
+        """v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands (cbsz = blgp = 0), op_sel 0, as measured on an MI355X (tools/ubench/
+        mfma_scale_probe.py): lane (i, g) of an operand holds, in its 32 bytes, k = 16 g + 0..15 (bytes 0-15) and 32 + 16 g + 0..15 (bytes
+        16-31) of row i; the scale of (row i, k block 0 = k < 32) is byte 0 of lane i's scale register, that of k block 1 byte 0 of lane
+        i + 32's (E8M0: 2^(byte - 127)).  First operand -> rows of D, second -> columns; fp32 accumulate (the hardware's internal rounding
+        of the 64-term sums -- ~6e-5 relative in the probe -- is not modelled: float64 products, one fp32 rounding)."""
+        D, Aop, Bop, Cop, SA, SB = ins.args
+        assert Aop.n == 8 and Bop.n == 8 and D.n == 16
+        lanes = np.arange(64)
+        g = lanes // 32
+
+        def matrix(op, sc):
+            regs = self.tuple_read(op)                                   # [8][64] uint32
+            by = np.ascontiguousarray(regs.T).view(np.uint8).reshape(64, 32)  # lane-major bytes
+            vals = fp8_e4m3_to_f64(by)
+            m = np.zeros((32, 64))
+            for lane in range(64):
+                kk = [16 * g[lane] + b for b in range(16)] + [32 + 16 * g[lane] + b for b in range(16)]
+                m[lane % 32, kk] = vals[lane]
+            e8 = (self.rd(sc) & 0xFF).astype(np.float64) - 127.0
+            for row in range(32):
+                m[row, :32] *= 2.0 ** e8[row]
+                m[row, 32:] *= 2.0 ** e8[row + 32]
+            return m
+        am, bm = matrix(Aop, SA), matrix(Bop, SB)
+        prod = am @ bm.T
+        if isinstance(Cop, Reg):
+            c = f32(self.tuple_read(Cop).copy())
+        else:
+            assert Cop == 0
+            c = np.zeros((16, 64), np.float32)
+        out = np.zeros((16, 64), np.float32)
+        for r in range(16):
+            rows = 8 * (r // 4) + (r % 4) + 4 * g
+            out[r] = (prod[rows, lanes % 32] + c[r].astype(np.float64)).astype(np.float32)
+        self.file(D.kind)[D.idx:D.idx + 16] = out.view(np.uint32)
+
     # ---- waits
     def retire(self, queue, keep):
         while len(queue) > keep:
@@ -334,6 +371,9 @@ class Wave:
         # ---------------- vector ALU
         if op.startswith("v_mfma_f32_32x32x16"):
             self.mfma(it, 16)
+            return
+        if op == "v_mfma_scale_f32_32x32x64_f8f6f4":
+            self.mfma_scale_fp8(it)
             return
         if op.startswith("v_mfma_f32_32x32x8"):
             self.mfma(it, 8)
@@ -603,6 +643,40 @@ class Wave:
             self.vm.append(lambda: None)
             return
         raise NotImplementedError(it.text())
+
+
+_FP8_TABLE = None
+
+
+def fp8_e4m3_to_f64(b):
+    """OCP e4m3 (fn: no infinities, 0x7F / 0xFF = NaN) bytes -> float64"""
+    global _FP8_TABLE
+    if _FP8_TABLE is None:
+        t = np.zeros(256)
+        for v in range(256):
+            s, e, m = v >> 7, (v >> 3) & 15, v & 7
+            if e == 15 and m == 7:
+                x = np.nan
+            elif e == 0:
+                x = m / 8.0 * 2.0 ** -6
+            else:
+                x = (1 + m / 8.0) * 2.0 ** (e - 7)
+            t[v] = -x if s else x
+        _FP8_TABLE = t
+    return _FP8_TABLE[np.asarray(b, np.uint8)]
+
+
+def f64_to_fp8_e4m3(x):
+    """round to nearest even onto the e4m3 grid after clamping to +-448 (what the producers of the fp8 planes do) -> bytes"""
+    fp8_e4m3_to_f64(np.zeros(1, np.uint8))
+    x = np.clip(np.asarray(x, np.float64), -448.0, 448.0)
+    pos = _FP8_TABLE[:127]   # 0 .. 448 ascending (0x7F is NaN)
+    a = np.abs(x)
+    idx = np.clip(np.searchsorted(pos, a), 1, 126)
+    lo, hi = pos[idx - 1], pos[idx]
+    pick_hi = (a - lo > hi - a) | ((a - lo == hi - a) & (idx % 2 == 0))   # tie -> even code
+    code = np.where(pick_hi, idx, idx - 1).astype(np.uint8)
+    return (code | np.where(np.signbit(x), 0x80, 0).astype(np.uint8)).astype(np.uint8)
 
 
 class Workgroup:

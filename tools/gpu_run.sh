@@ -143,6 +143,9 @@ PY
       timeout 900 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 --no-alt --no-cpu-baseline --no-hot ${BENCH_EXTRA:-} > $d/bench_quick.json 2> $d/err.log; tail -c 5000 $d/bench_quick.json; tail -5 $d/err.log ;;
     attnasm)    # the generated attention kernels (the clock bracket of round 5 touched prologue + epilogue)
       timeout 900 python -m pytest tests/test_attn_asm_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -40 > $d/pytest.log; tail -12 $d/pytest.log ;;
+    gemmf8)     # parity of the fp8-low-plane GEMM + LayerNorm rows, then W2 vs W2F8 timings of the transformer's linear roles
+      timeout 900 python -m pytest tests/test_gemm_asm_gpu.py -q -x -s -p no:cacheprovider -k "fp8 or f8" 2>&1 | tail -40 > $d/pytest.log; grep -E "w2f8|passed|failed|Error|assert" $d/pytest.log | tail -20
+      timeout 600 python tools/kernel_bench.py --what gemmf8 --views ${F8_VIEWS:-320,100} > $d/gemm_w2_vs_w2f8.jsonl 2> $d/err.log; cat $d/gemm_w2_vs_w2f8.jsonl | cut -c1-300; tail -3 $d/err.log ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)

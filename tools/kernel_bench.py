@@ -449,6 +449,37 @@ if __name__ == "__main__":
                                   "frac_of_peak": round(fl / ms / 1e9 / 2500.0, 4), "rounds_ms": [round(x, 3) for x in res[steal]]}), flush=True)
             ops.ATTN_WORK_STEALING = True
         sys.exit(0)
+    if args.what == "gemmf8":  # the transformer's linear roles: two fp16 weight planes (W2, today) next to the low plane in fp8 (W2F8), hand-scheduled kernels
+        f16 = torch.float16
+        for M in [int(v) * 1024 for v in args.views.split(",")]:
+            for (n, k, nm, kw) in ((4096, 1024, "fc1+gelu", dict(act="gelu", out="lp")), (1024, 4096, "fc2+res", dict(res=True)), (1024, 1024, "proj+res", dict(res=True)),
+                                   (2048, 1024, "q|k lp", dict(out="lp"))):
+                a16 = torch.randn((M, k), device=DEV).to(f16)
+                rows = torch.empty((M, 3 * k // 2), dtype=f16, device=DEV)
+                rows[:, :k] = a16
+                rows.view(torch.uint8).view(M, 3 * k)[:, 2 * k:] = a16.float().clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+                w32 = torch.randn((n, k), device=DEV) * k ** -0.5
+                w2 = ops.pack_linear_weight(w32, f16, split=True)
+                w8, ws = ops.pack_linear_weight_f8(w32)
+                bias = torch.randn(n, device=DEV)
+                o32 = torch.randn((M, n), device=DEV) if kw.get("res") else None
+                olp = torch.empty((M, n), dtype=f16, device=DEV) if kw.get("out") == "lp" else None
+                common = dict(bias=bias, act=kw.get("act"), res_f32=o32, out_f32=o32, out_lp=olp)
+                fns = {"w2 (two fp16 planes)": lambda: ops.gemm(rows[:, :k], w2, split="w2", kernel_sel=6, **common),
+                       "w2f8 (low plane in fp8)": lambda: ops.gemm(rows, w8, split="w2f8", w_scale=ws, **common)}
+                res = {nm_: [] for nm_ in fns}
+                for rnd_ in range(4):
+                    for nm_, f in fns.items():
+                        if rnd_ == 0:
+                            f()
+                        res[nm_].append(time_ms(f, rounds=3, inner=3)[0])
+                base = None
+                for nm_ in fns:
+                    ms = sorted(res[nm_])[len(res[nm_]) // 2]
+                    base = base or ms
+                    print(json.dumps({"kernel": "gemm", "role": nm, "form": nm_, "M": M, "N": n, "K": k, "ms": round(ms, 3), "tflops_algorithmic": round(2.0 * M * n * k / ms / 1e9, 1),
+                                      "speedup_vs_w2": round(base / ms, 3)}), flush=True)
+        sys.exit(0)
     if args.what == "convheads":  # the DPT-head convolutions and the encoder's QKV + RoPE-2D as the N = 320 forward runs them (fp16, X3 / W2; 25-view head chunks)
         f16 = torch.float16
         bench_conv(f16, 25, 256, 256, 256, 128, "head0 x3", split="x3", sels=(0,))
