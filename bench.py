@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--precision", default="high", choices=["fast", "high"],
                     help="high: split-precision GEMM operands (weights hi+lo in the transformer, both operands in the heads), see DESIGN.md section 4; "
                          "the default pair (fp16, high) is the operand format that meets the 1e-3 parity bar on the stress fixture")
+    ap.add_argument("--low-plane", default="fp16", choices=["fp16", "fp8"],
+                    help="precision high: where the MLPs' correction products A W_lo run -- a second fp16 plane, or the block-scaled fp8 MFMA "
+                         "(Fast3R.low_plane; f3r.h F3R_SPLIT_W2F8)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other operand format (bf16 / fast)")
     ap.add_argument("--fusion-only", action="store_true",
                     help="BASELINE configs[1]: time only the fusion decoder on frozen random encoder features")
@@ -472,6 +475,7 @@ def main():
         weights = args.weights if weights is None else weights
         lp = torch.float16 if dtype_name == "fp16" else torch.bfloat16
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
+        model.low_plane = args.low_plane
         model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
         if emu:
@@ -692,7 +696,7 @@ def main():
             "dtype": main_res["dtype"], "precision": main_res["precision"], "data": "synthetic", "rccl_ranks_seen": ranks_seen,
             "config": {"workload": workload, "views": V, "views_per_gpu": views_per_gpu,
                        "tokens": V * 1024, "image": "512x512", "parallelism": f"view-sharded x{world}, K/V all-gather per fusion layer" if world > 1 else "single GPU",
-                       "operands": main_res["operands"]},
+                       "operands": main_res["operands"], "low_plane": args.low_plane},
             # `live` = this run's own clock / utilisation / power record; `traffic` and `reference_pmc` are read from committed rocprofv3
             # PMC passes of other runs (they carry their source file) and are there to be compared with `live`, not to stand in for it
             "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), reference_pmc=load_pmc(main_res["dtype"])),

@@ -30,7 +30,7 @@ struct f3r_gemm_asm_args {
   uint32_t flags, nk1_w, pad;           // FLAG_BIAS_ON_M = 1; wrap period of the W stream
   // ---- ARG_F8: read by the f8 kernels only (their kernarg segment is 144 bytes, the others' 128)
   const uint32_t* w_scale;              // E8M0 scale words of the weight rows' fp8 plane
-  uint32_t nk8, pad8;                   // fp8 K-tiles ([256][128 k]) at the end of every output tile's K loop
+  uint32_t nk8, out8_off;               // fp8 K-tiles ([256][128 k]) at the end of every output tile's K loop; byte offset of the output's fp8 copy in its row (0 = none)
 };
 static_assert(sizeof(f3r_gemm_asm_args) == 144 && offsetof(f3r_gemm_asm_args, w_scale) == 128 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
               offsetof(f3r_gemm_asm_args, seg_stride) == 96 && offsetof(f3r_gemm_asm_args, nk1_w) == 120, "must match ARG_* of gemm_gen.py");
@@ -203,7 +203,9 @@ bool f3r_gemm_asm_f8_eligible(const f3r_gemm_args& a, const char** why) {
     if (a.res_f32) { *why = "fp32 residual with a lowp output"; return false; }
     if ((((uintptr_t)a.out_lp) & 15) != 0 || (a.ldo_lp * 2) % 16 != 0) { *why = "lowp output not 16-byte aligned"; return false; }
     if ((int64_t)256 * a.ldo_lp * 2 >= (1ll << 32)) { *why = "lowp row stride too large"; return false; }
+    if (a.out_lp_f8 && (a.act != F3R_ACT_GELU || a.ldo_lp * 2 < (int64_t)a.N * 3)) { *why = "out_lp_f8 needs the GELU epilogue and rows of >= 3 N / 2 elements"; return false; }
   }
+  if (a.out_lp_f8 && a.out_f32) { *why = "out_lp_f8 with an fp32 output"; return false; }
   if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.K * 3 >= (1ll << 32)) { *why = "operand row strides too large for 32-bit lane offsets"; return false; }
   if ((a.M / 256) * (int64_t)(a.N / 256) >= (1ll << 24) || !tile_map_exact(a.M / 256, a.N / 256, a.N / 256)) { *why = "grid too large"; return false; }
   if (get_fn(role_of(a), a.dtype, true) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
@@ -235,6 +237,7 @@ int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.act = (uint32_t)a.act;
   k.scale = 1.0f;
   k.w_scale = a.w_scale;
+  k.out8_off = a.out_lp_f8 ? (uint32_t)a.N * 2u : 0u;
   return launch_tiles(fn, k, a.M, a.N, stream);
 }
 

@@ -350,7 +350,7 @@ def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 
 
-def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None):
+def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None, f8=False):
     p = _PackedBlock()
     p.head_dim = head_dim
     p.n1w, p.n1b, p.n2w, p.n2b = _f32(blk.norm1.weight), _f32(blk.norm1.bias), _f32(blk.norm2.weight), _f32(blk.norm2.bias)
@@ -363,6 +363,13 @@ def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None):
     p.fc1_split = bool(split) if fc1_split is None else bool(fc1_split)
     p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, p.fc1_split), _f32(blk.mlp.fc1.bias)
     p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp, split), _f32(blk.mlp.fc2.bias)
+    # Fast3R.low_plane = "fp8" (precision "high", fp16): fc1's weight a second time as rows [K fp16 hi | K fp8 low plane] + one scale per output
+    # channel (f3r.h F3R_SPLIT_W2F8); the block uses it whenever its token count is a multiple of 256, the two-fp16-plane pack otherwise
+    w1 = blk.mlp.fc1.weight.detach().float()
+    w2_ = blk.mlp.fc2.weight.detach().float()
+    if f8 and split and lp == torch.float16 and p.fc1_split and w1.shape[1] % 128 == 0 and w1.shape[0] % 256 == 0 and w2_.shape[0] % 256 == 0:
+        p.fc1_w8, p.fc1_ws = ops.pack_linear_weight_f8(w1)
+        p.fc2_w8, p.fc2_ws = ops.pack_linear_weight_f8(w2_)
     return p
 
 
@@ -751,6 +758,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """split (hi + lo) weight planes and head activations: "high" and "exact"."""
         return self.precision in ("high", "exact")
 
+    # "fp8" (precision "high", fp16 operands): the correction products A W_lo of the transformer's fc1 layers run on the block-scaled fp8 MFMA
+    # (f3r.h F3R_SPLIT_W2F8: 1.4x the matrix-pipe rate of a second fp16 plane; fc2 reads the fp8 copy fc1's GELU epilogue writes beside its fp16
+    # output); changing it needs invalidate_packed_weights()
+    low_plane = "fp16"
     high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
 
     @property
@@ -768,14 +779,15 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
 
     def _pack(self, device):
         lp = self.compute_dtype
-        key = (lp, self.precision, str(device), self._params_version())
+        f8 = self.low_plane == "fp8" and self.precision == "high" and lp == torch.float16
+        key = (lp, self.precision, str(device), self._params_version(), f8)
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
         alt = getattr(self, "_packed_alt", None)
         if alt is not None and alt["key"] == key:  # two packs are kept, so alternating inference(dtype=...) calls do not re-pack
             self._packed, self._packed_alt = alt, self._packed
             return self._packed
-        if self._packed is not None and self._packed["key"][-1] != key[-1]:  # parameters changed: both packs are stale
+        if self._packed is not None and self._packed["key"][3] != key[3]:  # parameters changed: both packs are stale
             self._packed = self._packed_alt = None
             self._graphs.clear()
         if alt is not None:  # a third format evicts the older pack: captured graphs may hold pointers into its weight tensors
@@ -794,7 +806,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:
             pk["pe_w"] = ops.pack_linear_weight(enc.patch_embed.proj.weight.detach().float(), lp, hp)
             pk["pe_b"] = _f32(enc.patch_embed.proj.bias)
-            pk["enc"] = [_pack_block(b, lp, hp, fc1_split=self._fc1_split) for b in enc.enc_blocks]
+            pk["enc"] = [_pack_block(b, lp, hp, fc1_split=self._fc1_split, f8=f8) for b in enc.enc_blocks]
             pk["enc_norm"] = (_f32(enc.enc_norm.weight), _f32(enc.enc_norm.bias), enc.enc_norm.eps)
         pk["de_w"] = ops.pack_linear_weight(dec.decoder_embed.weight.detach().float(), lp, hp)
         pk["de_b"] = _f32(dec.decoder_embed.bias)
@@ -803,7 +815,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             pk["dec_norm"] = (_f32(dec.norm.weight), None, dec.norm.eps)
             pk["view0"] = _f32(dec.view0_embed)
         else:
-            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=self._fc1_split) for b in dec.dec_blocks]
+            pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=self._fc1_split, f8=f8) for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
         pk["head"] = _pack_head(self.downstream_head, lp, hp)
         pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None
@@ -881,6 +893,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True, **gqa)
             sharding.end_layer(kv_exchange)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
+        if getattr(pb, "fc1_w8", None) is not None and T > 0 and T % 256 == 0 and not pb.swiglu_hidden:
+            # low plane in fp8: LayerNorm writes rows [D fp16 | D fp8], fc1 runs A W_hi on the fp16 MFMA and A W_lo on the block-scaled fp8 one
+            rows = ops.layernorm_f8(x, pb.n2w, pb.n2b, pb.eps, out_rows=ws.rows8(D), rms=pb.rms)
+            _, hid = ops.gemm(rows, pb.fc1_w8, bias=pb.fc1_b, act="gelu", out_lp=ws.hid8(), split="w2f8", w_scale=pb.fc1_ws, out_f8_rows=True)
+            ops.gemm(hid, pb.fc2_w8, bias=pb.fc2_b, res_f32=x, out_f32=x, split="w2f8", w_scale=pb.fc2_ws)
+            return x
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)
             _, ab = ops.gemm(h2, pb.fc1_w, out_lp=ws.hid, split=sp)

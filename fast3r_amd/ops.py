@@ -168,9 +168,10 @@ def _split_operand(g, a, split, a_lo):
 
 def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f32=None, res_lp=None, res_lp2=None,
          out_f32=None, out_lp=None, want_f32=False, want_lp=False, split=None, a_lo=None, res_lp_lo=None, res_lp2_lo=None,
-         out_lp_lo=None, want_lo=False, kernel_sel=0, w_scale=None):
+         out_lp_lo=None, want_lo=False, kernel_sel=0, w_scale=None, out_f8_rows=False):
     """out = act(A W^T + bias) [+ rowadd[m//div]] [+ residuals].  a: lowp [M][lda>=K]; w: packed lowp [N][Kpad].
-    split "w2f8" (+ w_scale): a = rows [K fp16 | K fp8] (layernorm_f8), w / w_scale from pack_linear_weight_f8.
+    split "w2f8" (+ w_scale): a = rows [K fp16 | K fp8] (layernorm_f8), w / w_scale from pack_linear_weight_f8; out_f8_rows (with act="gelu"): out_lp
+    is [M][3 N / 2] = rows [N fp16 | N fp8], the operand of the next "w2f8" GEMM.
     split "w2" / "x3": w packed with split=True ([hi | lo] planes), "x3" also takes a_lo (f3r.h f3r_split); *_lo: low planes of the lowp
     residuals / output.  Returns (out_f32, out_lp) or, with want_lo / out_lp_lo, (out_f32, out_lp, out_lp_lo)."""
     require_gpu(a, "a")
@@ -185,6 +186,11 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
         assert a.shape[1] * 2 >= 3 * K
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if out_f8_rows:
+        assert split == "w2f8" and act == "gelu"
+        if out_lp is None:
+            out_lp = torch.empty((M, 3 * N // 2), dtype=lp, device=a.device)
+        assert out_lp.shape[1] * 2 >= 3 * N
     if (want_lp or want_lo) and out_lp is None:
         out_lp = torch.empty((M, N), dtype=lp, device=a.device)
     if want_lo and out_lp_lo is None:
@@ -219,6 +225,7 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
     g.dtype = dtype_id(lp)
     if w_scale is not None:
         g.w_scale = ptr(w_scale)
+    g.out_lp_f8 = int(bool(out_f8_rows))
     check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
     if out_lp_lo is not None:
         return out_f32, out_lp, out_lp_lo
@@ -248,6 +255,19 @@ class BlockWorkspace:
         if ld != seq_len and kv_dim:
             self.vt.zero_()  # the pad columns are read by the last key tile and never written by the QKV epilogue
         self.key = (tokens, D, hidden, n_seq, seq_len, lp, str(device))
+        self._rows8 = None
+
+    def hid8(self):
+        """[tokens][3 hidden / 2]: the MLP hidden state as rows [hidden fp16 | hidden fp8] (fc1's GELU epilogue writes both, fc2 reads both)"""
+        if getattr(self, "_hid8", None) is None:
+            self._hid8 = torch.empty((self.hid.shape[0], 3 * self.hid.shape[1] // 2), dtype=torch.float16, device=self.buf.device)
+        return self._hid8
+
+    def rows8(self, D):
+        """[tokens][3 D / 2] float16-typed rows [D fp16 | D fp8] for the LayerNorm output of the fp8-low-plane GEMMs (made on first use)"""
+        if self._rows8 is None:
+            self._rows8 = torch.empty((self.h.shape[0], 3 * D // 2), dtype=torch.float16, device=self.buf.device)
+        return self._rows8
 
 
 def vt_ld(seq_len: int) -> int:

@@ -166,7 +166,10 @@ typedef struct f3r_gemm_args {
      [ q: qkv_dq | k: (N - qkv_dq) / 2 | v: (N - qkv_dq) / 2 ], q -> [M][qkv_dq], k -> [M][Dkv], v -> vt[m / seq_len][Dkv][ldvt].
      0 = three equal thirds (N / 3 each).  Both widths must be multiples of 64 (whole heads). */
   int32_t qkv_dq;
-  int32_t reserved1;
+  /* F3R_SPLIT_W2F8 with act = GELU and out_lp (ABI 330; was reserved): != 0 = the rows of out_lp are [N fp16 | N fp8] (ldo_lp >= 3 N / 2) and the
+     epilogue also writes the fp8 (e4m3, clamped to 448) copy of its output N sixteen-bit elements into the row: the A operand of the NEXT
+     W2F8 GEMM (fc1 -> fc2 of a transformer MLP, blocks.py:94-105) */
+  int32_t out_lp_f8;
   const uint32_t* w_scale; /* F3R_SPLIT_W2F8: [N] scale words of the weight rows' fp8 plane (see f3r_split); NULL otherwise (ABI 330) */
 } f3r_gemm_args;
 

@@ -38,9 +38,10 @@ def _vitl_hot():
     return _CACHE["args"], _CACHE["sd"]
 
 
-def _build(dt, precision):
+def _build(dt, precision, low_plane="fp16"):
     (enc, dec, head), sd = _vitl_hot()
     m = Fast3R(enc, dec, head, compute_dtype=dt, precision=precision).eval()
+    m.low_plane = low_plane
     m.load_state_dict(sd, strict=True)
     return m.to(DEV)
 
@@ -67,8 +68,8 @@ def test_vit_large_depth_with_stress_weights_vs_cpu_oracle(built_lib, n_views):
         O.ATTN_IMPL = "naive"
     gv = views_to(views, DEV)
     report = {}
-    for dt, precision in ((torch.float16, "high"), (torch.float16, "fast"), (torch.bfloat16, "fast"), (torch.float16, "exact")):
-        m = _build(dt, precision)
+    for dt, precision in ((torch.float16, "high"), (torch.float16, "high+fp8"), (torch.float16, "fast"), (torch.bfloat16, "fast"), (torch.float16, "exact")):
+        m = _build(dt, precision.split("+")[0], low_plane="fp8" if precision.endswith("+fp8") else "fp16")
         with torch.no_grad():
             torch.manual_seed(1234)
             out = m(gv)
@@ -77,6 +78,8 @@ def test_vit_large_depth_with_stress_weights_vs_cpu_oracle(built_lib, n_views):
         del m, out
         torch.cuda.empty_cache()
     assert max(report[("float16", "high")].values()) <= TOL, report
+    # Fast3R.low_plane = "fp8" (the MLPs' correction products on the block-scaled fp8 MFMA): the same bar
+    assert max(report[("float16", "high+fp8")].values()) <= TOL, report
     assert max(report[("float16", "exact")].values()) <= 2e-5, report   # the fp32-equivalent mode stays an anchor at depth 48
 
 
@@ -131,8 +134,8 @@ def test_vit_large_n100_stress_weights_vs_fp32_equivalent_path(built_lib):
     del m
     torch.cuda.empty_cache()
     report = {}
-    for dt, precision in ((torch.float16, "high"), (torch.float16, "fast")):
-        m = _build(dt, precision)
+    for dt, precision in ((torch.float16, "high"), (torch.float16, "high+fp8"), (torch.float16, "fast")):
+        m = _build(dt, precision.split("+")[0], low_plane="fp8" if precision.endswith("+fp8") else "fp16")
         with torch.no_grad():
             torch.manual_seed(4321)
             out = m(views)
@@ -141,6 +144,7 @@ def test_vit_large_n100_stress_weights_vs_fp32_equivalent_path(built_lib):
         del m, out
         torch.cuda.empty_cache()
     assert max(report[(str(torch.float16), "high")].values()) <= TOL, report
+    assert max(report[(str(torch.float16), "high+fp8")].values()) <= TOL, report
 
 
 def test_vit_large_n320_stress_weights_vs_fp32_equivalent_path(built_lib):

@@ -88,3 +88,15 @@ def test_generated_text_assembles_and_has_no_hazards(tmp_path):
     src = tmp_path / "gemm.s"
     src.write_text(gemm_gen.module_text(gens))
     subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "gemm.o")], check=True)
+
+
+@pytest.mark.parametrize("kw,tol", [(dict(role="f32", nk16=4), 1e-6), (dict(role="f32", ntm=3, nk16=6, grid=1, outliers=False), 1e-6),
+                                    (dict(role="lp", nk16=4, act="gelu", out8=True), 5e-4), (dict(role="lp", ntn=2, nk16=4, act="none", out8=True, grid=1, bias=False), 8e-4)])
+def test_emulated_fp8_low_plane(kw, tol):
+    """F3R_SPLIT_W2F8 (round 5): after the fp16 K-tiles the same two operand streams run on into fp8 K-tiles [256 rows][128 k] consumed by the
+    block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (emulated with the lane layout and scale semantics measured on an MI355X,
+    tools/ubench/mfma_scale_probe.py) -- the four window kinds (fp16 -> fp16, fp16 -> fp8, fp8 -> fp8, fp8 -> next output tile), the per-channel
+    scale words re-loaded per output tile by persistent workgroups, activations beyond the fp8 range (clamped in their fp8 copy), and the GELU
+    epilogue's fp8 copy of its own output (rows [N fp16 | N fp8] for the next GEMM; not written without GELU) -- against float64 on the planes"""
+    import emu_gemm
+    assert emu_gemm.run_case_f8(**kw) < tol

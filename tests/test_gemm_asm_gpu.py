@@ -230,3 +230,31 @@ def test_layernorm_f8_rows(built_lib):
     assert not ((got8 & 0x7F) == 0x7F).any()          # no NaN codes: the clamp came before the conversion
     rms = ops.layernorm_f8(xd, gd, None, 1e-5, rms=True)
     assert torch.equal(rms[:, :1024], ops.layernorm(xd, gd, None, 1e-5, torch.float16, rms=True)[0])
+
+
+def test_mlp_chain_on_fp8_rows(built_lib):
+    """LayerNorm rows -> fc1 (+GELU, writes rows [N fp16 | N fp8]) -> fc2 (+fp32 residual), both with the low plane in fp8, as Fast3R._block issues
+    them with low_plane = "fp8": against fp64 on the UNROUNDED weights and the kernel's own fp16 activations (what W2 computes, to the
+    fp8 planes' 2^-15)"""
+    g = torch.Generator().manual_seed(21)
+    T, D, Hd = 1536, 512, 2048
+    x = torch.randn((T, D), generator=g) * 2
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1, b1 = torch.randn((Hd, D), generator=g) * D ** -0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2, b2 = torch.randn((D, Hd), generator=g) * Hd ** -0.5, 0.1 * torch.randn(D, generator=g)
+    xd = x.to(DEV)
+    rows = ops.layernorm_f8(xd, gamma.to(DEV), beta.to(DEV), 1e-6)
+    w1p, w1s = ops.pack_linear_weight_f8(w1)
+    w2p, w2s = ops.pack_linear_weight_f8(w2)
+    _, hid = ops.gemm(rows, w1p.to(DEV), bias=b1.to(DEV), act="gelu", split="w2f8", w_scale=w1s.to(DEV), out_f8_rows=True)
+    assert hid.shape == (T, 3 * Hd // 2)
+    h16 = hid[:, :Hd]
+    ref_h = F.gelu(rows[:, :D].double().cpu() @ w1.double().t() + b1.double())
+    assert_close(h16.float(), ref_h, lp_tol(torch.float16), "fc1 + GELU on fp8 rows")
+    h8 = hid.view(torch.uint8).view(T, 3 * Hd)[:, 2 * Hd:].contiguous().view(torch.float8_e4m3fn).float().cpu()
+    want8 = h16.float().clamp(max=448).to(torch.float8_e4m3fn).float().cpu()
+    assert ((h8 - want8).abs() > 0.13 * want8.abs().clamp_min(2.0 ** -9)).float().mean() < 2e-3   # (the copy is taken from the fp32 value, not from its fp16 rounding)
+    out = xd.clone()
+    ops.gemm(hid, w2p.to(DEV), bias=b2.to(DEV), res_f32=out, out_f32=out, split="w2f8", w_scale=w2s.to(DEV))
+    ref = x.double() + h16.double().cpu() @ w2.double().t() + b2.double()
+    assert_close(out, ref, 3e-5, "fc2 + residual on fp8 rows")

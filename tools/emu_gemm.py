@@ -94,7 +94,7 @@ def pack_rows_f8(x16, x8):
     return out
 
 
-def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=True, wgs=None, seed=0, grid=None, outliers=True):
+def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=True, wgs=None, seed=0, grid=None, outliers=True, out8=False):
     """the split-precision GEMM with its low plane in fp8 (GemmGen(f8=True), F3R_SPLIT_W2F8): out = epilogue(A16 W_hi^T + A8 (W_lo8 2^-s_n)^T),
     A rows = [K fp16 | K fp8 (e4m3 of the same numbers, clamped to +-448)], W rows = [K fp16 hi | K fp8 e4m3((W - hi) 2^s_n)], one power-of-two
     scale per output channel handed to the kernel as E8M0 words.  Reference: float64 on exactly these planes."""
@@ -125,11 +125,19 @@ def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=Tru
     if role == "f32":
         a_o = mem.alloc(x.copy() if res else np.full((M, N), np.nan, np.float32))
         a_r = a_o if res else 0
+    elif out8:   # rows [N fp16 | N fp8]: the lp role's GELU epilogue also writes the fp8 copy
+        rows0 = np.zeros((M, 3 * N), np.uint8)
+        rows0[:, :2 * N] = np.full((M, N), 0x7E00, np.uint16).view(np.uint8).reshape(M, 2 * N)
+        rows0[:, 2 * N:] = 0x7F
+        a_o = mem.alloc(rows0)
+        a_r = 0
     else:
         a_o = mem.alloc(np.full((M, N), 0x7E00, np.uint16))
         a_r = 0
     nk = nk16 + nk8
-    karg, grid = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, 3 * K, 3 * K, N * 4, N * esize, nk, nk, ntm, ntn, ACTS[act], grid=grid, wscale=a_s, nk8=nk8)
+    ldo_b = 3 * N if (role == "lp" and out8) else N * esize
+    karg, grid = gemm_gen.pack_args(a_a, a_w, a_b, a_r, a_o, 3 * K, 3 * K, N * 4, ldo_b, nk, nk, ntm, ntn, ACTS[act], grid=grid, wscale=a_s, nk8=nk8,
+                                    out8_off=2 * N if (role == "lp" and out8) else 0)
     g = gemm_gen.GemmGen("f16", role, f8=True)
     prog = g.build()
     problems = prog.check_hazards()
@@ -150,7 +158,16 @@ def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=Tru
         got = mem.get(a_o, np.float32, (M, N)).astype(np.float64)
     else:
         ref = {"none": lambda v: v, "relu": lambda v: np.maximum(v, 0.0), "gelu": gelu64}[act](ref)
-        got = half_to_f32(mem.get(a_o, np.uint16, (M, N)), "f16").astype(np.float64)
+        if out8:
+            rows = mem.get(a_o, np.uint8, (M, 3 * N))
+            got = half_to_f32(np.ascontiguousarray(rows[:, :2 * N]).view(np.uint16).reshape(M, N), "f16").astype(np.float64)
+            got8 = fp8_e4m3_to_f64(rows[:, 2 * N:])
+            want8 = fp8_e4m3_to_f64(f64_to_fp8_e4m3(ref))
+            bad = np.abs(got8 - want8) > 0.13 * np.maximum(np.abs(want8), 2.0 ** -9)   # one e4m3 step (fp32 GELU vs float64 may round the other way)
+            assert act != "gelu" or bad.mean() < 1e-3, ("fp8 copy", float(bad.mean()))
+            assert act == "gelu" or (rows[:, 2 * N:] == 0x7F).all(), "an fp8 copy without GELU"
+        else:
+            got = half_to_f32(mem.get(a_o, np.uint16, (M, N)), "f16").astype(np.float64)
     scale = float(np.abs(ref).max())
     err = float(np.abs(got - ref).max()) / scale
     a_exact = half_to_f32(a16, "f16").astype(np.float64) @ w.astype(np.float64).T   # what W2 is after: the weight's rounding removed

@@ -326,7 +326,7 @@ class Wave:
             self.s[a[0].idx] = v & 0xFFFFFFFF
             self.s[a[0].idx + 1] = v >> 32
             return
-        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_add_i32", "s_sub_i32"):
+        if op in ("s_add_u32", "s_addc_u32", "s_sub_u32", "s_subb_u32", "s_add_i32", "s_sub_i32"):
             x, y = self.rds(a[1]), self.rds(a[2])
             if op == "s_add_u32" or op == "s_add_i32":
                 r = x + y
@@ -334,6 +334,9 @@ class Wave:
             elif op == "s_addc_u32":
                 r = x + y + self.scc
                 self.scc = int(r > 0xFFFFFFFF)
+            elif op == "s_subb_u32":
+                r = x - y - self.scc
+                self.scc = int(y + self.scc > x)
             else:
                 r = x - y
                 self.scc = int(y > x)
@@ -398,10 +401,21 @@ class Wave:
             r = (x.astype(np.uint64) << sh.astype(np.uint64)) if op == "v_lshlrev_b32" else (x >> sh)
             self.wr(a[0], (r & 0xFFFFFFFF).astype(np.uint32))
             return
-        if op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32"):
+        if op == "v_cvt_pk_fp8_f32":   # two fp32 -> two e4m3 bytes (RNE; out of range -> NaN code, as measured) into the low or (op_sel:[0,0,1]) high half of dst
+            x, y = f32(self.rd(a[1])).astype(np.float64), f32(self.rd(a[2])).astype(np.float64)
+
+            def enc(v):
+                b = f64_to_fp8_e4m3(v).astype(np.uint32)
+                return np.where(np.abs(v) > 464.0, np.uint32(0x7F) | (np.signbit(v).astype(np.uint32) << 7), b)   # (464 = the rounding boundary above 448)
+            pair = enc(x) | (enc(y) << 8)
+            old = self.rd(a[0])
+            hi = "op_sel:[0,0,1]" in str(it.mods.get("text", ""))
+            self.wr(a[0], ((old & np.uint32(0x0000FFFF)) | (pair << 16)) if hi else ((old & np.uint32(0xFFFF0000)) | pair))
+            return
+        if op in ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32", "v_min_f32"):
             x, y = f32(self.rd(a[1])), f32(self.rd(a[2]))
             with np.errstate(all="ignore"):
-                r = {"v_add_f32": x + y, "v_sub_f32": x - y, "v_mul_f32": x * y, "v_max_f32": np.fmax(x, y)}[op]
+                r = {"v_add_f32": x + y, "v_sub_f32": x - y, "v_mul_f32": x * y, "v_max_f32": np.fmax(x, y), "v_min_f32": np.fmin(x, y)}[op]
             self.wr(a[0], u32(r))
             return
         if op == "v_fma_f32":

@@ -146,6 +146,14 @@ PY
     gemmf8)     # parity of the fp8-low-plane GEMM + LayerNorm rows, then W2 vs W2F8 timings of the transformer's linear roles
       timeout 900 python -m pytest tests/test_gemm_asm_gpu.py -q -x -s -p no:cacheprovider -k "fp8 or f8" 2>&1 | tail -40 > $d/pytest.log; grep -E "w2f8|passed|failed|Error|assert" $d/pytest.log | tail -20
       timeout 600 python tools/kernel_bench.py --what gemmf8 --views ${F8_VIEWS:-320,100} > $d/gemm_w2_vs_w2f8.jsonl 2> $d/err.log; cat $d/gemm_w2_vs_w2f8.jsonl | cut -c1-300; tail -3 $d/err.log ;;
+    f8model)    # the model with Fast3R.low_plane = "fp8": kernel chain test, parity at ViT-L depth (N = 3, 8 vs the CPU oracle; N = 100 vs the exact mode), then the bench A/B
+      timeout 1500 python -m pytest tests/test_gemm_asm_gpu.py tests/test_depth_parity_gpu.py -q -s -p no:cacheprovider -k "fp8 or f8 or stress_weights_vs_cpu_oracle or n100_stress" > $d/pytest_full.log 2>&1; grep -E "\[parity\]|\[w2f8|passed|failed|^E " $d/pytest_full.log | sed 's/^[.sF]*//' | cut -c1-300 > $d/parity_lines.txt; cat $d/parity_lines.txt; tail -60 $d/pytest_full.log > $d/pytest.log; rm -f $d/pytest_full.log
+      for lpn in fp8 fp16; do timeout 600 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-inference --low-plane $lpn > $d/bench_$lpn.json 2> $d/err_$lpn.log; python - $d/bench_$lpn.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(sys.argv[1], "N=320:", round(d["value"], 2), "views/s", round(d["ms_per_step"], 1), "ms; attn frac", round(d["roofline"]["frac"], 4), "| n100:", round(d["n100"]["value"], 2), "views/s | n20 fusion:", round(d["fusion_only_n20"]["value"], 1))
+PY
+      done ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)
