@@ -337,9 +337,11 @@ class PixelwiseTaskWithDPT(_Params):
 # ======================================================================================= packed (device) weights
 class _PackedBlock:
     __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim", "fc1_split")
+                 "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim", "fc1_split",
+                 "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws")   # the MLP weights with their low plane in fp8 (Fast3R.low_plane = "fp8"), or None
 
     def __init__(self):
+        self.fc1_w8 = self.fc1_ws = self.fc2_w8 = self.fc2_ws = None
         self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
         self.fc1_split = None  # None: like every other projection of the block
         self.head_dim = 64  # the Fast3R fusion decoder may have another width (model_scaling_huge.yaml: 80)

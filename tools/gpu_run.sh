@@ -151,7 +151,9 @@ PY
       for lpn in fp8 fp16; do timeout 600 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-inference --low-plane $lpn > $d/bench_$lpn.json 2> $d/err_$lpn.log; python - $d/bench_$lpn.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print(sys.argv[1], "N=320:", round(d["value"], 2), "views/s", round(d["ms_per_step"], 1), "ms; attn frac", round(d["roofline"]["frac"], 4), "| n100:", round(d["n100"]["value"], 2), "views/s | n20 fusion:", round(d["fusion_only_n20"]["value"], 1))
+r = lambda x, n=2: None if x is None else round(x, n)
+print(sys.argv[1], "N=320:", r(d.get("value")), "views/s", r(d.get("ms_per_step"), 1), "ms; attn frac", r(d.get("roofline", {}).get("frac"), 4), "| n100:", r(d.get("n100", {}).get("value")),
+      "views/s | n20 fusion:", r(d.get("fusion_only_n20", {}).get("value"), 1), "| error:", d.get("error"), d.get("n100", {}).get("error"))
 PY
       done ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
