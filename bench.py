@@ -16,7 +16,7 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.  F3R_BENCH_DRYRUN=1 swaps th
 launcher, the view split and the rank-0 JSON plumbing can be exercised on a CPU box (tests/test_bench_launcher.py).
 
 Operand format: the default is fp16 MFMA operands with precision "high" (split hi + lo planes for the GEMM weights and the DPT
-heads) -- the format whose pointmaps are within 1e-3 rel-L2 of the fp32 reference on the stress fixture as well
+heads, DESIGN.md section 3 (Precision modes)) -- the format whose pointmaps are within 1e-3 rel-L2 of the fp32 reference on the stress fixture as well
 as on the default-init protocol.  `alt_format` in the same line is the same workload measured right after in bf16 / "fast" (one
 16-bit number per operand: the round-1 headline format, faster, 2e-2 on the stress fixture); --no-alt skips it.
 
@@ -56,9 +56,9 @@ def parse(argv=None):
     ap.add_argument("--views", type=int, default=320, help="total views N of the forward pass (BASELINE headline: 320)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type (fp32 accumulate)")
     ap.add_argument("--precision", default="high", choices=["fast", "high"],
-                    help="high: split-precision GEMM operands (weights hi+lo in the transformer, both operands in the heads), see DESIGN.md section 4; "
+                    help="high: split-precision GEMM operands (weights hi+lo in the transformer, both operands in the heads), see DESIGN.md section 3 (Precision modes); "
                          "the default pair (fp16, high) is the operand format that meets the 1e-3 parity bar on the stress fixture")
-    ap.add_argument("--low-plane", default="fp16", choices=["fp16", "fp8"],
+    ap.add_argument("--low-plane", default="fp8", choices=["fp16", "fp8"],
                     help="precision high: where the MLPs' correction products A W_lo run -- a second fp16 plane, or the block-scaled fp8 MFMA "
                          "(Fast3R.low_plane; f3r.h F3R_SPLIT_W2F8)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other operand format (bf16 / fast)")

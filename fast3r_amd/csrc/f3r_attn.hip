@@ -17,7 +17,7 @@
 // QKV GEMM epilogue) is read from LDS as ordinary 16-byte A-operand fragments: no transpose anywhere.  Each K / V^T fragment read
 // from LDS feeds the MFMAs of both query blocks.
 //
-// Softmax, built to minimise the instructions a wave issues per tile (the measured bound):
+// Softmax, built to minimise the instructions a wave issues per tile (the measured bound, docs/history/ (the lab notes of rounds 1 - 4)):
 //   * scores come out of the matrix pipe already in exp2 units and already minus the softmax reference m: Q is pre-multiplied by
 //     scale*log2(e) (QKV epilogue, f3r_gemm_args.q_scale) and m enters through a fifth MFMA k-step (v_mfma_f32_32x32x8) whose K-side
 //     fragment is the constant (1, 1, 0, ..) and whose Q-side fragment is (-m_hi, -m_lo, 0, ..), m kept as an exact sum of two

@@ -361,7 +361,7 @@ def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None, f8=Fa
     p.proj_w, p.proj_b = ops.pack_linear_weight(blk.attn.proj.weight.detach().float(), lp, split), _f32(blk.attn.proj.bias)
     # fc1_split False = fc1 single-plane inside "high" (Fast3R.high_fc1_planes = False): measured +3.5 % views/s at N = 100 for TWICE the
     # distance to the fp32 path on the real-size stress model (4.8e-4 / 6.1e-4 against 2.4e-4 / 2.8e-4), so it is an experiment knob, not
-    # the default (oracle/precision_study.py per-role run, DESIGN.md section 3 "Precision")
+    # the default (oracle/precision_study.py per-role run, DESIGN.md section 3 (Precision modes))
     p.fc1_split = bool(split) if fc1_split is None else bool(fc1_split)
     p.fc1_w, p.fc1_b = ops.pack_linear_weight(blk.mlp.fc1.weight.detach().float(), lp, p.fc1_split), _f32(blk.mlp.fc1.bias)
     p.fc2_w, p.fc2_b = ops.pack_linear_weight(blk.mlp.fc2.weight.detach().float(), lp, split), _f32(blk.mlp.fc2.bias)
@@ -581,7 +581,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     Two arguments the reference does not have (both optional):
       compute_dtype   the 16-bit MFMA operand type (torch.float16 default, torch.bfloat16);
       precision       default "high" with fp16 operands: the one format that is within 1e-3 rel-L2 of the fp32 reference on EVERY
-                      fixture, the stress fixture included (DESIGN.md section 4) -- what bench.py measures;
+                      fixture, the stress fixture included (DESIGN.md section 3 (Precision modes)) -- what bench.py measures;
                       "fast": every GEMM / conv operand is ONE 16-bit number (within 1e-3 on default-init weights only).
                       "high": split-precision operands (f3r.h f3r_split) -- transformer weights as hi + lo planes (2 MFMA passes per
                       GEMM), both operands of the DPT heads as hi + lo planes (3 passes, activations kept as two planes in HBM);
@@ -760,10 +760,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """split (hi + lo) weight planes and head activations: "high" and "exact"."""
         return self.precision in ("high", "exact")
 
-    # "fp8" (precision "high", fp16 operands): the correction products A W_lo of the transformer's fc1 layers run on the block-scaled fp8 MFMA
-    # (f3r.h F3R_SPLIT_W2F8: 1.4x the matrix-pipe rate of a second fp16 plane; fc2 reads the fp8 copy fc1's GELU epilogue writes beside its fp16
-    # output); changing it needs invalidate_packed_weights()
-    low_plane = "fp16"
+    # "fp8" (the default; precision "high" with fp16 operands): the correction products A W_lo of the transformer's MLPs (fc1, fc2) run on the
+    # block-scaled fp8 MFMA (f3r.h F3R_SPLIT_W2F8: 1.4x the matrix-pipe rate of a second fp16 plane; LayerNorm and fc1's GELU epilogue write the
+    # fp8 copies beside their fp16 outputs) for every pass whose token count is a multiple of 256; "fp16": two fp16 planes everywhere.  Measured
+    # on ViT-L stress weights (profiles/r05_parity_low_plane_fp8_vs_fp16_vit_large_hot.txt): the same distance to the fp32 path (2.34e-4 vs
+    # 2.39e-4 at N = 3, 2.76e-4 both at N = 100), +0.7 % views/s at N = 320, +1.7 % at N = 100, +3.9 % fusion-only at N = 20.  Changing it
+    # needs invalidate_packed_weights().
+    low_plane = "fp8"
     high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
 
     @property

@@ -16,7 +16,7 @@ selects the operand format of the HIP kernels:
                                                                    emulation excepted)
     torch.float32                                                  (in the reference: NOT fp32 but the default autocast dtype, SURVEY.md
                                                                    section 0.3) fp16 operands with precision="high" (split weights,
-                                                                   split head operands, fp16 attention); a
+                                                                   split head operands, fp16 attention; DESIGN.md section 3 (Precision modes)); a
                                                                    one-time warning says so
     anything else                                                  the model's own compute_dtype / precision
 Accumulation, residual stream, LayerNorm, softmax and outputs are always fp32; the measured distance of every mode to the

@@ -137,7 +137,7 @@ typedef struct f3r_gemm_args {
                         group m / rope_w (rope_w = tokens per view, or 1 with one table row per token); the first 32 dims of a head
                         rotate with table columns 0-15 (dim i pairs with i+16), the last 32 with columns 16-31 -- the host permutes
                         the q / k weight rows so that the reference's interleaved pairs (2j, 2j+1) land on these positions */
-  /* Split-precision operands (the "high" precision mode): a value x is carried as two lowp numbers
+  /* Split-precision operands (the "high" precision mode, DESIGN.md section 3 (Precision modes)): a value x is carried as two lowp numbers
      hi = lowp(x), lo = lowp(x - hi) (~22 significand bits with fp16 pieces) and the product is summed over K SEGMENTS on the same
      MFMA path (fp32 accumulate):  F3R_SPLIT_W2: A.W_hi + A.W_lo (weights exact to ~2^-22, activations single);
      F3R_SPLIT_X3: A_hi.W_hi + A_hi.W_lo + A_lo.W_hi.  With split != 0, W is [N][2][Kpad/2] (plane 0 = hi, plane 1 = lo; Kpad is still

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU emulation of operand-rounding designs for the HIP path (decides DESIGN.md section 4).
+"""TEST INFRASTRUCTURE ONLY -- CPU emulation of operand-rounding designs for the HIP path (decides DESIGN.md section 3 (Precision modes)).
 
 Runs the oracle (oracle/fast3r_oracle.py) with its GEMM-like functionals wrapped so that operands (and, optionally, stored
 activations) are rounded the way a candidate kernel design would round them, and prints the end-to-end rel-L2 of every design

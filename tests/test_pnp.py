@@ -269,7 +269,7 @@ def test_hip_matches_the_reference_wrapper(built_lib):
     from the ground truth on the noisy scenes, identically.
     'individual' mode is NOT compared value by value: there the reference keeps the FIRST of its 100 focal candidates that reaches the
     maximum inlier count (`score > best[0]`, init_im_poses.py:341-342), i.e. the low end of a plateau that is wide at 5 px on small images
-    (fixture: 55 for a true 70), while the product breaks ties by reprojection cost; only structure and failure
+    (fixture: 55 for a true 70), while the product breaks ties by reprojection cost (docs/rows_f.md); only structure and failure
     handling are compared in that mode."""
     from fast3r_amd import MultiViewDUSt3RLitModule
     for c in _pose_cases():

@@ -2,7 +2,7 @@
 # Builds tools/lab/libf3r_hip_lab.so: the product library with the ablation variants of the 8-wave GEMM compiled in (-DF3R_GEMM_LAB,
 # kernel_sel >= 16).  Used only by tools/kernel_bench.py --what lab / labtime through F3R_LAB_LIB; nothing in fast3r_amd/, tests/ or bench.py
 # loads it.  (The 90-variant study of the HIP attention kernel of rounds 1 - 2 -- f3r_attn_lab.h, f3r_attn_variants.hip, f3r_attn_xp.h -- was
-# removed in round 4: its conclusions are in DESIGN.md section 6, its sources in git history up to commit f40f83d.  Variants of the
+# removed in round 4: its conclusions are in docs/history/ (the lab notes of rounds 1 - 4), its sources in git history up to commit f40f83d.  Variants of the
 # hand-scheduled kernels: tools/lab/build_attn_variants.sh, tools/gemm_lab.py.)
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
