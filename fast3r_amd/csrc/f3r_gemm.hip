@@ -327,7 +327,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;
   F3R_REQUIRE(a.split != F3R_SPLIT_X3 || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 split needs A_lo (16-byte aligned) and no a_relu");
-  F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 7) || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
+  F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 7) || a.kernel_sel == 9 || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
   F3R_REQUIRE(a.N % 4 == 0, "f3r_gemm: N %d must be a multiple of 4", a.N);
   F3R_REQUIRE(al16(a.A) && al16(a.W), "f3r_gemm: A/W must be 16-byte aligned");
   F3R_REQUIRE(a.dtype == F3R_F16 || a.dtype == F3R_BF16, "f3r_gemm: bad dtype %d", a.dtype);
@@ -383,17 +383,17 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   // 6 = the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/gemm_gen.py), an ineligible launch is an error; 0 takes it for the launches
   // it is built for (the transformer's big linear layers: enough full 256 x 256 tiles to fill its persistent grid, f3r_gemm_asm_preferred);
   // 7 = automatic WITHOUT it
-  if (a.kernel_sel == 6 || a.kernel_sel == 0) {
+  if (a.kernel_sel == 6 || a.kernel_sel == 0 || a.kernel_sel == 9) {
     const char* why = "";
     // (QKV = two launches: q | k with 2/3 of the tiles, V^T with 1/3; the smaller one decides)
-    if (a.epi == F3R_EPI_QKV && f3r_gemm_asm_qkv_eligible(a, &why) && (a.kernel_sel == 6 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 3 / 256))))
+    if (a.epi == F3R_EPI_QKV && f3r_gemm_asm_qkv_eligible(a, &why) && (a.kernel_sel == 6 || a.kernel_sel == 9 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 3 / 256))))
       return f3r_gemm_asm_qkv_launch(a, s);
     const bool ok = a.epi != F3R_EPI_QKV && f3r_gemm_asm_eligible(a, &why);
-    if (a.kernel_sel == 6 && !ok) {
+    if ((a.kernel_sel == 6 || a.kernel_sel == 9) && !ok) {
       f3r_set_error("f3r_gemm: kernel_sel 6 (hand-scheduled kernel) but the launch is not eligible: %s", why);
       return F3R_ERR_UNSUPPORTED;
     }
-    if (ok && (a.kernel_sel == 6 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 256)))) return f3r_gemm_asm_launch(a, s);
+    if (ok && (a.kernel_sel == 6 || a.kernel_sel == 9 || f3r_gemm_asm_preferred((a.M / 256) * (a.N / 256)))) return f3r_gemm_asm_launch(a, s);
   }
   const int sel = a.kernel_sel == 7 ? 0 : a.kernel_sel;
   if (sel >= 2) F3R_REQUIRE(f3r_gemm256_eligible(a), "f3r_gemm: kernel_sel %d but the shape is not eligible for the 256-tile kernel", sel);

@@ -265,7 +265,7 @@ class Wave:
         if op.endswith("_e32") or op.endswith("_e64"):
             op = op[:-4]
         # ---------------- scalar
-        if op == "s_nop" or op == "s_setprio":
+        if op == "s_nop" or op == "s_setprio" or op == "s_sleep":
             return
         if op == "s_endpgm":
             self.retire(self.vm, 0)
