@@ -898,11 +898,19 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True, **gqa)
             sharding.end_layer(kv_exchange)
         ops.gemm(o, pb.proj_w, bias=pb.proj_b, res_f32=x, out_f32=x, split=sp)
-        if getattr(pb, "fc1_w8", None) is not None and T > 0 and T % 256 == 0 and not pb.swiglu_hidden:
-            # low plane in fp8: LayerNorm writes rows [D fp16 | D fp8], fc1 runs A W_hi on the fp16 MFMA and A W_lo on the block-scaled fp8 one
+        # low plane in fp8 (Fast3R.low_plane): only the hand-scheduled 256 x 256-tile kernels read the [fp16 | fp8] rows, so a GEMM takes that form
+        # when its tiles fill the chip at least once (256 CUs): fc1 (4 D wide) from 4096 tokens on, fc2 from 16 384; below that the scene is
+        # launch- and occupancy-bound and the compiler-scheduled small-tile kernels win (N = 3: 118 us against 36 us per fc2, round-5 profile)
+        f8_fc1 = pb.fc1_w8 is not None and T % 256 == 0 and not pb.swiglu_hidden and (T // 256) * (pb.fc1_w8.shape[0] // 256) >= 256
+        if f8_fc1:
+            f8_fc2 = (T // 256) * (pb.fc2_w8.shape[0] // 256) >= 256
             rows = ops.layernorm_f8(x, pb.n2w, pb.n2b, pb.eps, out_rows=ws.rows8(D), rms=pb.rms)
-            _, hid = ops.gemm(rows, pb.fc1_w8, bias=pb.fc1_b, act="gelu", out_lp=ws.hid8(), split="w2f8", w_scale=pb.fc1_ws, out_f8_rows=True)
-            ops.gemm(hid, pb.fc2_w8, bias=pb.fc2_b, res_f32=x, out_f32=x, split="w2f8", w_scale=pb.fc2_ws)
+            if f8_fc2:   # fc1's GELU epilogue writes rows [4 D fp16 | 4 D fp8], fc2 runs on them
+                _, hid = ops.gemm(rows, pb.fc1_w8, bias=pb.fc1_b, act="gelu", out_lp=ws.hid8(), split="w2f8", w_scale=pb.fc1_ws, out_f8_rows=True)
+                ops.gemm(hid, pb.fc2_w8, bias=pb.fc2_b, res_f32=x, out_f32=x, split="w2f8", w_scale=pb.fc2_ws)
+            else:
+                _, hid = ops.gemm(rows, pb.fc1_w8, bias=pb.fc1_b, act="gelu", out_lp=ws.hid, split="w2f8", w_scale=pb.fc1_ws)
+                ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split=sp)
             return x
         h2, _ = ops.layernorm(x, pb.n2w, pb.n2b, pb.eps, lp, out_lp=o, rms=pb.rms)
         if pb.swiglu_hidden:  # LlamaDecoder FeedForward: w2(silu(w1 x) * w3 x) (llama.py:284)

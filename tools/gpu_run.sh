@@ -182,7 +182,7 @@ import json; d = json.load(open('$d/emulated_rank3of8_n320.json')); print('rank 
     gemmpmc)    # rocprofv3 PMC over the GEMM micro-benchmark
       timeout 900 bash tools/pmc_gemm.sh > $d/pmc.log 2>&1; tail -30 $d/pmc.log; cp gpurun_out/pmcg/gemm_pmc.json $d/ 2>/dev/null ;;
     prof320)    # rocprofv3 kernel stats of the default bench command (3 forwards)
-      ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$d/prof --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-parity > $OLDPWD/$d/bench.json 2> $OLDPWD/$d/err.log )
+      ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/$d/prof --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-parity --no-inference --no-extra-configs > $OLDPWD/$d/bench.json 2> $OLDPWD/$d/err.log )
       f=$(ls $d/prof/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $d/kernel_stats.csv && head -12 $d/kernel_stats.csv | cut -c1-200
       find $d/prof -name "*kernel_trace.csv" -delete ;;
     *) echo "unknown step $step" ;;
