@@ -159,8 +159,6 @@ PY
     emurank)    # EMULATION: one GPU runs rank 3 of 8 of the view-sharded forward at N = 320 (and N = 1500) with the round's kernels (no collectives)
       timeout 900 python bench.py --emulate-rank 3 --of 8 --steps 2 --warmup 1 > $d/emulated_rank3of8_n320.json 2> $d/err.log; python -c "
 import json; d = json.load(open('$d/emulated_rank3of8_n320.json')); print('rank 3 of 8, N=320:', round(d['per_rank_step_ms'], 1), 'ms ->', round(d['projected_views_per_s_if_comm_is_hidden'], 1), 'views/s if the exchange is hidden')" ;;
-    smalln)     # small scenes (the README flow): latency of N = 3 / 8 / 20 forwards, eager and with hipGraph replay
-      timeout 600 python tools/small_n_latency.py --dtype fp16 --precision high --views 3,8,20 > $d/small_n_latency.jsonl 2> $d/err.log; cat $d/small_n_latency.jsonl | cut -c1-300 ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)
