@@ -128,7 +128,7 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
 namespace {
 
 // fills the tile map / persistent grid and launches one kernel: M x N outputs in 256 x 256 tiles
-int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, hipStream_t stream, bool skew = true) {
+int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, hipStream_t stream, bool skew = false) {
   const uint32_t ntm = (uint32_t)(M / 256), ntn = (uint32_t)(N / 256);
   const uint32_t n_wg = ntm * ntn;
   // tile map (gemm_gen.pack_args): XCD-contiguous runs, groups of gm m-tiles x all n-tiles, gm = the largest power of two <= 8 dividing ntm
@@ -146,8 +146,9 @@ int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, h
   const int cus = num_cus();
   k.n_wg = n_wg;
   k.grid = n_wg < (uint32_t)cus ? n_wg : (uint32_t)cus;
-  // persistent workgroups with >= 2 equal tiles each run in lock step: start them up to 3/4 of a tile period apart so that one quarter's epilogue
-  // traffic overlaps the others' K loops
+  // kernel_sel 9 (measurement): start the persistent workgroups up to 3/4 of a tile period apart, so that one quarter's epilogue traffic overlaps
+  // the others' K loops instead of all 256 CUs writing out at once.  MEASURED SLOWER (profiles/r05_gemm_w2_vs_w2f8_and_start_skew.jsonl: fc2 -6 %,
+  // fc1 -0.7 %, proj +1 %): workgroups that run in lock step share their operand panels through the XCD's L2 in time; off by default.
   if (skew && n_wg >= 2 * k.grid) k.flags |= FLAG_SKEW;
   size_t size = k.w_scale ? sizeof(k) : offsetof(f3r_gemm_asm_args, w_scale);   // the kernarg segment of the kernel taking the launch
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -186,7 +187,7 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.nk1_w = k.nk;  // the weight row holds its planes back to back: that stream never wraps
   k.act = (uint32_t)a.act;
   k.scale = 1.0f;
-  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel != 9);
+  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9);
 }
 
 // ---- F3R_SPLIT_W2F8: rows [K fp16 | K fp8] on both operands, the K loop runs on from K / 64 fp16 K-tiles into K / 128 fp8 ones
@@ -241,7 +242,7 @@ int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.scale = 1.0f;
   k.w_scale = a.w_scale;
   k.out8_off = a.out_lp_f8 ? (uint32_t)a.N * 2u : 0u;
-  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel != 9);
+  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9);
 }
 
 // ---- the QKV projection without rotary embedding (the fusion decoder: blocks.py:138-143 with rope = None) as two launches of the lowp
@@ -300,7 +301,7 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.scale = a.q_scale != 0.f ? a.q_scale : 1.0f;
   k.seg_stride = (int64_t)((const char*)a.k - (const char*)a.q);
   k.tps = (uint32_t)(D / 256);
-  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel != 9);
+  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel == 9);
   if (rc != F3R_OK) return rc;
   // launch 2: V^T[seq][d][t] = W_v X^T
   f3r_gemm_asm_args v;
@@ -320,5 +321,5 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   v.flags = FLAG_BIAS_ON_M;
   v.seg_stride = (int64_t)D * a.ldvt * 2;
   v.tps = (uint32_t)(a.seq_len / 256);
-  return launch_tiles(fn, v, D, a.M, stream, a.kernel_sel != 9);
+  return launch_tiles(fn, v, D, a.M, stream, a.kernel_sel == 9);
 }

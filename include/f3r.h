@@ -152,9 +152,10 @@ typedef struct f3r_gemm_args {
                          + GELU / ReLU), or F3R_EPI_QKV without rotary embedding and equal q / k / v widths (two launches) -- F3R_ERR_UNSUPPORTED otherwise.
                          0 uses it for eligible launches whose 256 x 256 tiles fill its persistent grid (>= one tile per CU, last round >= 80 % full);
                          7 = pick by shape among the compiler-scheduled kernels only;
-                         9 = like 6 but WITHOUT the start-up skew of the persistent workgroups (measurement only, round 5: by default workgroup b of a
-                         launch with >= 2 tiles per workgroup starts ((b / 8) % 4) quarter tile periods late, so that the epilogues' HBM traffic of
-                         one quarter of the chip overlaps the K loops of the rest instead of all 256 CUs writing out at once) */
+                         9 = like 6 but WITH a start-up skew of the persistent workgroups (measurement only, round 5: workgroup b of a launch with >= 2
+                         tiles per workgroup starts ((b / 8) % 4) quarter tile periods late, so that the epilogues' HBM traffic of one quarter of the
+                         chip overlaps the K loops of the rest; measured 6 % SLOWER on fc2, neutral elsewhere -- lock-step workgroups share their
+                         operand panels through L2 -- hence not the default) */
   const void* A_lo;
   /* low planes of the lowp outputs / residuals (NULL = not carried): out_lp_lo = lowp(v - float(out_lp)); res_lp*_lo are added like
      their high planes.  Same leading dimensions as the high planes. */

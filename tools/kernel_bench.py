@@ -465,9 +465,9 @@ if __name__ == "__main__":
                 o32 = torch.randn((M, n), device=DEV) if kw.get("res") else None
                 olp = torch.empty((M, n), dtype=f16, device=DEV) if kw.get("out") == "lp" else None
                 common = dict(bias=bias, act=kw.get("act"), res_f32=o32, out_f32=o32, out_lp=olp)
-                fns = {"w2 (two fp16 planes), lock-step start": lambda: ops.gemm(rows[:, :k], w2, split="w2", kernel_sel=9, **common),
+                fns = {"w2 (two fp16 planes), skewed start": lambda: ops.gemm(rows[:, :k], w2, split="w2", kernel_sel=9, **common),
                        "w2 (two fp16 planes)": lambda: ops.gemm(rows[:, :k], w2, split="w2", kernel_sel=6, **common),
-                       "w2f8 (low plane in fp8), lock-step start": lambda: ops.gemm(rows, w8, split="w2f8", w_scale=ws, kernel_sel=9, **common),
+                       "w2f8 (low plane in fp8), skewed start": lambda: ops.gemm(rows, w8, split="w2f8", w_scale=ws, kernel_sel=9, **common),
                        "w2f8 (low plane in fp8)": lambda: ops.gemm(rows, w8, split="w2f8", w_scale=ws, **common)}
                 res = {nm_: [] for nm_ in fns}
                 for rnd_ in range(4):
