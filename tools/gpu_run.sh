@@ -159,6 +159,35 @@ PY
     emurank)    # EMULATION: one GPU runs rank 3 of 8 of the view-sharded forward at N = 320 (and N = 1500) with the round's kernels (no collectives)
       timeout 900 python bench.py --emulate-rank 3 --of 8 --steps 2 --warmup 1 > $d/emulated_rank3of8_n320.json 2> $d/err.log; python -c "
 import json; d = json.load(open('$d/emulated_rank3of8_n320.json')); print('rank 3 of 8, N=320:', round(d['per_rank_step_ms'], 1), 'ms ->', round(d['projected_views_per_s_if_comm_is_hidden'], 1), 'views/s if the exchange is hidden')" ;;
+    gemmf8pmc)  # matrix-pipe utilisation + effective clock of the hand-scheduled GEMM kernels, two fp16 planes vs the low plane in fp8 (one PMC pass, M = 327 680)
+      ( cd /tmp; PYTHONPATH=$OLDPWD rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $OLDPWD/$d/pmc --output-format csv -- python $OLDPWD/tools/kernel_bench.py --what gemmf8 --views 320 ) > $d/pmc.log 2>&1
+      python - $d <<'PY'
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{d}/pmc/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "f3r_gemm_asm" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"] + " grid=" + r.get("Grid_Size", "?") + " lds=" + r.get("LDS_Block_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for f in glob.glob(f"{d}/pmc/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "f3r_gemm_asm" in r["Kernel_Name"]:
+            dur[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+out = {}
+for k, c in acc.items():
+    v = {n: sum(x) / len(x) for n, x in c.items()}
+    cyc = v.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc:
+        v["mfma_util_cycles"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024)
+        v["launches"] = len(next(iter(c.values())))
+    out[k] = v
+    print(k, {n: (round(x, 4) if x < 100 else int(x)) for n, x in v.items() if n in ("mfma_util_cycles", "SQ_INSTS_MFMA", "launches")})
+for k, x in dur.items():
+    print(k, "mean dispatch ms over all roles", round(sum(x) / len(x) / 1e6, 3), "n", len(x))
+json.dump(out, open(f"{d}/gemm_asm_f8_pmc.json", "w"), indent=1)
+PY
+      find $d/pmc -name "*kernel_trace.csv" -delete ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)
