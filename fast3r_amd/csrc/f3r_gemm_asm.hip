@@ -31,10 +31,14 @@ struct f3r_gemm_asm_args {
   // ---- ARG_F8: read by the f8 kernels only (their kernarg segment is 144 bytes, the others' 128)
   const uint32_t* w_scale;              // E8M0 scale words of the weight rows' fp8 plane
   uint32_t nk8, out8_off;               // fp8 K-tiles ([256][128 k]) at the end of every output tile's K loop; byte offset of the output's fp8 copy in its row (0 = none)
+  // ---- ARG_ROPE: read by the lowp-role kernels only (kernarg segment 176 bytes), ACT_ROPE
+  const float* rope_cos;                // [n_pos][16]
+  const float* rope_sin;
+  uint32_t seq_len, seq_magic, rope_w, rope_w_magic;   // token m of the launch sits at position m % seq_len = (y, x) = (pos / rope_w, pos % rope_w)
 };
-static_assert(sizeof(f3r_gemm_asm_args) == 144 && offsetof(f3r_gemm_asm_args, w_scale) == 128 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
+static_assert(sizeof(f3r_gemm_asm_args) == 176 && offsetof(f3r_gemm_asm_args, w_scale) == 128 && offsetof(f3r_gemm_asm_args, rope_cos) == 144 && offsetof(f3r_gemm_asm_args, lda_b) == 40 && offsetof(f3r_gemm_asm_args, xq) == 64 &&
               offsetof(f3r_gemm_asm_args, seg_stride) == 96 && offsetof(f3r_gemm_asm_args, nk1_w) == 120, "must match ARG_* of gemm_gen.py");
-enum { ACT_SCALE = 3, FLAG_BIAS_ON_M = 1, FLAG_SKEW = 2 };
+enum { ACT_SCALE = 3, ACT_ROPE = 4, FLAG_BIAS_ON_M = 1, FLAG_SKEW = 2 };
 
 enum { ROLE_F32 = 0, ROLE_LP = 1 };
 struct DevKernels {
@@ -128,7 +132,8 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
 namespace {
 
 // fills the tile map / persistent grid and launches one kernel: M x N outputs in 256 x 256 tiles
-int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, hipStream_t stream, bool skew = false) {
+// role / f8 select the kernarg segment the kernel declares: lowp role 176 bytes (.. ARG_ROPE), fp32 role 128, or 144 with the fp8 low plane
+int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, hipStream_t stream, bool skew, int role) {
   const uint32_t ntm = (uint32_t)(M / 256), ntn = (uint32_t)(N / 256);
   const uint32_t n_wg = ntm * ntn;
   // tile map (gemm_gen.pack_args): XCD-contiguous runs, groups of gm m-tiles x all n-tiles, gm = the largest power of two <= 8 dividing ntm
@@ -150,7 +155,7 @@ int launch_tiles(hipFunction_t fn, f3r_gemm_asm_args& k, int64_t M, int64_t N, h
   // the others' K loops instead of all 256 CUs writing out at once.  MEASURED SLOWER (profiles/r05_gemm_w2_vs_w2f8_and_start_skew.jsonl: fc2 -6 %,
   // fc1 -0.7 %, proj +1 %): workgroups that run in lock step share their operand panels through the XCD's L2 in time; off by default.
   if (skew && n_wg >= 2 * k.grid) k.flags |= FLAG_SKEW;
-  size_t size = k.w_scale ? sizeof(k) : offsetof(f3r_gemm_asm_args, w_scale);   // the kernarg segment of the kernel taking the launch
+  size_t size = role == ROLE_LP ? sizeof(k) : (k.w_scale ? offsetof(f3r_gemm_asm_args, rope_cos) : offsetof(f3r_gemm_asm_args, w_scale));
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   hipError_t e = hipModuleLaunchKernel(fn, k.grid, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
   if (e != hipSuccess) {
@@ -187,7 +192,7 @@ int f3r_gemm_asm_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.nk1_w = k.nk;  // the weight row holds its planes back to back: that stream never wraps
   k.act = (uint32_t)a.act;
   k.scale = 1.0f;
-  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9);
+  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9, role);
 }
 
 // ---- F3R_SPLIT_W2F8: rows [K fp16 | K fp8] on both operands, the K loop runs on from K / 64 fp16 K-tiles into K / 128 fp8 ones
@@ -242,7 +247,7 @@ int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.scale = 1.0f;
   k.w_scale = a.w_scale;
   k.out8_off = a.out_lp_f8 ? (uint32_t)a.N * 2u : 0u;
-  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9);
+  return launch_tiles(fn, k, a.M, a.N, stream, a.kernel_sel == 9, role);
 }
 
 // ---- the QKV projection without rotary embedding (the fusion decoder: blocks.py:138-143 with rope = None) as two launches of the lowp
@@ -252,7 +257,10 @@ int f3r_gemm_asm_f8_launch(const f3r_gemm_args& a, hipStream_t stream) {
 bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why) {
   *why = "";
   if (a.epi != F3R_EPI_QKV || a.a_mode != F3R_A_PLAIN) { *why = "not a QKV launch"; return false; }
-  if (a.rope_cos) { *why = "rotary embedding in the epilogue"; return false; }
+  if (a.rope_cos) {  // round 5: RoPE-2D of the CroCo encoder fused into the q | k launch's epilogue (ACT_ROPE); the per-group form of the LlamaDecoder is not
+    if (a.rope_mode != 0 || a.rope_w <= 0) { *why = "rotary embedding per row group (rope_mode 1)"; return false; }
+    if (a.M * (int64_t)a.seq_len >= (1ll << 32) || (int64_t)a.seq_len * a.rope_w >= (1ll << 32)) { *why = "token index x sequence length reaches 2^32 (magic-number division)"; return false; }
+  }
   if (a.split != F3R_SPLIT_NONE && a.split != F3R_SPLIT_W2) { *why = "X3 split"; return false; }
   const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
   const int Dkv = (a.N - Dq) / 2;
@@ -297,11 +305,19 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.nk1 = (uint32_t)(Kpad1 / 64);
   k.nk = k.nk1 * (uint32_t)planes;
   k.nk1_w = k.nk;
-  k.act = ACT_SCALE;
+  k.act = a.rope_cos ? ACT_ROPE : ACT_SCALE;
   k.scale = a.q_scale != 0.f ? a.q_scale : 1.0f;
+  if (a.rope_cos) {
+    k.rope_cos = a.rope_cos;
+    k.rope_sin = a.rope_sin;
+    k.seq_len = (uint32_t)a.seq_len;
+    k.seq_magic = a.seq_len > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)a.seq_len - 1) / (uint64_t)a.seq_len) : 0;
+    k.rope_w = (uint32_t)a.rope_w;
+    k.rope_w_magic = a.rope_w > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)a.rope_w - 1) / (uint64_t)a.rope_w) : 0;
+  }
   k.seg_stride = (int64_t)((const char*)a.k - (const char*)a.q);
   k.tps = (uint32_t)(D / 256);
-  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel == 9);
+  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel == 9, ROLE_LP);
   if (rc != F3R_OK) return rc;
   // launch 2: V^T[seq][d][t] = W_v X^T
   f3r_gemm_asm_args v;
@@ -321,5 +337,5 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   v.flags = FLAG_BIAS_ON_M;
   v.seg_stride = (int64_t)D * a.ldvt * 2;
   v.tps = (uint32_t)(a.seq_len / 256);
-  return launch_tiles(fn, v, D, a.M, stream, a.kernel_sel == 9);
+  return launch_tiles(fn, v, D, a.M, stream, a.kernel_sel == 9, ROLE_LP);
 }

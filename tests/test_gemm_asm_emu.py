@@ -59,7 +59,9 @@ def test_emulated_tile_map(tiles, wgs):
 
 
 @pytest.mark.parametrize("kw,tol", [(dict(), 5e-4), (dict(n_seq=1, seq_tiles=2, d_tiles=2, nk1=2, segs=2, grid=2), 5e-4),
-                                    (dict(dtype="bf16", n_seq=3, nk1=5, grid=1), 4e-3)])
+                                    (dict(dtype="bf16", n_seq=3, nk1=5, grid=1), 4e-3),
+                                    # round 5: RoPE-2D in the q | k launch's epilogue (ACT_ROPE) -- pairs through v_permlane32_swap, positions by magic division
+                                    (dict(n_seq=2, d_tiles=2, nk1=4, rope_w=12, grid=1), 8e-4), (dict(n_seq=3, nk1=2, segs=2, rope_w=1), 8e-4)])
 def test_emulated_qkv_as_two_launches(kw, tol):
     """the fusion decoder's QKV projection (no rotary embedding): q | k through output segments with the q scale, V^T through the swapped
     operand roles (weights with their lo plane as the kernel's A operand, activations wrapping per K segment as its W operand, bias by

@@ -87,9 +87,39 @@ def test_gemm_asm_qkv(built_lib, dt, n_seq, S, D, K, split):
         got_v = vt[:, :, :S].float().cpu().permute(0, 2, 1).reshape(M, D)
         assert_close(got_v, ref[:, 2 * D:], lp_tol(dt), f"v^T sel={sel}")
         assert float(vt[:, :, S:].float().abs().sum()) == 0.0  # padding untouched
-    cos, sin = ops.rope_tables(64, 100.0, DEV)
-    with pytest.raises((ValueError, RuntimeError)):  # rotary embedding stays on the compiler-scheduled kernel: forced -> error
-        ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, (cos, sin, 16), q_scale=qs, split=split, kernel_sel=ASM)
+    # RoPE-2D fused into the q | k launch's epilogue (round 5: ACT_ROPE; pairs (i, i + 16) meet through v_permlane32_swap): tokens of a sequence on
+    # a grid rope_w wide -- against the compiler-scheduled kernel's RoPE epilogue (the reference form, test_kernels_gpu.py) and fp64
+    for rope_w in (16, 12, 1):
+        n_pos = max(rope_w, -(-S // rope_w))
+        cos, sin = ops.rope_tables(n_pos, 100.0, DEV)
+        outs = {}
+        for sel in (ASM, HIP):
+            q = torch.zeros((M, D), dtype=dt, device=DEV)
+            k = torch.zeros((M, D), dtype=dt, device=DEV)
+            vt = torch.zeros((n_seq, D, ops.vt_ld(S)), dtype=dt, device=DEV)
+            ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, (cos, sin, rope_w), q_scale=qs, split=split, kernel_sel=sel)
+            outs[sel] = (q.float().cpu(), k.float().cpu(), vt.float().cpu())
+        pos = torch.arange(M) % S
+        py, px = pos // rope_w, pos % rope_w
+        c64, s64 = cos.double().cpu(), sin.double().cpu()
+
+        def rope(x):
+            out = x.clone()
+            for h0 in range(0, D, 64):
+                for half, p in ((0, py), (1, px)):
+                    a_, b_ = x[:, h0 + 32 * half:h0 + 32 * half + 16], x[:, h0 + 32 * half + 16:h0 + 32 * half + 32]
+                    out[:, h0 + 32 * half:h0 + 32 * half + 16] = a_ * c64[p] - b_ * s64[p]
+                    out[:, h0 + 32 * half + 16:h0 + 32 * half + 32] = b_ * c64[p] + a_ * s64[p]
+            return out
+        assert_close(outs[ASM][0], rope(ref[:, :D]) * qs, lp_tol(dt), f"rope q asm w={rope_w}")
+        assert_close(outs[ASM][1], rope(ref[:, D:2 * D]), lp_tol(dt), f"rope k asm w={rope_w}")
+        assert_close(outs[ASM][0], outs[HIP][0].double(), 2 * lp_tol(dt), "rope q asm vs HIP")
+        assert_close(outs[ASM][1], outs[HIP][1].double(), 2 * lp_tol(dt), "rope k asm vs HIP")
+        assert torch.equal(outs[ASM][2], outs[HIP][2]) or (outs[ASM][2] - outs[HIP][2]).abs().max() <= 2 * lp_tol(dt) * outs[HIP][2].abs().max()
+    cosg, sing = ops.rope_tables(64, 100.0, DEV)
+    with pytest.raises((ValueError, RuntimeError)):  # the per-row-group form of the LlamaDecoder stays on the compiler-scheduled kernel: forced -> error
+        ops.gemm_qkv(a.to(DEV), wp, bias.to(DEV), q, k, vt, S, (torch.cat([cosg, cosg], 1).contiguous(), torch.cat([sing, sing], 1).contiguous(), S), q_scale=qs,
+                     split=split, rope_mode=1, kernel_sel=ASM)
 
 
 def test_gemm_asm_strided_operand_and_outputs(built_lib):

@@ -178,7 +178,24 @@ def run_case_f8(role="f32", ntm=1, ntn=1, nk16=4, act="none", bias=True, res=Tru
     return err
 
 
-def run_qkv_case(dtype="f16", n_seq=2, seq_tiles=1, d_tiles=1, nk1=4, segs=1, scale=0.231, seed=0, grid=None):
+def rope2d_ref(x, seq_len, rope_w, cos, sin):
+    """RoPE-2D as f3r_gemm_epi.h applies it (pos_embed.py:162-183): per 64-wide head, dims i, i + 16 of the first 32 rotate by angle i of the token's
+    row position, of the last 32 by its column position; x [T][D] float64"""
+    T_, D = x.shape
+    out = x.copy()
+    pos = np.arange(T_) % seq_len
+    py, px = pos // rope_w, pos % rope_w
+    for h0 in range(0, D, 64):
+        for half, p in ((0, py), (1, px)):
+            a = x[:, h0 + 32 * half:h0 + 32 * half + 16]
+            b = x[:, h0 + 32 * half + 16:h0 + 32 * half + 32]
+            c, s = cos[p].astype(np.float64), sin[p].astype(np.float64)
+            out[:, h0 + 32 * half:h0 + 32 * half + 16] = a * c - b * s
+            out[:, h0 + 32 * half + 16:h0 + 32 * half + 32] = b * c + a * s
+    return out
+
+
+def run_qkv_case(dtype="f16", n_seq=2, seq_tiles=1, d_tiles=1, nk1=4, segs=1, scale=0.231, seed=0, grid=None, rope_w=0):
     """the decoder-style QKV projection as the product issues it (f3r_gemm_asm.hip): launch 1 = q | k columns of the fused weight into two
     buffers (output segments, ACT_SCALE on the q segment); launch 2 = V^T with the operand roles swapped (kernel A = the v weight rows incl.
     their lo plane, kernel W = the activations, wrapping per K segment; bias indexed by the output ROW; one output segment per sequence)"""
@@ -202,9 +219,15 @@ def run_qkv_case(dtype="f16", n_seq=2, seq_tiles=1, d_tiles=1, nk1=4, segs=1, sc
     assert not prog.check_hazards()
     nk = nk1 * segs
     ldw_b = K1 * segs * 2
+    rope = None
+    if rope_w:   # the encoder's form: RoPE-2D in the epilogue of the q | k launch (tokens of a sequence on a grid rope_w wide)
+        n_pos = max(rope_w, -(-S_ // rope_w))
+        ang = np.arange(n_pos)[:, None] * (100.0 ** (-np.arange(16) / 16.0))[None, :]
+        cos_t, sin_t = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        rope = (mem.alloc(cos_t), mem.alloc(sin_t), S_, rope_w)
     # launch 1: q | k
-    karg, gr = gemm_gen.pack_args(a_x, a_w, a_b, 0, a_q, K1 * 2, ldw_b, 0, D * 2, nk, nk1, T_ // 256, 2 * d_tiles, gemm_gen.ACT_SCALE, grid=grid,
-                                  seg_stride=a_k - a_q, tps=d_tiles, scale=scale)
+    karg, gr = gemm_gen.pack_args(a_x, a_w, a_b, 0, a_q, K1 * 2, ldw_b, 0, D * 2, nk, nk1, T_ // 256, 2 * d_tiles, gemm_gen.ACT_ROPE if rope else gemm_gen.ACT_SCALE, grid=grid,
+                                  seg_stride=a_k - a_q, tps=d_tiles, scale=scale, rope=rope)
     arg = mem.alloc(np.frombuffer(karg, np.uint8))
     for wg in range(gr):
         Workgroup(prog, mem, arg, (wg, 0, 0), 4, g.lds_bytes, dtype).run()
@@ -223,6 +246,9 @@ def run_qkv_case(dtype="f16", n_seq=2, seq_tiles=1, d_tiles=1, nk1=4, segs=1, sc
     pad = mem.get(a_vt, np.uint16, (n_seq, D, ldvt))[:, :, S_:]
     assert (pad == 0x7E00).all(), "V^T padding columns were written"
     v = np.transpose(vt[:, :, :S_], (0, 2, 1)).reshape(T_, D)
+    if rope:
+        ref[:, :D] = rope2d_ref(ref[:, :D], S_, rope_w, cos_t, sin_t)
+        ref[:, D:2 * D] = rope2d_ref(ref[:, D:2 * D], S_, rope_w, cos_t, sin_t)
     errs = [float(np.abs(q - ref[:, :D] * np.float32(scale)).max() / np.abs(ref[:, :D] * scale).max()), float(np.abs(k - ref[:, D:2 * D]).max() / np.abs(ref).max()),
             float(np.abs(v - ref[:, 2 * D:]).max() / np.abs(ref).max())]
     print(f"qkv {dtype}: {n_seq} x {S_} tokens, D = {D}, K = {segs} x {K1}: q {errs[0]:.3e} k {errs[1]:.3e} v {errs[2]:.3e}")

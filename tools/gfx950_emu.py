@@ -390,6 +390,17 @@ class Wave:
         if op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32"):
             self.wr(a[0], self.rd(a[1]).copy())
             return
+        if op == "v_mul_hi_u32":
+            x, y = self.rd(a[1]).astype(np.uint64), self.rd(a[2]).astype(np.uint64)
+            self.wr(a[0], ((x * y) >> np.uint64(32)).astype(np.uint32))
+            return
+        if op == "v_permlane32_swap_b32":   # the upper 32 lanes of the first operand <-> the lower 32 lanes of the second (EXEC ignored, as the generators use it)
+            x, y = self.rd(a[0]).copy(), self.rd(a[1]).copy()
+            nx, ny = x.copy(), y.copy()
+            nx[32:], ny[:32] = y[:32], x[32:]
+            self.file(a[0].kind)[a[0].idx] = nx
+            self.file(a[1].kind)[a[1].idx] = ny
+            return
         if op in ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_mul_lo_u32"):
             x, y = self.rd(a[1]).astype(np.uint64), self.rd(a[2]).astype(np.uint64)
             r = {"v_and_b32": x & y, "v_or_b32": x | y, "v_xor_b32": x ^ y, "v_add_u32": x + y, "v_sub_u32": x - y,
