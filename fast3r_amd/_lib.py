@@ -41,7 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("split", _c_i32), ("kernel_sel", _c_i32), ("A_lo", _c_vp),
         ("out_lp_lo", _c_vp), ("res_lp_lo", _c_vp), ("res_lp2_lo", _c_vp), ("out_relu", _c_vp), ("out_relu_lo", _c_vp),
         ("qkv_dq", _c_i32), ("out_lp_f8", _c_i32),
-        ("w_scale", _c_vp),
+        ("w_scale", _c_vp), ("W_aux", _c_vp),
     ]
 
 

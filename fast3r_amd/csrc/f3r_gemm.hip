@@ -317,6 +317,16 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(a.lda % 8 == 0 && a.lda * 2 >= (int64_t)a.K * 3, "f3r_gemm: W2F8 rows are [K fp16 | K fp8]: lda %lld must be >= 3 K / 2", (long long)a.lda);
     F3R_REQUIRE(a.epi != F3R_EPI_GENERIC || a.out_f32 || a.out_lp, "f3r_gemm: no output");
     const char* why = "";
+    if (a.epi == F3R_EPI_QKV) {  // q | k with the low plane in fp8, V^T (swapped operand roles) on two fp16 planes from W_aux
+      F3R_REQUIRE(a.q && a.k && a.vt && a.W_aux && al16(a.W_aux) && a.seq_len > 0 && a.M % a.seq_len == 0 && a.ldvt >= a.seq_len && a.act == F3R_ACT_NONE,
+                  "f3r_gemm: W2F8 QKV needs q, k, vt, W_aux (16-byte aligned), seq_len dividing M, no activation");
+      if (a.rope_cos) F3R_REQUIRE(a.rope_sin && a.rope_w > 0 && al16(a.rope_cos) && al16(a.rope_sin), "f3r_gemm: RoPE tables");
+      if (!f3r_gemm_asm_qkv_eligible(a, &why)) {
+        f3r_set_error("f3r_gemm: split W2F8 QKV but the launch is not eligible for the hand-scheduled kernel: %s", why);
+        return F3R_ERR_UNSUPPORTED;
+      }
+      return f3r_gemm_asm_qkv_launch(a, (hipStream_t)stream);
+    }
     if (!f3r_gemm_asm_f8_eligible(a, &why)) {
       f3r_set_error("f3r_gemm: split W2F8 (fp8 low plane) but the launch is not eligible for the hand-scheduled kernel: %s", why);
       return F3R_ERR_UNSUPPORTED;

@@ -261,15 +261,17 @@ bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why) {
     if (a.rope_mode != 0 || a.rope_w <= 0) { *why = "rotary embedding per row group (rope_mode 1)"; return false; }
     if (a.M * (int64_t)a.seq_len >= (1ll << 32) || (int64_t)a.seq_len * a.rope_w >= (1ll << 32)) { *why = "token index x sequence length reaches 2^32 (magic-number division)"; return false; }
   }
-  if (a.split != F3R_SPLIT_NONE && a.split != F3R_SPLIT_W2) { *why = "X3 split"; return false; }
+  if (a.split != F3R_SPLIT_NONE && a.split != F3R_SPLIT_W2 && a.split != F3R_SPLIT_W2F8) { *why = "X3 split"; return false; }
+  const bool f8 = a.split == F3R_SPLIT_W2F8;
+  if (f8 && (a.dtype != F3R_F16 || !a.w_scale || !a.W_aux || a.K % 128 != 0 || a.Kpad != a.K)) { *why = "W2F8 needs fp16, w_scale, W_aux, K = Kpad a multiple of 128"; return false; }
   const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
   const int Dkv = (a.N - Dq) / 2;
   if (Dq != Dkv) { *why = "grouped-query widths (q and k segments differ)"; return false; }
   if (Dq % 256 != 0 || a.M <= 0 || a.M % 256 != 0 || a.seq_len % 256 != 0) { *why = "D, M or seq_len not a multiple of 256"; return false; }
-  const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
+  const int Kpad1 = (a.split && !f8) ? a.Kpad / 2 : a.Kpad;
   if (a.K != Kpad1 || Kpad1 % 64 != 0 || a.Kpad / 64 < 4) { *why = "K tail or fewer than 4 K-tiles"; return false; }
   if ((((uintptr_t)a.q) & 15) || (((uintptr_t)a.k) & 15) || (((uintptr_t)a.vt) & 15) || (a.ldvt * 2) % 16 != 0) { *why = "outputs not 16-byte aligned"; return false; }
-  if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 2 >= (1ll << 32) || (int64_t)256 * a.ldvt * 2 >= (1ll << 32)) { *why = "row strides too large"; return false; }
+  if ((int64_t)256 * a.lda * 2 >= (1ll << 32) || (int64_t)256 * a.Kpad * 3 >= (1ll << 32) || (int64_t)256 * a.ldvt * 2 >= (1ll << 32)) { *why = "row strides too large"; return false; }
   if ((a.M / 256) * (int64_t)(a.N / 256) >= (1ll << 24)) { *why = "grid too large"; return false; }
   {
     const int64_t Dq256 = (a.qkv_dq ? a.qkv_dq : a.N / 3) / 256;
@@ -279,7 +281,7 @@ bool f3r_gemm_asm_qkv_eligible(const f3r_gemm_args& a, const char** why) {
       return false;
     }
   }
-  if (get_fn(ROLE_LP, a.dtype) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  if (get_fn(ROLE_LP, a.dtype) == nullptr || (f8 && get_fn(ROLE_LP, a.dtype, true) == nullptr)) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }
 
@@ -289,7 +291,8 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
     f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
     return F3R_ERR_LAUNCH;
   }
-  const int planes = a.split ? 2 : 1;
+  const bool f8 = a.split == F3R_SPLIT_W2F8;
+  const int planes = (a.split && !f8) ? 2 : 1;
   const int Kpad1 = a.Kpad / planes;
   const int D = a.qkv_dq ? a.qkv_dq : a.N / 3;
   f3r_gemm_asm_args k;
@@ -300,11 +303,24 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   k.bias = a.bias;
   k.out = a.q;
   k.lda_b = (uint32_t)(a.lda * 2);
-  k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
   k.ldo_b = (uint32_t)(D * 2);
-  k.nk1 = (uint32_t)(Kpad1 / 64);
-  k.nk = k.nk1 * (uint32_t)planes;
-  k.nk1_w = k.nk;
+  if (f8) {  // rows [K fp16 | K fp8] on both operands: K / 64 fp16 K-tiles, then K / 128 fp8 ones; neither stream wraps
+    hipFunction_t fn8 = get_fn(ROLE_LP, a.dtype, true);
+    if (!fn8) {
+      f3r_set_error("f3r_gemm: the embedded hand-scheduled kernel could not be loaded on this device");
+      return F3R_ERR_LAUNCH;
+    }
+    k.ldw_b = (uint32_t)((int64_t)a.K * 3);
+    k.nk8 = (uint32_t)(a.K / 128);
+    k.nk = (uint32_t)(a.K / 64) + k.nk8;
+    k.nk1 = k.nk1_w = k.nk;
+    k.w_scale = a.w_scale;
+  } else {
+    k.ldw_b = (uint32_t)((int64_t)a.Kpad * 2);
+    k.nk1 = (uint32_t)(Kpad1 / 64);
+    k.nk = k.nk1 * (uint32_t)planes;
+    k.nk1_w = k.nk;
+  }
   k.act = a.rope_cos ? ACT_ROPE : ACT_SCALE;
   k.scale = a.q_scale != 0.f ? a.q_scale : 1.0f;
   if (a.rope_cos) {
@@ -317,21 +333,22 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream) {
   }
   k.seg_stride = (int64_t)((const char*)a.k - (const char*)a.q);
   k.tps = (uint32_t)(D / 256);
-  int rc = launch_tiles(fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel == 9, ROLE_LP);
+  int rc = launch_tiles(f8 ? get_fn(ROLE_LP, a.dtype, true) : fn, k, a.M, 2 * (int64_t)D, stream, a.kernel_sel == 9, ROLE_LP);
   if (rc != F3R_OK) return rc;
-  // launch 2: V^T[seq][d][t] = W_v X^T
+  // launch 2: V^T[seq][d][t] = W_v X^T (W2F8: the v rows as two fp16 planes from W_aux, the activations' fp16 part)
   f3r_gemm_asm_args v;
   memset(&v, 0, sizeof(v));
-  v.A = (const char*)a.W + (int64_t)2 * D * a.Kpad * 2;
+  const int64_t kp_v = f8 ? (int64_t)2 * a.K : a.Kpad;   // elements per v weight row (both planes)
+  v.A = f8 ? a.W_aux : (const void*)((const char*)a.W + (int64_t)2 * D * a.Kpad * 2);
   v.W = a.A;
   v.bias = a.bias ? a.bias + 2 * D : nullptr;
   v.out = a.vt;
-  v.lda_b = (uint32_t)((int64_t)a.Kpad * 2);
+  v.lda_b = (uint32_t)(kp_v * 2);
   v.ldw_b = (uint32_t)(a.lda * 2);
   v.ldo_b = (uint32_t)(a.ldvt * 2);
-  v.nk = k.nk;
-  v.nk1 = k.nk;      // the weight planes follow each other in a row: that stream runs on
-  v.nk1_w = k.nk1;   // the activations wrap per K segment
+  v.nk = f8 ? (uint32_t)(2 * (a.K / 64)) : k.nk;
+  v.nk1 = v.nk;      // the weight planes follow each other in a row: that stream runs on
+  v.nk1_w = f8 ? (uint32_t)(a.K / 64) : k.nk1;   // the activations wrap per K segment
   v.act = 0;
   v.scale = 1.0f;
   v.flags = FLAG_BIAS_ON_M;

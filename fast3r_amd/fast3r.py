@@ -338,10 +338,11 @@ class PixelwiseTaskWithDPT(_Params):
 class _PackedBlock:
     __slots__ = ("n1w", "n1b", "n2w", "n2b", "eps", "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
                  "rms", "rope_mode", "swiglu_hidden", "q_dim", "kv_dim", "kv_group", "causal", "head_dim", "fc1_split",
-                 "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws")   # the MLP weights with their low plane in fp8 (Fast3R.low_plane = "fp8"), or None
+                 "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws",   # the MLP weights with their low plane in fp8 (Fast3R.low_plane = "fp8"), or None
+                 "qk_w8", "qk_ws", "v_w2")                 # ... and the q | k rows of the QKV weight; its v rows as two fp16 planes
 
     def __init__(self):
-        self.fc1_w8 = self.fc1_ws = self.fc2_w8 = self.fc2_ws = None
+        self.fc1_w8 = self.fc1_ws = self.fc2_w8 = self.fc2_ws = self.qk_w8 = self.qk_ws = self.v_w2 = None
         self.rms, self.rope_mode, self.swiglu_hidden = False, 0, 0
         self.fc1_split = None  # None: like every other projection of the block
         self.head_dim = 64  # the Fast3R fusion decoder may have another width (model_scaling_huge.yaml: 80)
@@ -372,6 +373,11 @@ def _pack_block(blk: _Block, lp, split=False, head_dim=64, fc1_split=None, f8=Fa
     if f8 and split and lp == torch.float16 and p.fc1_split and w1.shape[1] % 128 == 0 and w1.shape[0] % 256 == 0 and w2_.shape[0] % 256 == 0:
         p.fc1_w8, p.fc1_ws = ops.pack_linear_weight_f8(w1)
         p.fc2_w8, p.fc2_ws = ops.pack_linear_weight_f8(w2_)
+    wq = blk.attn.qkv.weight.detach().float()
+    Dm = wq.shape[0] // 3
+    if f8 and split and lp == torch.float16 and wq.shape[1] % 128 == 0 and Dm % 256 == 0 and head_dim == 64:
+        p.qk_w8, p.qk_ws = ops.pack_linear_weight_f8(wq[:2 * Dm])
+        p.v_w2 = ops.pack_linear_weight(wq[2 * Dm:], lp, True)
     return p
 
 
@@ -852,14 +858,23 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         T = x.shape[0]
         if ws is None:
             ws = self._block_ws(pb, T, D, n_seq, seq_len, x.device)
-        h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, out_lp=ws.h, rms=pb.rms)
         q = ws.q
         if kv_exchange is None:
             k, vt = ws.k, ws.vt
             ldvt = vt.shape[-1]
         else:  # view-sharded: write K / V^T straight into the (padded, persistent) send buffers of the exchange
             k, vt = kv_exchange.k_loc, kv_exchange.vt_loc
-        ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp, q_dim=pb.q_dim)
+        # the q | k launch with its low plane in fp8 (Fast3R.low_plane) where its 256 x 256 tiles fill the chip (from 8192 tokens on; the encoder's
+        # RoPE-2D rides in that launch's epilogue since round 5), V^T on two fp16 planes; sequences must be multiples of 256 tokens for the V^T tiles
+        f8_qkv = (pb.qk_w8 is not None and T % 256 == 0 and seq_len % 256 == 0 and pb.rope_mode == 0 and pb.q_dim == 0
+                  and (T // 256) * (pb.qk_w8.shape[0] // 256) >= 256)
+        if f8_qkv:
+            rows1 = ops.layernorm_f8(x, pb.n1w, pb.n1b, pb.eps, out_rows=ws.rows8(D), rms=pb.rms)
+            ops.gemm_qkv(rows1, pb.qk_w8, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, split="w2f8", w_scale=pb.qk_ws, w_aux=pb.v_w2)
+            h = ws.h
+        else:
+            h, _ = ops.layernorm(x, pb.n1w, pb.n1b, pb.eps, lp, out_lp=ws.h, rms=pb.rms)
+            ops.gemm_qkv(h, pb.qkv_w, pb.qkv_b, q, k, vt, seq_len, rope, q_scale=scale * ops.LOG2E, rope_mode=pb.rope_mode, split=sp, q_dim=pb.q_dim)
         if kv_tap is not None and kv_exchange is None:
             kv_tap(k, vt)  # the K / V^T of this fusion layer (capture for the per-rank emulation test)
         o = h  # LN output is dead: reuse as the attention output buffer

@@ -278,18 +278,28 @@ def vt_ld(seq_len: int) -> int:
 LOG2E = 1.4426950408889634
 
 
-def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0, split=None, a_lo=None, kernel_sel=0, q_dim=0):
+def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0, split=None, a_lo=None, kernel_sel=0, q_dim=0, w_scale=None, w_aux=None):
     """QKV projection with the attention-layout epilogue: q -> [M][Dq], k -> [M][Dkv] (optionally RoPE'd), v -> vt[M/seq][Dkv][ldvt]
     (Dq = Dkv = N/3 unless q_dim is given: grouped-query attention).
     rope = (cos, sin, tokens_per_row) or None; rope_mode 0 = RoPE-2D tables [n_pos][16], 1 = per-row-group tables [n_groups][32]
-    (rope[2] = rows per group; see f3r_gemm_args.rope_mode).  vt must be zero-initialised once (its padding is never written)."""
+    (rope[2] = rows per group; see f3r_gemm_args.rope_mode).  vt must be zero-initialised once (its padding is never written).
+    split "w2f8": a = rows [K fp16 | K fp8] (layernorm_f8); w / w_scale = pack_linear_weight_f8 of the q and k rows; w_aux = the v rows packed
+    with pack_linear_weight(split=True) (f3r_gemm_args.W_aux: the V^T launch runs on two fp16 planes)."""
     require_gpu(a, "a")
     lp = a.dtype
     M = a.shape[0]
     N, Kpad = w.shape
+    K = a.shape[1]
+    if split == "w2f8":
+        assert w_scale is not None and w_aux is not None and lp == torch.float16 and w_aux.dtype == lp
+        K = Kpad = 2 * w.shape[1] // 3
+        N = w.shape[0] + w_aux.shape[0]
+        assert w_aux.shape[1] == 2 * K and a.shape[1] * 2 >= 3 * K and w_scale.numel() == w.shape[0]
     g = GemmArgs()
     g.A, g.W, g.bias = ptr(a), ptr(w), ptr(bias)
-    g.M, g.N, g.K, g.Kpad, g.lda = M, N, a.shape[1], Kpad, a.stride(0)
+    g.M, g.N, g.K, g.Kpad, g.lda = M, N, K, Kpad, a.stride(0)
+    if split == "w2f8":
+        g.w_scale, g.W_aux = ptr(w_scale), ptr(w_aux)
     g.a_mode, g.epi, g.act = F3R_A_PLAIN, F3R_EPI_QKV, F3R_ACT_NONE
     g.q, g.k, g.vt = ptr(q), ptr(k), ptr(vt)
     g.seq_len, g.ldvt = seq_len, vt.stride(-2)

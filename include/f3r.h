@@ -175,6 +175,10 @@ typedef struct f3r_gemm_args {
      W2F8 GEMM (fc1 -> fc2 of a transformer MLP, blocks.py:94-105) */
   int32_t out_lp_f8;
   const uint32_t* w_scale; /* F3R_SPLIT_W2F8: [N] scale words of the weight rows' fp8 plane (see f3r_split); NULL otherwise (ABI 330) */
+  /* F3R_EPI_QKV with F3R_SPLIT_W2F8 (ABI 330): W / w_scale hold the q and k rows only ([N - Dkv] rows of [K fp16 | K fp8]); the v rows come as TWO
+     fp16 planes here ([Dkv][2 K], as F3R_SPLIT_W2 packs them): the V^T launch runs with swapped operand roles on the fp16 kernel (its "weights"
+     are the activations).  NULL otherwise. */
+  const void* W_aux;
 } f3r_gemm_args;
 
 /* F3R_SPLIT_W2F8 (ABI 330): W2 with the LOW plane of the weights, and the copy of the activations it multiplies, in fp8 (OCP e4m3) on the

@@ -288,3 +288,57 @@ def test_mlp_chain_on_fp8_rows(built_lib):
     ops.gemm(hid, w2p.to(DEV), bias=b2.to(DEV), res_f32=out, out_f32=out, split="w2f8", w_scale=w2s.to(DEV))
     ref = x.double() + h16.double().cpu() @ w2.double().t() + b2.double()
     assert_close(out, ref, 3e-5, "fc2 + residual on fp8 rows")
+
+
+@pytest.mark.parametrize("n_seq,S,D,K,rope_w", [(2, 768, 256, 256, 0), (3, 512, 512, 384, 16), (1, 70 * 256, 1024, 1024, 0), (20, 1024, 1024, 1024, 32)])
+def test_gemm_asm_qkv_fp8_low_plane(built_lib, n_seq, S, D, K, rope_w):
+    """F3R_EPI_QKV with F3R_SPLIT_W2F8 (round 5): the q | k launch reads rows [K fp16 | K fp8] of both operands (block-scaled fp8 MFMA for the
+    weight-correction product; RoPE-2D of the encoder in its epilogue), the V^T launch runs with swapped roles on two fp16 planes (W_aux).
+    Reference: fp64 on exactly those planes."""
+    M = n_seq * S
+    g = torch.Generator().manual_seed(31 + K)
+    a32 = torch.randn((M, K), generator=g) * 2.0
+    w32 = torch.randn((3 * D, K), generator=g) * K ** -0.5
+    bias = torch.randn(3 * D, generator=g) * 0.3
+    a16 = a32.to(torch.float16)
+    a8 = a16.float().clamp(-448, 448).to(torch.float8_e4m3fn)
+    rows = torch.empty((M, 3 * K), dtype=torch.uint8)
+    rows[:, :2 * K] = a16.contiguous().view(torch.uint8).view(M, 2 * K)
+    rows[:, 2 * K:] = a8.view(torch.uint8)
+    rows = rows.view(torch.float16).view(M, 3 * K // 2)
+    qk8, qks = ops.pack_linear_weight_f8(w32[:2 * D])
+    v2 = ops.pack_linear_weight(w32[2 * D:], torch.float16, True)
+    wb = qk8.view(torch.uint8).view(2 * D, 3 * K)
+    w_hi = wb[:, :2 * K].contiguous().view(torch.float16).view(2 * D, K).double()
+    w_lo = wb[:, 2 * K:].contiguous().view(torch.float8_e4m3fn).double() * torch.exp2((qks & 0xFF).double() - 127.0)[:, None]
+    ref_qk = a16.double() @ w_hi.t() + a8.double() @ w_lo.t() + bias[:2 * D].double()
+    ref_v = a16.double() @ (v2[:, :K].double() + v2[:, K:].double()).t() + bias[2 * D:].double()
+    qs = 0.160192 * ops.LOG2E
+    rope = None
+    if rope_w:
+        n_pos = max(rope_w, -(-S // rope_w))
+        cos, sin = ops.rope_tables(n_pos, 100.0, DEV)
+        rope = (cos, sin, rope_w)
+        pos = torch.arange(M) % S
+        py, px = pos // rope_w, pos % rope_w
+        c64, s64 = cos.double().cpu(), sin.double().cpu()
+
+        def rot(x):
+            out = x.clone()
+            for h0 in range(0, D, 64):
+                for half, p in ((0, py), (1, px)):
+                    a_, b_ = x[:, h0 + 32 * half:h0 + 32 * half + 16], x[:, h0 + 32 * half + 16:h0 + 32 * half + 32]
+                    out[:, h0 + 32 * half:h0 + 32 * half + 16] = a_ * c64[p] - b_ * s64[p]
+                    out[:, h0 + 32 * half + 16:h0 + 32 * half + 32] = b_ * c64[p] + a_ * s64[p]
+            return out
+        ref_qk = torch.cat([rot(ref_qk[:, :D]), rot(ref_qk[:, D:])], 1)
+    q = torch.zeros((M, D), dtype=torch.float16, device=DEV)
+    k = torch.zeros((M, D), dtype=torch.float16, device=DEV)
+    ld = ops.vt_ld(S) + 64
+    vt = torch.zeros((n_seq, D, ld), dtype=torch.float16, device=DEV)
+    ops.gemm_qkv(rows.to(DEV), qk8.to(DEV), bias.to(DEV), q, k, vt, S, rope, q_scale=qs, split="w2f8", w_scale=qks.to(DEV), w_aux=v2.to(DEV))
+    assert_close(q.float(), ref_qk[:, :D] * qs, lp_tol(torch.float16), "q (fp8 low plane)")
+    assert_close(k.float(), ref_qk[:, D:], lp_tol(torch.float16), "k (fp8 low plane)")
+    got_v = vt[:, :, :S].float().cpu().permute(0, 2, 1).reshape(M, D)
+    assert_close(got_v, ref_v, lp_tol(torch.float16), "v^T (two fp16 planes)")
+    assert float(vt[:, :, S:].float().abs().sum()) == 0.0

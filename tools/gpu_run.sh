@@ -188,6 +188,17 @@ for k, x in dur.items():
 json.dump(out, open(f"{d}/gemm_asm_f8_pmc.json", "w"), indent=1)
 PY
       find $d/pmc -name "*kernel_trace.csv" -delete ;;
+    qkvasm)     # QKV on the hand-scheduled kernel: RoPE-2D epilogue + fp8 low plane (tests), then the model parity at depth and the bench A/B vs low_plane fp16
+      timeout 900 python -m pytest tests/test_gemm_asm_gpu.py -q -x -s -p no:cacheprovider -k "qkv" 2>&1 | tail -30 > $d/pytest.log; grep -E "passed|failed|Error|assert|^E " $d/pytest.log | tail -12
+      timeout 900 python -m pytest tests/test_depth_parity_gpu.py tests/test_e2e_gpu.py -q -s -p no:cacheprovider -k "stress_weights_vs_cpu_oracle or n100_stress or vit_large_512_n8 or sharded_forward_equals_unsharded" > $d/pytest_full.log 2>&1; grep -E "\[parity\]|passed|failed|^E " $d/pytest_full.log | sed 's/^[.sF]*//' | cut -c1-260 > $d/parity_lines.txt; cat $d/parity_lines.txt; tail -40 $d/pytest_full.log > $d/pytest2.log; rm -f $d/pytest_full.log
+      timeout 600 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-hot --no-inference > $d/bench_fp8.json 2> $d/err.log; python - $d/bench_fp8.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+r = lambda x, n=2: None if x is None else round(x, n)
+print(sys.argv[1], "N=320:", r(d.get("value")), "views/s", r(d.get("ms_per_step"), 1), "ms; attn frac", r(d.get("roofline", {}).get("frac"), 4), "| n100:", r(d.get("n100", {}).get("value")),
+      "views/s | n20 fusion:", r(d.get("fusion_only_n20", {}).get("value"), 1), "| error:", d.get("error"), d.get("n100", {}).get("error"))
+PY
+      ;;
     steal)      # the fusion attention with and without work stealing, interleaved rounds, N = 320 and N = 100 (tools/kernel_bench.py --what attnsteal)
       timeout 600 python tools/kernel_bench.py --what attnsteal --views ${STEAL_VIEWS:-320,100,20} > $d/attn_work_stealing.jsonl 2> $d/err.log; cat $d/attn_work_stealing.jsonl | cut -c1-400; tail -3 $d/err.log ;;
     gpuslow)    # the GPU tests kept out of -m gpu (conftest.py: gpu_slow)
