@@ -1,6 +1,7 @@
 """CPU tests of the host side: state_dict layout, image-id RNG recipe, weight packing layouts (checked by emulating
 the kernels' index maps with torch on CPU), collate / inference plumbing, error behaviour without a GPU."""
 import copy
+import time
 import warnings
 
 import pytest
@@ -310,3 +311,63 @@ def test_a_missing_or_stale_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "ABI_VERSION", real.f3r_version() + 1)
     with pytest.raises(F3RError, match="rebuild"):
         _lib.lib()
+
+
+def test_fp8_low_plane_weight_pack_on_cpu():
+    """ops.pack_linear_weight_f8 (f3r.h F3R_SPLIT_W2F8): rows [K fp16 hi | K fp8 e4m3((W - hi) 2^s_n)] + one E8M0 word per output channel; decoding the
+    planes recovers the weight ~16x closer than one fp16 plane, whatever the row's scale; no NaN code is ever produced"""
+    from fast3r_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn((512, 256), generator=g) * 0.05 * torch.exp2(torch.randint(-8, 4, (512, 1), generator=g).float())
+    w[7] = 0.0   # an all-zero row must not break the scale search
+    p, s = ops.pack_linear_weight_f8(w)
+    assert p.shape == (512, 384) and p.dtype == torch.float16 and s.shape == (512,) and s.dtype == torch.int32
+    raw = p.view(torch.uint8).view(512, 768)
+    hi = raw[:, :512].contiguous().view(torch.float16).view(512, 256).double()
+    lo_b = raw[:, 512:].contiguous()
+    assert not ((lo_b & 0x7F) == 0x7F).any()
+    e = (s & 0xFF).double() - 127.0
+    assert torch.equal(s & 0xFF, (s >> 8) & 0xFF) and torch.equal(s & 0xFF, (s >> 24) & 0xFF)   # the byte in every position of the word
+    rec = hi + lo_b.view(torch.float8_e4m3fn).double() * torch.exp2(e)[:, None]
+    rows = w.abs().amax(1) > 0
+    err8 = ((rec - w.double()).abs().amax(1) / w.abs().amax(1).clamp_min(1e-30))[rows]
+    err1 = ((hi - w.double()).abs().amax(1) / w.abs().amax(1).clamp_min(1e-30))[rows]
+    assert float(err8.max()) <= 2.0 ** -14 and float((err8 / err1.clamp_min(1e-12)).median()) <= 1 / 12
+    assert torch.equal(rec[7], torch.zeros(256, dtype=torch.float64))
+    with pytest.raises(AssertionError):
+        ops.pack_linear_weight_f8(torch.randn(256, 192))   # K must be a multiple of 128
+
+
+def test_bench_live_roofline_arithmetic():
+    """bench.live_roofline turns the attention kernel's own counters (f3r_attn_args.dbg_counters, ABI 330) into utilisation / clock / implied rate:
+    checked on counters constructed for a known answer (head_dim 64: 64 MFMAs of 32 cycles per 64-key tile and wave)"""
+    import bench
+    from fast3r_amd import _lib
+    waves, tiles_per_wave = 4096, 5120
+    cycles_per_wave = int(32 * 64 * tiles_per_wave / 0.75)        # utilisation 0.75 by construction
+    ticks_per_wave = int(cycles_per_wave / 1.7e9 * 1e8)            # 1.7 GHz shader clock against the 100 MHz constant clock
+    per_xcd = [[cycles_per_wave * waves // 8, ticks_per_wave * waves // 8 * (1.04 if x == 3 else 1.0), waves // 8] for x in range(8)]
+    counters = [waves + 7, waves, tiles_per_wave * waves, cycles_per_wave * waves, ticks_per_wave * waves, per_xcd]
+    saved = _lib.lib
+    _lib.lib = lambda: type("L", (), {"f3r_wall_clock_khz": staticmethod(lambda: 100000)})()
+    try:
+        live = bench.live_roofline(counters, avg_launch_ms=300.0, achieved_tflops=1300.0, head_dim=64, power={"source": None})
+    finally:
+        _lib.lib = saved
+    assert abs(live["mfma_util_cycles"] - 0.75) < 1e-3 and abs(live["effective_clock_ghz"] - 1.7) < 2e-3
+    assert abs(live["implied_tflops"] - 0.75 * 1.7 * 256 * 4 * 1024 / 1e3) < 2.0
+    assert abs(live["achieved_over_implied"] - 1300.0 / live["implied_tflops"]) < 1e-9
+    assert abs(live["per_xcd"]["slowest_over_mean"] - 1.04 / (1 + 0.04 / 8)) < 1e-3 and live["per_xcd"]["waves"] == [waves // 8] * 8
+    empty = bench.live_roofline([0, 0, 0, 0, 0, [[0, 0, 0]] * 8], 1.0, 1.0, 64, {"source": None})
+    assert "note" in empty
+
+
+def test_bench_power_sampler_never_raises_without_a_gpu():
+    """the 2 Hz sampler of bench.py (amdsmi, else rocm-smi --json): on a box with neither it reports source None and an error text, and costs nothing"""
+    import bench
+    s = bench.PowerSampler(0, period=0.05)
+    with s:
+        time.sleep(0.2)
+    out = s.summary()
+    assert set(out) >= {"source", "samples", "power_w_mean", "sclk_mhz_mean", "error"}
+    assert out["samples"] == 0 or out["source"] in ("amdsmi", "rocm-smi")
