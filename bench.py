@@ -293,7 +293,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout, **kw)
         # (three times the data plane's timeout: a rank that failed at once waits here for the ranks that first have to run into theirs)
-        ctl["group"] = dist.new_group(backend="gloo", timeout=3 * pg_timeout + datetime.timedelta(seconds=30))
+        # Single node, rendezvous on 127.0.0.1: let gloo use the loopback interface instead of resolving the host name (which a container
+        # may not be able to do).  A control group that cannot be made is not fatal: flags and timings then travel over the data-plane group.
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            ctl["group"] = dist.new_group(backend="gloo", timeout=3 * pg_timeout + datetime.timedelta(seconds=30))
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] no gloo control group ({type(exc).__name__}: {exc}): using the default process group for control traffic", file=sys.stderr, flush=True)
+            ctl["group"] = None
 
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -331,8 +339,9 @@ def main():
         """[x of rank 0, x of rank 1, ...] over the gloo control group (a list of one without ranks)"""
         if not distributed:
             return [float(x)]
-        out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(out, torch.tensor([float(x)], dtype=torch.float64), group=ctl["group"])
+        cdev = torch.device("cpu") if (ctl["group"] is not None or dry) else dev   # (without the gloo group: device tensors over RCCL)
+        out = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([float(x)], dtype=torch.float64, device=cdev), group=ctl["group"])
         return [float(t.item()) for t in out]
 
     def shutdown():
