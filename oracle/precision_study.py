@@ -221,6 +221,56 @@ def main():
             print(f"{dist:8s} tr={tr:6s} hd={hd:11s} attn={attn}: " + "  ".join(f"{k.replace('pts3d_', 'p_')}={v:.2e}" for k, v in worst.items()), flush=True)
 
 
+STUDIES = {
+    # round 5.  Each entry: (weight distribution, [(label, transformer mode, head mode, attention formats, per-role overrides, per-conv overrides)])
+    "heads": ("hot", [   # can the last convolutions of the DPT head (29 = head.0, 30 = head.2: 2/3 of the heads' FLOPs) carry fewer planes?  -> no
+        ("x3 everywhere (the product)", "f16w2", "f16x3", None, None, {}),
+        ("head.0 single fp16", "f16w2", "f16x3", None, None, {29: "f16"}), ("head.2 single fp16", "f16w2", "f16x3", None, None, {30: "f16"}),
+        ("head.0 + head.2 single fp16", "f16w2", "f16x3", None, None, {29: "f16", 30: "f16"}),
+        ("head.0 + head.2 activations split only", "f16w2", "f16x3", None, None, {29: "f16x2", 30: "f16x2"}),
+        ("head.0 + head.2 weights split only", "f16w2", "f16x3", None, None, {29: "f16w2", 30: "f16w2"}),
+        ("every conv: activations split only", "f16w2", "f16x3", None, None, {i: "f16x2" for i in range(32)})]),
+    "fp8": ("hot", [     # the weight-correction product of the transformer's linear layers from fp8 operands (Fast3R.low_plane = "fp8")
+        ("w2 everywhere (two fp16 planes)", "f16w2", "f16x3", None, None, {}), ("low plane in fp8 everywhere", "f16w2_8", "f16x3", None, None, {}),
+        ("low plane in fp8 on qkv + fc1 + fc2 (the product)", "f16w2", "f16x3", None, {"qkv": "f16w2_8", "fc1": "f16w2_8", "fc2": "f16w2_8"}, {}),
+        ("single fp16 plane (precision fast)", "f16", "f16x3", None, None, {})]),
+    "heavy": ("heavy", [  # Student-t weights + LayerNorm gains in [0.2, 5]: which 16-bit rounding site is to blame?  -> every one of them alone
+        ("the product: tr w2, attention fp16, heads x3", "f16w2", "f16x3", None, None, {}),
+        ("attention operands exact, rest as the product", "f16w2", "f16x3", {"qk": "f32", "pv": "f32"}, None, {}),
+        ("q k^T exact only", "f16w2", "f16x3", {"qk": "f32", "pv": "f16"}, None, {}), ("p v exact only", "f16w2", "f16x3", {"qk": "f16", "pv": "f32"}, None, {}),
+        ("linear layers x3, attention fp16", "f16x3", "f16x3", None, None, {}), ("linear layers x3 AND attention exact", "f16x3", "f16x3", {"qk": "f32", "pv": "f32"}, None, {}),
+        ("transformer exact, attention fp16, heads x3", "f32", "f16x3", None, None, {}), ("heads exact, rest as the product", "f16w2", "f32", None, None, {}),
+        ("precision fast", "f16", "f16", None, None, {})]),
+}
+
+
+def study(name):
+    """python oracle/precision_study.py --study heads | fp8 | heavy  (the round-5 questions; results: profiles/r05_precision_study_*.txt)"""
+    from fast3r_amd import Fast3R
+    dist, cases = STUDIES[name]
+    args = tiny_args()
+    shp = {k: tuple(v.shape) for k, v in Fast3R(*args).state_dict().items()}
+    sd = synth_state_dict(shp, 0, dist)
+    views = make_views(3, 64, 64)
+    torch.manual_seed(1234)
+    ref = O.forward(views, sd, *args)
+    for label, tr, hd, attn, roles, convs in cases:
+        out = run_design(views, sd, args, tr, hd, attn or {"qk": "f16", "pv": "f16"}, roles=roles, conv_roles=convs)
+        worst = {}
+        for o, r in zip(out, ref):
+            for k in r:
+                worst[k] = max(worst.get(k, 0.0), O.rel_l2(o[k], r[k]))
+        print(f"{dist:8s} {label:52s} " + "  ".join(f"{k.replace('pts3d_', 'p_')}={v:.2e}" for k, v in worst.items()), flush=True)
+
+
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--study", default="", choices=[""] + sorted(STUDIES))
+    a = ap.parse_args()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     with torch.no_grad():
-        main()
+        if a.study:
+            study(a.study)
+        else:
+            main()
