@@ -749,14 +749,21 @@ def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
     clock_ghz = cycles / (ticks / (khz * 1e3)) / 1e9
     util = 32.0 * mfma_per_tile * tiles / cycles
     implied = util * clock_ghz * 256 * 4 * 1024 / 1e3   # TFLOP/s
-    # per XCD: workgroup ids are dealt round-robin over the 8 XCDs (equal work each), so the launch lasts as long as the slowest XCD needs
+    # per XCD: with one item per workgroup id the ids are dealt round-robin over the 8 XCDs (equal work each) and the launch lasts as long as the
+    # slowest XCD needs; with work stealing (f3r_attn_args.sched_counter) an XCD takes items as fast as its clock lets it, and the XCDs' busy
+    # times (the tick sums) come out equal instead of their wave counts
     xcd = None
     if all(w > 0 and t > 0 for _, t, w in per_xcd):
         mean_us = [t / w / (khz * 1e3) * 1e6 for _, t, w in per_xcd]
+        busy = [t for _, t, _ in per_xcd]
+        stealing = len({w for _, _, w in per_xcd}) > 1
         xcd = {"wave_time_us_mean": mean_us, "clock_ghz": [c / (t / (khz * 1e3)) / 1e9 for c, t, _ in per_xcd], "waves": [w for _, _, w in per_xcd],
-               "slowest_over_mean": max(mean_us) / (sum(mean_us) / 8),
-               "note": "equal work per XCD (static round-robin of workgroup ids): the slowest XCD bounds the launch; achieved_over_implied below "
-                       "1 / slowest_over_mean is idle time inside the XCDs (tail of the last round, dispatch gaps)"}
+               "slowest_over_mean": max(mean_us) / (sum(mean_us) / 8), "busiest_over_mean": max(busy) / (sum(busy) / 8),
+               "dealing": "work stealing" if stealing else "static",
+               "note": ("work stealing: persistent workgroups take items from one counter, so a faster XCD walks more of them (waves) and the busy "
+                        "times (wave time x waves) are level: busiest_over_mean, not slowest_over_mean, is what bounds the launch" if stealing else
+                        "equal work per XCD (static round-robin of workgroup ids): the slowest XCD bounds the launch; achieved_over_implied below "
+                        "1 / slowest_over_mean is idle time inside the XCDs (tail of the last round, dispatch gaps)")}
     return {"source": "s_memtime / s_memrealtime brackets + tile counts written by every wave of the timed launches (f3r_attn_args.dbg_counters)",
             "effective_clock_ghz": clock_ghz, "mfma_util_cycles": util, "cycles_per_launch": avg_launch_ms * 1e-3 * clock_ghz * 1e9,
             "wave_cycles_mean": cycles / waves, "waves": waves, "mfma_per_wave_mean": mfma_per_tile * tiles / waves, "wall_clock_khz": khz,

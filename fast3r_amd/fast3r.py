@@ -15,7 +15,6 @@ residual stream, LayerNorm statistics, softmax and post-processing are fp32; GEM
 """
 import math
 import time
-import warnings
 from collections import OrderedDict
 from copy import deepcopy
 

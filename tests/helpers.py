@@ -1,5 +1,4 @@
 """Shared test helpers: fixture loading, model construction from a golden fixture, comparators."""
-import copy
 import os
 
 import torch

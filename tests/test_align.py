@@ -6,7 +6,6 @@ SVD) and the HIP path (raw fp64 moments + Jacobi SVD) are checked, on exact, noi
 properties of the oracle (CPU, below) and HIP path == oracle on the same inputs (GPU): quantile thresholds bit-exact vs
 torch.quantile, transforms / points to fp32 noise."""
 import ctypes
-import math
 
 import pytest
 import torch

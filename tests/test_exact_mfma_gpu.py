@@ -2,7 +2,6 @@
 16-bit planes, every product as three MFMAs, fp32 softmax) against the FMA-pipe kernel it stands in for at large key counts (f3r_attn_f32_ex,
 the reference implementation of the mode) and against float64 -- same inputs, through the C ABI.  Bar: 3e-6 rel-L2 (the mode's own distance to
 the reference's fp32 path is ~1e-6 on fixtures, 7.7e-6 through 48 ViT-L blocks)."""
-import math
 
 import pytest
 import torch

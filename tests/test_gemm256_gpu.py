@@ -7,7 +7,6 @@ multiples of 128 and the launches whose 256 x 256 tiles would leave CUs idle): a
 shapes include ragged M / N, every epilogue the model uses on this path, and K-tile counts that are odd (the loop runs two tiles per
 iteration) and minimal (one tile).
 """
-import math
 
 import pytest
 import torch

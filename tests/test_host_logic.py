@@ -358,6 +358,17 @@ def test_bench_live_roofline_arithmetic():
     assert abs(live["implied_tflops"] - 0.75 * 1.7 * 256 * 4 * 1024 / 1e3) < 2.0
     assert abs(live["achieved_over_implied"] - 1300.0 / live["implied_tflops"]) < 1e-9
     assert abs(live["per_xcd"]["slowest_over_mean"] - 1.04 / (1 + 0.04 / 8)) < 1e-3 and live["per_xcd"]["waves"] == [waves // 8] * 8
+    assert live["per_xcd"]["dealing"] == "static" and abs(live["per_xcd"]["busiest_over_mean"] - live["per_xcd"]["slowest_over_mean"]) < 1e-9
+    # work stealing: the slow XCD (x = 3: 4 % longer waves) takes 4 % fewer items, the busy times are level
+    for x in range(8):
+        w = int(round(waves // 8 / (1.04 if x == 3 else 1.0)))
+        per_xcd[x] = [cycles_per_wave * w, ticks_per_wave * w * (1.04 if x == 3 else 1.0), w]
+    _lib.lib = lambda: type("L", (), {"f3r_wall_clock_khz": staticmethod(lambda: 100000)})()
+    try:
+        live = bench.live_roofline(counters, avg_launch_ms=300.0, achieved_tflops=1300.0, head_dim=64, power={"source": None})
+    finally:
+        _lib.lib = saved
+    assert live["per_xcd"]["dealing"] == "work stealing" and live["per_xcd"]["busiest_over_mean"] < 1.003 < 1.03 < live["per_xcd"]["slowest_over_mean"]
     empty = bench.live_roofline([0, 0, 0, 0, 0, [[0, 0, 0]] * 8], 1.0, 1.0, 64, {"source": None})
     assert "note" in empty
 

@@ -16,7 +16,7 @@ import sys
 import os
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fast3r_amd", "csrc", "asm"))
-from isa import Ins, Label, LabelRef, Lit, Neg, Reg, Special  # noqa: E402
+from isa import Label, LabelRef, Lit, Neg, Reg, Special  # noqa: E402
 
 POISON = np.uint32(0x7FC0DEAD)
 MASK64 = (1 << 64) - 1
