@@ -225,6 +225,20 @@ def fail_line(fd, args, world, ranks_seen, exchange_state, exc):
     os.write(fd, (json.dumps(out) + "\n").encode())
 
 
+def first_to_fail():
+    """True for exactly one rank of a job whose ranks fail before they can talk to each other (the ranks of one launcher share its pid as
+    parent): that rank prints the line."""
+    run_id = "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:40]
+    path = f"/tmp/f3r_bench_fail_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{run_id}"
+    try:
+        os.close(os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600))
+        return True
+    except FileExistsError:
+        return False
+    except OSError:
+        return int(os.environ.get("RANK", "0")) == 0
+
+
 def flops_forward(V, P=1024, D=1024, L_enc=24, L_dec=24, heads=2):
     """Algorithmic FLOPs of one forward pass at 512x512: GEMMs 2mnk, attention 4 T^2 D per layer, DPT heads."""
     T = V * P
@@ -278,6 +292,8 @@ def main():
     import datetime
     pg_timeout = datetime.timedelta(seconds=float(os.environ.get("F3R_BENCH_PG_TIMEOUT_S", "300")))
     wd_seconds = float(os.environ.get("F3R_BENCH_WATCHDOG_S", "120"))
+    exchange_state = {"requested": args.exchange, "in_use": args.exchange, "fallback_reason": None}
+    ranks_seen = 1
     ctl = {"group": None}   # gloo control plane beside RCCL: failure flags and per-rank timings travel here, so a broken communicator cannot hide them
 
     def init_groups(attempt=0):
@@ -312,8 +328,20 @@ def main():
         if world > 1 and not dry:   # the first multi-GPU run must explain itself if it stalls: RCCL's own log per rank, read back by the watchdog
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/f3r_bench_rccl_rank{rank}_%p.log")
-        with Watchdog("process-group start-up + first collective", wd_seconds, rank):
-            init_groups()
+        try:
+            with Watchdog("process-group start-up + first collective", wd_seconds, rank):
+                if os.environ.get("F3R_BENCH_INJECT_FAULT") == f"{rank}:startup":
+                    raise RuntimeError("injected fault (F3R_BENCH_INJECT_FAULT=%d:startup)" % rank)
+                init_groups()
+                t = torch.ones(1, dtype=torch.float64, device=dev)   # every rank adds 1: the sum is the number of ranks that really took part in a collective
+                dist.all_reduce(t)
+                ranks_seen = int(t.item())
+        except Exception as exc:  # noqa: BLE001  -- a job that cannot even start still ends with ONE line (printed by whichever rank failed first:
+            import traceback        # rank 0 may be the one that is stuck) and a non-zero exit code
+            traceback.print_exc(file=sys.stderr)
+            if first_to_fail():
+                fail_line(real_stdout, args, world, ranks_seen, exchange_state, RuntimeError(f"rank {rank} at start-up: {type(exc).__name__}: {exc}"))
+            os._exit(1)
 
     V = args.views
     emu = args.emulate_rank is not None
@@ -364,8 +392,6 @@ def main():
             print(f"[bench] destroy_process_group: {exc}", file=sys.stderr)
         t.cancel()
 
-    exchange_state = {"requested": args.exchange, "in_use": args.exchange, "fallback_reason": None}
-
     def with_exchange_fallback(setup_and_warm):
         """setup_and_warm(exchange) builds the sharded path with that exchange form and runs the warm-up steps.  An exception on ANY rank
         (also: a collective that ran into the process-group timeout) is agreed on through the gloo control group; if the form was "auto" or
@@ -404,12 +430,6 @@ def main():
                 print(f"[bench] destroy_process_group: {exc}", file=sys.stderr)
             with Watchdog("process-group restart for the allgather retry", wd_seconds, rank):
                 init_groups(attempt + 1)
-
-    ranks_seen = 1
-    if distributed:  # every rank adds 1: the sum is the number of ranks that really took part in a collective
-        t = torch.ones(1, dtype=torch.float64, device=dev)
-        dist.all_reduce(t)
-        ranks_seen = int(t.item())
 
     if dry:
         # launcher / plumbing check only: no kernels (the product path has no CPU fallback), no measurement claimed.  The exchange fallback is

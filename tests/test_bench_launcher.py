@@ -75,3 +75,10 @@ def test_the_watchdog_reports_a_stall_without_killing_the_run():
     """a warm-up that outlives F3R_BENCH_WATCHDOG_S gets its Python stacks dumped to stderr; the run itself goes on"""
     out = _run(["--views", "3", "--steps", "1", "--warmup", "0"], {"F3R_BENCH_WATCHDOG_S": "0.0"})
     assert out["n_gpus"] == 1   # (a zero-second watchdog may or may not fire before the block ends: the run must be unaffected either way)
+
+
+def test_a_rank_that_cannot_start_its_process_group_still_ends_the_job_with_one_line():
+    """the failure nobody can agree on over a control group, because there is none yet: rank 1 dies before init_process_group.  It prints the line
+    itself (first_to_fail: one rank per launcher), the launcher ends the other rank, the exit code is non-zero"""
+    out = _run(["--gpus", "2", "--views", "6", "--steps", "1", "--warmup", "1"], {"F3R_BENCH_INJECT_FAULT": "1:startup", "F3R_BENCH_PG_TIMEOUT_S": "8"}, expect_rc0=False)
+    assert out["value"] is None and "rank 1 at start-up" in out["error"] and "injected fault" in out["error"] and out["n_gpus"] == 2
