@@ -407,6 +407,13 @@ if __name__ == "__main__":
             bench_gemm(dt, M, 1024, 4096, f"fc2+res M={M}", res=True, sels=(1, 2, 4))
             bench_gemm(dt, M, 4096, 1024, f"fc1+gelu M={M}", act="gelu", out="lp", sels=(1, 2, 4))
         sys.exit(0)
+    if args.what == "gemmsmallw2":  # the same question for the product's W2 launches, with the hand-scheduled kernel (6) in the field: automatic (0) should be the fastest
+        for M in [int(v) * 1024 for v in args.views.split(",")]:
+            for sels in ((0, 6, 2, 4, 1),):
+                bench_gemm(torch.float16, M, 1024, 1024, f"proj+res M={M}", res=True, sels=sels, split="w2")
+                bench_gemm(torch.float16, M, 1024, 4096, f"fc2+res M={M}", res=True, sels=sels, split="w2")
+                bench_gemm(torch.float16, M, 4096, 1024, f"fc1+gelu M={M}", act="gelu", out="lp", sels=sels, split="w2")
+        sys.exit(0)
     if args.what == "attnproduct":
         for nv in [int(v) for v in args.views.split(",")]:
             for d in (args.attn_dtypes.split(",")):
