@@ -687,12 +687,20 @@ def main():
     # format that meets the 1e-3 parity bar on the stress fixture; bf16 / "fast" is the round-1 headline format (parity 2e-2 there).
     alt_fmt = ("bf16", "fast") if (args.dtype, args.precision) != ("bf16", "fast") else ("fp16", "high")
     # (bounded: at most 3 timed steps after at most 1 warm-up, whatever --steps / --warmup ask of the main measurement)
-    alt_res = None if args.no_alt else measure(*alt_fmt, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+    # (an extra like the ones below: never at the price of the headline line.  With ranks, a failed extra leaves the communicators in an unknown
+    # state, so the remaining extras are skipped)
+    alt_res, extras_ok = None, True
+    if not args.no_alt:
+        try:
+            alt_res = measure(*alt_fmt, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+        except Exception as exc:  # noqa: BLE001
+            print(f"alt-format measurement failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+            extras_ok = not distributed
 
     # The dominant kernel on inputs that exercise it: with the default-init weights the softmax is near-uniform and the
     # kernel's re-base branch is never taken in the timed region; the hot weights attend sharply.  Bounded: 1 warm-up + at most 2 steps.
     hot_res = None
-    if args.weights == "default" and not args.no_hot and not emu and not args.fusion_only:
+    if args.weights == "default" and not args.no_hot and not emu and not args.fusion_only and extras_ok:
         try:
             hot_res = measure(args.dtype, args.precision, steps=min(args.steps, 2), warmup=min(args.warmup, 1), weights="hot")
         except Exception as exc:  # noqa: BLE001  (an extra: never at the price of the headline line)
@@ -748,7 +756,11 @@ def main():
             if "parity" in alt_res:
                 out["alt_format"]["parity"] = alt_res["parity"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, enc, dec, head, args.cpu_views)
+            try:
+                out["cpu_baseline"] = cpu_baseline(sd, enc, dec, head, args.cpu_views)
+            except Exception as exc:  # noqa: BLE001
+                print(f"CPU baseline failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+                out["cpu_baseline"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     shutdown()
 
