@@ -382,3 +382,29 @@ def test_bench_power_sampler_never_raises_without_a_gpu():
     out = s.summary()
     assert set(out) >= {"source", "samples", "power_w_mean", "sclk_mhz_mean", "error"}
     assert out["samples"] == 0 or out["source"] in ("amdsmi", "rocm-smi")
+
+
+def test_magic_number_division_is_exact_under_the_bound_the_launchers_check():
+    """The kernels divide by multiplying with ceil(2^32 / d) and keeping the high word (attention work items -> (query block, head, batch):
+    f3r_attn_asm.hip takes the work-stealing form only while n_work * nxy < 2^32; GEMM tile map: f3r_gemm_asm.hip tile_map_exact; RoPE token ->
+    (y, x) in the q | k epilogue).  The claim behind those checks: for d >= 2 and a * d < 2^32, (a * ceil(2^32 / d)) >> 32 == a // d -- and just
+    above the bound it fails, so the bound is not decoration."""
+    from hypothesis import given, settings, strategies as st
+
+    def magic(d):
+        return -(-(1 << 32) // d)
+
+    @settings(max_examples=3000, deadline=None)
+    @given(st.integers(2, 1 << 20), st.data())
+    def exact(d, data):
+        a = data.draw(st.integers(0, ((1 << 32) - 1) // d))
+        assert a * d < (1 << 32) and magic(d) < (1 << 32)
+        assert (a * magic(d)) >> 32 == a // d
+    exact()
+    # edge of the bound, dense: every a for a few divisors, incl. the largest a the bound admits
+    for d in (2, 3, 5, 7, 40, 320, 640, 1023, 1025, 65535):
+        top = ((1 << 32) - 1) // d
+        for a in list(range(0, 2000)) + list(range(max(0, top - 2000), top + 1)):
+            assert (a * magic(d)) >> 32 == a // d, (a, d)
+    # beyond it the trick does break: d = 3, a = 2^31 (a * d = 1.5 x 2^32) comes out one too high
+    assert ((1 << 31) * magic(3)) >> 32 == (1 << 31) // 3 + 1
