@@ -143,13 +143,45 @@ def attention_emul(x, sd, pre, num_heads, scale, xpos=None, rope_base=None, q_ch
     pv_dt = ATTN.get("pv", mode)
     if qk_dt in DT:
         q, k = rnd(q * scale, DT[qk_dt]) / scale, rnd(k, DT[qk_dt])
-    a = (q @ k.transpose(-2, -1)) * scale
+        a = (q @ k.transpose(-2, -1)) * scale
+    elif qk_dt == "f16x3_8":   # hi . hi on fp16, the two correction products from fp8 operands (block-scaled fp8 MFMA)
+        qh, ql = split2(q * scale, torch.float16)
+        kh, kl = split2(k, torch.float16)
+        a = qh @ kh.transpose(-2, -1) + rnd8(ql) @ rnd8(kh).transpose(-2, -1) + rnd8(qh) @ rnd8(kl).transpose(-2, -1)
+    elif qk_dt in ("f16x3", "f16q2", "f16k2"):   # round 6: Q and / or K as hi + lo fp16 planes (q_hi k_hi + q_lo k_hi + q_hi k_lo on the matrix pipe)
+        qh, ql = split2(q * scale, torch.float16)
+        kh, kl = split2(k, torch.float16)
+        a = qh @ kh.transpose(-2, -1)
+        if qk_dt in ("f16x3", "f16q2"):
+            a = a + ql @ kh.transpose(-2, -1)
+        if qk_dt in ("f16x3", "f16k2"):
+            a = a + qh @ kl.transpose(-2, -1)
+    else:
+        a = (q @ k.transpose(-2, -1)) * scale
     a = a - a.amax(dim=-1, keepdim=True)
     p = a.exp()
+    l = p.sum(-1, keepdim=True)
     if pv_dt in DT:
         p = rnd(p, DT[pv_dt])
         v = rnd(v, DT[pv_dt])
-    o = (p @ v) / p.sum(-1, keepdim=True)
+        o = p @ v
+    elif pv_dt in ("f16x3_8", "f16v2_8"):
+        ph, pl = split2(p, torch.float16)
+        vh, vl = split2(v, torch.float16)
+        o = ph @ vh + rnd8(ph) @ rnd8(vl)
+        if pv_dt == "f16x3_8":
+            o = o + rnd8(pl) @ rnd8(vh)
+    elif pv_dt in ("f16x3", "f16p2", "f16v2"):   # round 6: P and / or V as hi + lo planes
+        ph, pl = split2(p, torch.float16)
+        vh, vl = split2(v, torch.float16)
+        o = ph @ vh
+        if pv_dt in ("f16x3", "f16p2"):
+            o = o + pl @ vh
+        if pv_dt in ("f16x3", "f16v2"):
+            o = o + ph @ vl
+    else:
+        o = p @ v
+    o = o / l
     o = o.transpose(1, 2).reshape(B, S, C)
     if ZONE.mode in DT or ZONE.mode.endswith("+store"):
         pass
@@ -241,6 +273,43 @@ STUDIES = {
         ("linear layers x3, attention fp16", "f16x3", "f16x3", None, None, {}), ("linear layers x3 AND attention exact", "f16x3", "f16x3", {"qk": "f32", "pv": "f32"}, None, {}),
         ("transformer exact, attention fp16, heads x3", "f32", "f16x3", None, None, {}), ("heads exact, rest as the product", "f16w2", "f32", None, None, {}),
         ("precision fast", "f16", "f16", None, None, {})]),
+    # round 6: price a "robust" tier between high and exact.  Linear layers x3 (both operands as planes) is the known floor of the
+    # transformer side; which attention operands must ALSO carry a low plane?  "f16x3" = hi + lo on both operands of the product (3 MFMA products),
+    # "f16q2" / "f16k2" / "f16p2" / "f16v2" = a low plane on that one operand only (2 products)
+    "robust": ("heavy", [
+        ("linear x3, attention fp16 (r5 row)", "f16x3", "f16x3", None, None, {}),
+        ("linear x3, QK^T 3 products, PV fp16", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16"}, None, {}),
+        ("linear x3, QK^T fp16, PV 3 products", "f16x3", "f16x3", {"qk": "f16", "pv": "f16x3"}, None, {}),
+        ("linear x3, QK^T 3 products, PV 3 products", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x3, QK^T exact, PV fp16", "f16x3", "f16x3", {"qk": "f32", "pv": "f16"}, None, {}),
+        ("linear x3, QK^T fp16, PV exact", "f16x3", "f16x3", {"qk": "f16", "pv": "f32"}, None, {}),
+        ("linear x3, Q lo only + PV 3", "f16x3", "f16x3", {"qk": "f16q2", "pv": "f16x3"}, None, {}),
+        ("linear x3, K lo only + PV 3", "f16x3", "f16x3", {"qk": "f16k2", "pv": "f16x3"}, None, {}),
+        ("linear x3, QK 3 + P lo only", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16p2"}, None, {}),
+        ("linear x3, QK 3 + V lo only", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16v2"}, None, {}),
+        ("linear w2, QK 3 + PV 3", "f16w2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x2 (activations split, weights single), QK 3 + PV 3", "f16x2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x3 with fp8 corrections, QK 3 + PV 3", "f16x3_8", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x3 on qkv + proj only (MLP w2), QK 3 + PV 3", "f16w2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, {"qkv": "f16x3", "proj": "f16x3"}, {}),
+        ("linear x3 on fc1 + fc2 only (qkv, proj w2), QK 3 + PV 3", "f16w2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, {"fc1": "f16x3", "fc2": "f16x3"}, {}),
+        ("linear x3 on qkv only, QK 3 + PV 3", "f16w2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, {"qkv": "f16x3"}, {}),
+        ("linear x3_8, QK 3_8 + PV 3_8 (every correction in fp8)", "f16x3_8", "f16x3", {"qk": "f16x3_8", "pv": "f16x3_8"}, None, {}),
+        ("linear x3_8, QK 3_8 + V lo in fp8 (no P lo)", "f16x3_8", "f16x3", {"qk": "f16x3_8", "pv": "f16v2_8"}, None, {}),
+        ("linear x3, QK 3_8 + PV 3_8", "f16x3", "f16x3", {"qk": "f16x3_8", "pv": "f16x3_8"}, None, {}),
+    ]),
+    # the same question on the model the GPU test measures (--model vitl: ViT-L / ViT-L / 2 DPT heads, N = 3 views of 512^2; ~2 min per row on 8 cores)
+    "robust_vitl": ("heavy", [
+        ("the product (high): linear w2, attention fp16", "f16w2", "f16x3", None, None, {}),
+        ("linear x3, attention fp16", "f16x3", "f16x3", None, None, {}),
+        ("linear w2, QK 3 + PV 3", "f16w2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x3, QK 3, PV fp16", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16"}, None, {}),
+        ("linear x3, QK 3 + V lo only", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16v2"}, None, {}),
+        ("linear x3, QK 3 + PV 3", "f16x3", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+        ("linear x3_8, QK 3_8 + PV 3_8 (every correction in fp8)", "f16x3_8", "f16x3", {"qk": "f16x3_8", "pv": "f16x3_8"}, None, {}),
+        ("linear x3_8, QK 3_8 + V lo in fp8 (no P lo)", "f16x3_8", "f16x3", {"qk": "f16x3_8", "pv": "f16v2_8"}, None, {}),
+        ("linear w2, QK 3_8 + PV 3_8", "f16w2", "f16x3", {"qk": "f16x3_8", "pv": "f16x3_8"}, None, {}),
+        ("linear x2 (activations split, weights single), QK 3 + PV 3", "f16x2", "f16x3", {"qk": "f16x3", "pv": "f16x3"}, None, {}),
+    ]),
 }
 
 
@@ -248,10 +317,16 @@ def study(name):
     """python oracle/precision_study.py --study heads | fp8 | heavy  (the round-5 questions; results: profiles/r05_precision_study_*.txt)"""
     from fast3r_amd import Fast3R
     dist, cases = STUDIES[name]
-    args = tiny_args()
+    if name.endswith("_vitl"):
+        from fast3r_amd.synthetic import vit_large_args
+        args = vit_large_args(attn_implementation="pytorch_naive")
+        size = 512
+    else:
+        args = tiny_args()
+        size = 64
     shp = {k: tuple(v.shape) for k, v in Fast3R(*args).state_dict().items()}
     sd = synth_state_dict(shp, 0, dist)
-    views = make_views(3, 64, 64)
+    views = make_views(3, size, size)
     torch.manual_seed(1234)
     ref = O.forward(views, sd, *args)
     for label, tr, hd, attn, roles, convs in cases:
