@@ -230,13 +230,31 @@ def first_to_fail():
     parent): that rank prints the line."""
     run_id = "".join(c for c in os.environ.get("TORCHELASTIC_RUN_ID", "") if c.isalnum())[:40]
     path = f"/tmp/f3r_bench_fail_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{run_id}"
-    try:
-        os.close(os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600))
-        return True
-    except FileExistsError:
-        return False
-    except OSError:
-        return int(os.environ.get("RANK", "0")) == 0
+    for attempt in range(2):
+        try:
+            os.close(os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600))
+            return True
+        except FileExistsError:
+            # The marker of an EARLIER job with the same parent pid / port / run id (a shell loop re-running the bench, a reused pid) must not
+            # silence this one: the ranks of one job fail within seconds of each other (or together at the process-group timeout), so a marker
+            # older than FAIL_MARKER_STALE_S belongs to a job that is gone -- take it over (ADVICE r5)
+            try:
+                age = time.time() - os.stat(path).st_mtime
+            except OSError:
+                continue   # it vanished between the two calls: try to create it again
+            if attempt == 0 and age > FAIL_MARKER_STALE_S:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+                continue
+            return False
+        except OSError:
+            break
+    return int(os.environ.get("RANK", "0")) == 0
+
+
+FAIL_MARKER_STALE_S = 300.0
 
 
 def flops_forward(V, P=1024, D=1024, L_enc=24, L_dec=24, heads=2):

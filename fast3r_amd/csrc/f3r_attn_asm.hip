@@ -190,6 +190,13 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
     k.grid = cus;
     gx = cus;
     gy = gz = 1;
+    // the kernel trusts {next, done} to be zero on entry and leaves them zero; a launch that was aborted (or a buffer the caller did not clear)
+    // would make the next one silently skip items [0, next): clear the two words on the launch stream (a memset node under graph capture)
+    hipError_t me = hipMemsetAsync(a.sched_counter, 0, 2 * sizeof(uint32_t), stream);
+    if (me != hipSuccess) {
+      f3r_set_error("f3r_attn_fwd: clearing sched_counter failed: %s", hipGetErrorString(me));
+      return F3R_ERR_LAUNCH;
+    }
   }
   size_t size = sizeof(k);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

@@ -316,8 +316,23 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(a.K > 0 && a.K % 128 == 0 && a.Kpad == a.K, "f3r_gemm: W2F8 needs K = Kpad, a multiple of 128 (got %d / %d)", a.K, a.Kpad);
     F3R_REQUIRE(a.lda % 8 == 0 && a.lda * 2 >= (int64_t)a.K * 3, "f3r_gemm: W2F8 rows are [K fp16 | K fp8]: lda %lld must be >= 3 K / 2", (long long)a.lda);
     F3R_REQUIRE(a.epi != F3R_EPI_GENERIC || a.out_f32 || a.out_lp, "f3r_gemm: no output");
+    // the checks the other splits get further down (a C caller reaches the hand-scheduled epilogues only through here: ADVICE r5)
+    F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 7) || a.kernel_sel == 9, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
+    F3R_REQUIRE(a.dtype == F3R_F16, "f3r_gemm: W2F8 corrects fp16 planes only (dtype %d)", a.dtype);
+    F3R_REQUIRE(a.act >= F3R_ACT_NONE && a.act <= F3R_ACT_RELU, "f3r_gemm: bad act %d", a.act);
+    F3R_REQUIRE(a.N % 4 == 0 && (!a.bias || al16(a.bias)), "f3r_gemm: N %d must be a multiple of 4, bias 16-byte aligned", a.N);
+    if (a.epi == F3R_EPI_GENERIC) {
+      F3R_REQUIRE(!a.out_f32 || (al16(a.out_f32) && a.ldo_f32 % 4 == 0 && a.ldo_f32 >= a.N), "f3r_gemm: out_f32 alignment/ld");
+      F3R_REQUIRE(!a.out_lp || (al16(a.out_lp) && a.ldo_lp % 8 == 0 && a.ldo_lp >= a.N), "f3r_gemm: out_lp alignment/ld");
+      F3R_REQUIRE(!a.res_f32 || (al16(a.res_f32) && a.ldr_f32 % 4 == 0 && a.ldr_f32 >= a.N), "f3r_gemm: res_f32 alignment/ld");
+    }
     const char* why = "";
-    if (a.epi == F3R_EPI_QKV) {  // q | k with the low plane in fp8, V^T (swapped operand roles) on two fp16 planes from W_aux
+    if (a.epi == F3R_EPI_QKV) {
+      F3R_REQUIRE(a.qkv_dq != 0 || a.N % 3 == 0, "f3r_gemm: QKV with three equal parts needs N %% 3 == 0 (got %d)", a.N);
+      {
+        const int Dq = a.qkv_dq ? a.qkv_dq : a.N / 3;
+        F3R_REQUIRE(Dq > 0 && Dq % 64 == 0 && a.N > Dq && (a.N - Dq) % 128 == 0, "f3r_gemm: QKV parts must be whole 64-wide heads (N %d, q %d)", a.N, Dq);
+      }  // q | k with the low plane in fp8, V^T (swapped operand roles) on two fp16 planes from W_aux
       F3R_REQUIRE(a.q && a.k && a.vt && a.W_aux && al16(a.W_aux) && a.seq_len > 0 && a.M % a.seq_len == 0 && a.ldvt >= a.seq_len && a.act == F3R_ACT_NONE,
                   "f3r_gemm: W2F8 QKV needs q, k, vt, W_aux (16-byte aligned), seq_len dividing M, no activation");
       if (a.rope_cos) F3R_REQUIRE(a.rope_sin && a.rope_w > 0 && al16(a.rope_cos) && al16(a.rope_sin), "f3r_gemm: RoPE tables");

@@ -477,8 +477,10 @@ class _GraphCache:
             return None
         if model._orientation_plan(views)["any_portrait"]:  # also the eager path's argument checks (utils/misc.py:69), done on the host
             return None
+        # (the operand-format knobs are part of the key: a graph captured with another low_plane / high_fc1_planes would keep replaying the old
+        # packed weights after the model re-packed)
         key = (len(views), tuple(imgs[0].shape), str(dev), model.compute_dtype, model.precision, model.max_parallel_views_for_head,
-               model.training, model._params_version())
+               model.training, model._params_version(), model.low_plane, model.high_fc1_planes)
         dec = model.decoder
         B = imgs[0].shape[0]
         if key not in self.entries:
@@ -491,14 +493,15 @@ class _GraphCache:
             for t, i in zip(static_imgs, imgs):
                 t.copy_(i)
             graph = torch.cuda.CUDAGraph()
+            sched = torch.zeros(2, dtype=torch.int32, device=dev)   # this graph's own work-stealing pair (ops.sched_scope), allocated outside the capture
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph), ops.sched_scope(sched):
                 outs = model._forward_eager(static_views, False, _emb_rows=static_emb)
-            self.entries[key] = (graph, static_imgs, static_emb, outs)
+            self.entries[key] = (graph, static_imgs, static_emb, outs, sched)
             while len(self.entries) > self.max_entries:
                 self.entries.popitem(last=False)
         self.entries.move_to_end(key)
-        graph, static_imgs, static_emb, outs = self.entries[key]
+        graph, static_imgs, static_emb, outs, _sched = self.entries[key]
         for t, i in zip(static_imgs, imgs):
             t.copy_(i, non_blocking=True)
         ids = dec.draw_image_ids(B, len(views))
@@ -790,7 +793,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def _pack(self, device):
         lp = self.compute_dtype
         f8 = self.low_plane == "fp8" and self.precision == "high" and lp == torch.float16
-        key = (lp, self.precision, str(device), self._params_version(), f8)
+        key = (lp, self.precision, str(device), self._params_version(), f8, bool(self.high_fc1_planes))
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
         alt = getattr(self, "_packed_alt", None)

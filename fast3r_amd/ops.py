@@ -25,9 +25,38 @@ ATTN_COUNTERS = None
 # (one per device and stream, kept here: the kernel leaves it zero); the library uses it for launches of at least two rounds of workgroups.
 ATTN_WORK_STEALING = True
 _SCHED = {}
+_SCHED_CAPTURE = None   # sched_scope(): the counter of the graph being captured
+
+
+class sched_scope:
+    """`with ops.sched_scope(counter):` -- every attention launch inside uses `counter` (int32[2] on the device) as its work-stealing pair.
+    Fast3R's graph cache allocates one per captured graph OUTSIDE the capture and keeps it with the graph: graphs replayed concurrently on
+    different streams then never share a pair, and the words do not live in a capture-private pool keyed by torch's shared
+    capture stream."""
+
+    def __init__(self, counter):
+        assert counter.dtype == torch.int32 and counter.numel() >= 2 and counter.is_cuda
+        self.counter = counter
+
+    def __enter__(self):
+        global _SCHED_CAPTURE
+        self.prev, _SCHED_CAPTURE = _SCHED_CAPTURE, self.counter
+        return self.counter
+
+    def __exit__(self, *exc):
+        global _SCHED_CAPTURE
+        _SCHED_CAPTURE = self.prev
+        return False
 
 
 def _sched_counter(dev):
+    """The {next, done} pair of this launch: the scope's (graph capture), else one per (device, stream).  A capture nobody opened a scope for gets
+    a FRESH pair per launch (8 bytes from that graph's own pool, alive as long as the graph): never the eager pair of the capture stream.  The
+    library clears the pair on the launch stream before the kernel starts, so none of them needs to be zero here."""
+    if _SCHED_CAPTURE is not None and _SCHED_CAPTURE.device == dev:
+        return _SCHED_CAPTURE
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(2, dtype=torch.int32, device=dev)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     t = _SCHED.get(key)
     if t is None:

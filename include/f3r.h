@@ -280,8 +280,10 @@ typedef struct f3r_attn_args {
      (how often the lazy reference really moved) and, from the clocks, the effective shader clock and the matrix-pipe utilisation of the
      timed launches themselves (roofline.live). */
   uint32_t* dbg_counters;
-  /* Work stealing for the hand-scheduled kernels (NULL = off; ABI 330): device uint32[2] {next item, workgroups done}, ZERO when the launch
-     starts; the kernel leaves it zero again, so one buffer serves any number of launches that do not overlap in time (one per stream).
+  /* Work stealing for the hand-scheduled kernels (NULL = off; ABI 330): device uint32[2] {next item, workgroups done}.  The library clears the two
+     words on `stream` ahead of every launch that uses them (since round 6; the kernel also leaves them zero), so one buffer serves any number of
+     launches that do not overlap in time -- one buffer per stream, and per captured graph if graphs may replay concurrently: two launches in
+     flight on the same pair would steal each other's items.
      With it, launches of at least two rounds of workgroups run as ONE persistent workgroup per CU that takes (query block, head, batch)
      items from `next`: the hardware deals workgroup ids round-robin over the 8 XCDs whatever their clocks (up to 6 % apart under the power
      cap), which left the faster XCDs idle for ~2.4 % of every fusion-attention launch (profiles/r05_*per_xcd*).  Other launches ignore it. */

@@ -328,6 +328,20 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
             torch.cuda.synchronize()
             assert ctr.tolist() == [0, 0]
             assert torch.equal(stolen.view(torch.int16), plain.view(torch.int16))
+        # leftovers of an aborted launch in the pair: the library clears it on the launch stream before the kernel starts (round 6)
+        saved_ctrs, ops.ATTN_COUNTERS = ops.ATTN_COUNTERS, None
+        ctr.copy_(torch.tensor([7, 3], dtype=torch.int32))
+        again = run(qs, k, v, H, hd=hd)
+        torch.cuda.synchronize()
+        assert ctr.tolist() == [0, 0] and torch.equal(again.view(torch.int16), plain.view(torch.int16))
+        # a scope hands the launches another pair (what Fast3R's graph cache does per captured graph)
+        mine = torch.full((2,), 5, dtype=torch.int32, device=DEV)
+        with ops.sched_scope(mine):
+            assert ops._sched_counter(mine.device) is mine
+            scoped = run(qs, k, v, H, hd=hd)
+        torch.cuda.synchronize()
+        assert mine.tolist() == [0, 0] and torch.equal(scoped.view(torch.int16), plain.view(torch.int16))
+        ops.ATTN_COUNTERS = saved_ctrs
         c = [int(x) & 0xFFFFFFFF for x in ops.ATTN_COUNTERS.tolist()]
         wq = 512 if hd == 64 else 256
         waves = 3 * 4 * (-(-Tq // wq)) * H

@@ -82,3 +82,27 @@ def test_a_rank_that_cannot_start_its_process_group_still_ends_the_job_with_one_
     itself (first_to_fail: one rank per launcher), the launcher ends the other rank, the exit code is non-zero"""
     out = _run(["--gpus", "2", "--views", "6", "--steps", "1", "--warmup", "1"], {"F3R_BENCH_INJECT_FAULT": "1:startup", "F3R_BENCH_PG_TIMEOUT_S": "8"}, expect_rc0=False)
     assert out["value"] is None and "rank 1 at start-up" in out["error"] and "injected fault" in out["error"] and out["n_gpus"] == 2
+
+
+def test_a_stale_failure_marker_does_not_silence_the_next_job(monkeypatch, tmp_path):
+    """the O_EXCL marker that elects the rank which prints the failure line is never removed; a later job with the same parent pid, port
+    and run id found it and printed nothing.  A marker older than FAIL_MARKER_STALE_S is taken over; a fresh one (a sibling rank of THIS job got
+    there first) still means "stay silent"."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("MASTER_PORT", "1")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", f"stale{os.getpid()}")
+    path = f"/tmp/f3r_bench_fail_{os.getppid()}_1_stale{os.getpid()}"
+    try:
+        assert bench.first_to_fail() is True          # first rank of the job: creates the marker
+        assert bench.first_to_fail() is False         # its sibling, seconds later: silent
+        old = time.time() - bench.FAIL_MARKER_STALE_S - 5
+        os.utime(path, (old, old))
+        assert bench.first_to_fail() is True          # a new job long after: the stale marker is taken over
+        assert bench.first_to_fail() is False
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
