@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--views", type=int, default=320, help="total views N of the forward pass (BASELINE headline: 320)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type (fp32 accumulate)")
-    ap.add_argument("--precision", default="high", choices=["fast", "high"],
+    ap.add_argument("--precision", default="high", choices=["fast", "high", "robust"],
                     help="high: split-precision GEMM operands (weights hi+lo in the transformer, both operands in the heads), see DESIGN.md section 3 (Precision modes); "
                          "the default pair (fp16, high) is the operand format that meets the 1e-3 parity bar on the stress fixture")
     ap.add_argument("--low-plane", default="fp8", choices=["fp16", "fp8"],
@@ -76,6 +76,7 @@ def parse(argv=None):
                     help="skip the two bounded extra objects of the default line: n100 (BASELINE configs[2]: N = 100 end to end) and fusion_only_n20 "
                          "(configs[1]: N = 20, fusion transformer only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true", help="skip the extra forward that times every launch per kernel family (roofline.others)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=3)
     ap.add_argument("--emulate-rank", type=int, default=None,
@@ -511,7 +512,7 @@ def main():
     views = [v if v is not None else placeholder for v in views]  # never read outside [lo, hi)
 
     def measure(dtype_name, precision, steps=None, warmup=None, weights=None, parity_exact=False, time_inference=False, n_views=None, fusion_only=None,
-                parity=True):
+                parity=True, families=False):
         """W warm-up + K timed steps of one operand format -> the measured fields of the JSON line.  n_views / fusion_only: the bounded extra
         objects of the default line (the first n_views of the resident views; BASELINE configs[1] / [2]) -- single-GPU runs only."""
         V = args.views if n_views is None else n_views
@@ -592,7 +593,9 @@ def main():
             fus = [(ms, fl) for ms, fl, _ in fus if fl == big]
             avg_ms = sum(ms for ms, _ in fus) / len(fus)
         achieved = big / (avg_ms * 1e-3) / 1e12
-        prec = "" if precision == "fast" else "; split-precision GEMM operands (weights hi+lo in the transformer, both operands hi+lo in the heads)"
+        prec = {"fast": "", "robust": "; every GEMM / conv with both operands as hi+lo planes, fusion attention with Q and K as hi+lo planes (three products per "
+                                      "score block, f3r_attn_asm_qk3_f16), the encoder's attention in fp32"}.get(
+            precision, "; split-precision GEMM operands (weights hi+lo in the transformer, both operands hi+lo in the heads)")
         e2e = None if (fo or emu) else flops_forward(V) / (dt / steps) / 1e12 / world
         if emu:
             kvx = model.sharding.last_exchange
@@ -651,6 +654,13 @@ def main():
                 del host_views
             except Exception as exc:  # noqa: BLE001
                 res["inference"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if families and not (emu or distributed):
+            # roofline.others: ONE more forward with an event pair around every launch, summed per kernel family.  Outside the
+            # timed steps (the events cost a few microseconds per launch); the families are exactly the ones the rocprofv3 kernel stats group.
+            try:
+                res["roofline"]["others"] = family_rooflines(ops, step_fn, steps=1, fusion_flops=big)
+            except Exception as exc:  # noqa: BLE001  (an extra: never at the price of the headline line)
+                res["roofline"]["others"] = {"error": f"{type(exc).__name__}: {exc}"}
         if rank == 0 and not args.no_parity and not emu and parity:
             res["parity"] = parity_on_stress_fixture(lp, precision, dev)
         if parity_exact and not (emu or distributed or fo):
@@ -683,7 +693,7 @@ def main():
         workload = f"Fast3R ViT-L 512x512 end-to-end single forward pass (encoder + fusion decoder + 2 DPT heads), N={V} views"
 
     try:
-        main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact, time_inference=not args.no_inference)
+        main_res = measure(args.dtype, args.precision, parity_exact=args.parity_exact, time_inference=not args.no_inference, families=not args.no_families)
     except Exception as exc:  # noqa: BLE001  -- a failed run still ends with ONE line on rank 0's stdout, and a non-zero exit code
         import traceback
         traceback.print_exc(file=sys.stderr)
@@ -730,12 +740,14 @@ def main():
     if world == 1 and not distributed and not emu and not args.fusion_only and not args.no_extra_configs and V >= 100:
         for key, kw in (("n100", dict(n_views=100)), ("fusion_only_n20", dict(n_views=20, fusion_only=True))):
             try:
-                r = measure(args.dtype, args.precision, steps=2, warmup=1, parity=False, **kw)
+                r = measure(args.dtype, args.precision, steps=2, warmup=1, parity=False, families=not args.no_families, **kw)
                 extra[key] = {"what": "BASELINE configs[2]: N = 100 views 512x512, full encoder + fusion + heads" if key == "n100" else
                                       "BASELINE configs[1]: N = 20 views 512x512, fusion transformer only on frozen random encoder features",
                               "value": r["value"], "unit": "views/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
                               "dtype": r["dtype"], "precision": r["precision"],
                               "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_timed", "e2e")}}
+                if "others" in r["roofline"]:
+                    extra[key]["roofline"]["others"] = r["roofline"]["others"]
                 extra[key]["roofline"]["live"] = {k: v for k, v in r["roofline"]["live"].items() if k not in ("source", "power", "per_xcd")}
                 extra[key]["attention_share_of_step"] = r["roofline"]["avg_launch_ms"] * int(dec["depth"]) / r["ms_per_step"]
             except Exception as exc:  # noqa: BLE001
@@ -819,6 +831,49 @@ def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power):
             "wave_cycles_mean": cycles / waves, "waves": waves, "mfma_per_wave_mean": mfma_per_tile * tiles / waves, "wall_clock_khz": khz,
             "implied_tflops": implied, "implied_frac": implied / MFMA_PEAK_TFLOPS, "achieved_over_implied": achieved_tflops / implied,
             "per_xcd": xcd, "power": power}
+
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured with a float4 copy)
+
+
+def family_rooflines(ops, step_fn, steps, fusion_flops):
+    """One forward with ops.OP_TIMER on: every launch of the C ABI is bracketed by an event pair on its stream and booked under its kernel family --
+    transformer_linears (patch embedding, QKV, proj, fc1, fc2, decoder_embed), head_convs (every 1x1 / 3x3 / transposed convolution of the two DPT
+    heads), attention (split into the fusion launches = the roofline kernel, and the encoder's), elementwise (LayerNorm, casts, bilinear upsampling,
+    final conv + postprocess, patchify).  MFMA families: ALGORITHMIC FLOP (one product per output, whatever planes the precision mode executes)
+    / summed launch time / 2.5 PFLOP/s; elementwise: tensor bytes in + out / time / 8 TB/s.  Launch gaps are in nobody's sum (`sum_ms` vs the step)."""
+    import torch
+    ops.OP_TIMER = {}
+    try:
+        with torch.no_grad():
+            for _ in range(steps):
+                step_fn()
+        torch.cuda.synchronize()
+        rec = ops.OP_TIMER
+    finally:
+        ops.OP_TIMER = None
+    fams = {}
+    att = rec.pop("attention", [])
+    rec["attention_fusion"] = [r for r in att if r[2] >= 0.99 * fusion_flops]
+    rec["attention_other"] = [r for r in att if r[2] < 0.99 * fusion_flops]
+    out, total = [], 0.0
+    for fam in ("attention_fusion", "transformer_linears", "head_convs", "attention_other", "elementwise", "other"):
+        rs = rec.get(fam, [])
+        if not rs:
+            continue
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in rs) / steps
+        fl = sum(r[2] for r in rs) / steps
+        by = sum(r[3] for r in rs) / steps
+        total += ms
+        e = {"family": fam, "ms_per_forward": ms, "launches_per_forward": len(rs) // steps}
+        if fam == "elementwise":
+            e.update({"bound": "hbm", "algorithmic_gbytes": by / 1e9, "achieved_gb_s": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        else:
+            e.update({"bound": "mfma", "algorithmic_tflop": fl / 1e12, "algorithmic_tflops": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS})
+        out.append(e)
+    return {"what": "one extra forward with an event pair around every launch (fast3r_amd.ops.OP_TIMER), summed per kernel family; algorithmic work "
+                    "(one product per output; the split-precision planes a mode executes are NOT counted) over the summed launch time",
+            "families": out, "sum_ms": total}
 
 
 def make_fusion_only_step(model, V, lp, dev):
@@ -930,7 +985,15 @@ def cpu_baseline(sd, enc, dec, head, n_views):
     torch.set_num_threads(saved)
     O.ATTN_IMPL = "naive"
     dt = min(times)
-    return {"value": n_views / dt, "unit": "views/s", "cores": best, "kind": "port",
+    anchor = None
+    try:   # what `kind: "port"` rests on: the oracle timed beside the imported reference where both can run (the build container; /root/reference
+        a = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")))   # does not exist on the GPU box)
+        anchor = {"source": "profiles/r03_cpu_port_vs_reference.json (oracle/time_reference.py, build container, %d threads)" % a["threads"],
+                  "port_over_reference_throughput": a["port_over_reference_throughput"], "port_vs_reference_rel_l2": a["port_vs_reference_rel_l2"],
+                  "reference_views_per_s_there": a["reference_views_per_s"], "port_views_per_s_there": a["port_views_per_s"]}
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": n_views / dt, "unit": "views/s", "cores": best, "kind": "port", "port_over_reference": anchor,
             "sample": f"same model (ViT-L/ViT-L/2 DPT), {n_views} views of 512x512, fp32, SDPA attention; 1 warm-up + 2 timed forwards "
                       f"({', '.join('%.1f s' % t for t in times)}; best reported) at {best} threads of {nproc}",
             "thread_sweep_s_per_view": {str(k): round(v, 2) for k, v in sweep.items()}}

@@ -63,6 +63,7 @@ class AttnArgs(ctypes.Structure):
         ("kernel_sel", _c_i32), ("head_dim", _c_i32),
         ("dbg_counters", _c_vp),
         ("sched_counter", _c_vp),
+        ("qk_planes", _c_i32), ("reserved0", _c_i32),
     ]
 
 
@@ -90,6 +91,7 @@ SYMBOLS = {
     "f3r_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _c_vp]),
     "f3r_attn_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(AttnArgs)]),
     "f3r_block_workspace_bytes": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "f3r_block_workspace_bytes_ex": (ctypes.c_size_t, [_c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "f3r_upsample2x": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_dpt_final": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      _c_f32, _c_f32, ctypes.c_int, _c_vp]),
@@ -111,6 +113,8 @@ SYMBOLS = {
     "f3r_attn_f32_ex": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp]),
     "f3r_attn_f32_mfma_workspace": (ctypes.c_int64, [ctypes.POINTER(AttnF32Args)]),
     "f3r_attn_f32_mfma": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp, ctypes.c_int64, _c_vp]),
+    "f3r_qkv_planes": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
+    "f3r_attn_state_finish": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
 }
@@ -125,7 +129,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 330  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 340  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():

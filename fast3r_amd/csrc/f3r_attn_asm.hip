@@ -52,20 +52,22 @@ int hd_index(int hd) {
     if (kHd[i] == hd) return i;
   return -1;
 }
-int wave_rows(int hd) { return hd == 64 ? 128 : 64; }  // query rows of a wave (32 x the query blocks per wave)
+int wave_rows(int hd, int qk_planes = 1) { return (hd == 64 && qk_planes != 2) ? 128 : 64; }  // query rows of a wave (32 x the query blocks per wave)
 
 struct DevKernels {
   bool tried = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[kNumHd][2] = {};  // [head_dim index][F3R_F16, F3R_BF16]
+  hipFunction_t fn_qk3 = nullptr;    // head_dim 64, fp16, Q and K as hi + lo planes (f3r_attn_args.qk_planes = 2)
 };
 std::map<int, DevKernels> g_dev;
 std::mutex g_mu;
 
-hipFunction_t get_fn(int dtype, int hd) {
+hipFunction_t get_fn(int dtype, int hd, int qk_planes = 1) {
   int dev = 0;
   const int hi = hd_index(hd);
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1 || hi < 0) return nullptr;
+  if (qk_planes == 2 && (hd != 64 || dtype != F3R_F16)) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevKernels& d = g_dev[dev];
   if (!d.tried) {
@@ -80,10 +82,11 @@ hipFunction_t get_fn(int dtype, int hd) {
             snprintf(name, sizeof(name), "f3r_attn_asm_d%d_%s", kHd[i], t == F3R_F16 ? "f16" : "bf16");
           if (hipModuleGetFunction(&d.fn[i][t], d.mod, name) != hipSuccess) d.fn[i][t] = nullptr;
         }
+      if (hipModuleGetFunction(&d.fn_qk3, d.mod, "f3r_attn_asm_qk3_f16") != hipSuccess) d.fn_qk3 = nullptr;
     }
     (void)hipGetLastError();
   }
-  return d.fn[hi][dtype];
+  return qk_planes == 2 ? d.fn_qk3 : d.fn[hi][dtype];
 }
 
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -102,7 +105,9 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   *why = none;
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   if (hd_index(hd) < 0) { *why = "no generated kernel for this head_dim (64, 80, 128)"; return false; }
-  const int64_t wrows = wave_rows(hd);
+  const int qkp = a.qk_planes == 2 ? 2 : 1;
+  if (qkp == 2 && (hd != 64 || a.dtype != F3R_F16)) { *why = "qk_planes 2 needs head_dim 64 and fp16"; return false; }
+  const int64_t wrows = wave_rows(hd, qkp);
   if (a.causal) { *why = "causal mask"; return false; }
   if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
   if (a.tq < wrows) { *why = "fewer query rows than one wave takes (128 at head_dim 64, 64 otherwise)"; return false; }
@@ -132,13 +137,14 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   if (a.tq >= (1ll << 31) || a.n_heads >= 65536 || a.batch >= 65536) { *why = "grid too large"; return false; }
   // a code object that does not load on this device makes the launch INELIGIBLE (kernel_sel 0 then takes the general HIP kernel,
   // kernel_sel 2 reports why) instead of failing every fusion-attention call of the process
-  if (get_fn(a.dtype, hd) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
+  if (get_fn(a.dtype, hd, qkp) == nullptr) { *why = "the embedded code object could not be loaded on this device"; return false; }
   return true;
 }
 
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
-  hipFunction_t fn = get_fn(a.dtype, hd);
+  const int qkp = a.qk_planes == 2 ? 2 : 1;
+  hipFunction_t fn = get_fn(a.dtype, hd, qkp);
   if (!fn) {
     f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");
     return F3R_ERR_LAUNCH;
@@ -176,7 +182,7 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   // Work stealing (f3r_attn_args.sched_counter): one persistent workgroup per CU takes (q block, head, batch) items from a shared counter, so
   // the XCDs -- which the hardware feeds round-robin by workgroup id whatever their clocks -- finish together.  Worth it from two rounds of
   // workgroups on; the kernel's magic-number division needs item x period < 2^32.
-  const unsigned nx = (unsigned)((a.tq + 4 * wave_rows(hd) - 1) / (4 * wave_rows(hd)));
+  const unsigned nx = (unsigned)((a.tq + 4 * wave_rows(hd, qkp) - 1) / (4 * wave_rows(hd, qkp)));
   unsigned gx = nx, gy = (unsigned)a.n_heads, gz = (unsigned)a.batch;
   const uint64_t n_work = (uint64_t)nx * gy * gz, nxy = (uint64_t)nx * gy;
   const unsigned cus = (unsigned)num_cus();

@@ -24,7 +24,7 @@ int f3r_check_launch(const char* what) {
   return F3R_OK;
 }
 
-extern "C" int f3r_version(void) { return 330; /* 0.3.3: round-5 ABI (dbg_counters widened to uint32[8] with two clock sums, f3r_wall_clock_khz) */ }
+extern "C" int f3r_version(void) { return 340; /* 0.3.3: round-5 ABI (dbg_counters widened to uint32[8] with two clock sums, f3r_wall_clock_khz) */ }
 
 extern "C" int f3r_wall_clock_khz(void) {
   int dev = 0, khz = 0;
@@ -46,16 +46,24 @@ extern "C" size_t f3r_sizeof(int what) {
   }
 }
 
-extern "C" size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]) {
+extern "C" size_t f3r_block_workspace_bytes_ex(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, int f8_rows, size_t offsets[5]) {
   if (tokens < 0 || D <= 0 || kv_dim < 0 || hidden <= 0 || n_seq <= 0 || seq_len < 0 || n_seq * seq_len != tokens || !offsets) return 0;
+  if (f8_rows && (D % 8 != 0 || hidden % 8 != 0)) return 0;
   const size_t al = 256;
   const size_t ldvt = (size_t)((seq_len + 63) / 64 * 64);
-  const size_t sizes[5] = {(size_t)tokens * D * 2, (size_t)tokens * D * 2, (size_t)tokens * kv_dim * 2, (size_t)n_seq * kv_dim * ldvt * 2,
-                           (size_t)tokens * hidden * 2};
+  // f8_rows: regions 0 and 4 hold rows [w fp16 | w fp8] (3 w bytes) -- the LayerNorm output and the MLP hidden state of the F3R_SPLIT_W2F8 GEMMs; the
+  // plain [tokens][w] forms (attention output, hidden state of a pass that stays on fp16 planes) alias the head of the same regions
+  const size_t wide = f8_rows ? 3 : 2;
+  const size_t sizes[5] = {(size_t)tokens * D * wide, (size_t)tokens * D * 2, (size_t)tokens * kv_dim * 2, (size_t)n_seq * kv_dim * ldvt * 2,
+                           (size_t)tokens * hidden * wide};
   size_t off = 0;
   for (int i = 0; i < 5; ++i) {
     offsets[i] = off;
     off += (sizes[i] + al - 1) / al * al;
   }
   return off > 0 ? off : al;
+}
+
+extern "C" size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]) {
+  return f3r_block_workspace_bytes_ex(tokens, D, kv_dim, hidden, n_seq, seq_len, 0, offsets);
 }

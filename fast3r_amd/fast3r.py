@@ -604,8 +604,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         super().__init__()
         if isinstance(compute_dtype, str):  # config.json round trip stores the dtype as text
             compute_dtype = getattr(torch, compute_dtype.replace("torch.", ""))
-        if precision not in ("fast", "high", "exact"):
-            raise ValueError(f"precision must be 'fast', 'high' or 'exact', got {precision!r}")
+        if precision not in ("fast", "high", "robust", "exact"):
+            raise ValueError(f"precision must be 'fast', 'high', 'robust' or 'exact', got {precision!r}")
         self.encoder_args = dict(encoder_args)
         self.build_encoder(encoder_args)
         self.decoder_args = dict(decoder_args)
@@ -623,6 +623,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         self._graphs = _GraphCache()
         self._packed = None
         self._rope_cache = {}
+        self.weights_loaded = False   # load_state_dict / from_pretrained sets it: a checkpoint, not this constructor's default init
+        self.calibration = None       # calibrate_precision()'s report: which precision tier THESE weights need for 1e-3
         self.set_freeze(freeze)
 
     # ---------------------------------------------------------------- construction (fast3r.py:72-157)
@@ -745,7 +747,78 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     # ---------------------------------------------------------------- packed weights
     def load_state_dict(self, state_dict, strict=True, assign=False):
         self.invalidate_packed_weights()
+        self.weights_loaded, self.calibration = True, None
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    # ---------------------------------------------------------------- which precision tier do these weights need?
+    PRECISION_TIERS = ("fast", "high", "robust", "exact")   # cheapest first (N = 320: 8.3 / 8.9 / ~19 / 36 s on one MI355X)
+
+    @torch.no_grad()
+    def calibrate_precision(self, views, tol=1e-3, tiers=("fast", "high", "robust"), max_views=8, seed=1234):
+        """Measure, on up to `max_views` of the caller's own views, how far every 16-bit operand tier is from the fp32-equivalent mode
+        (precision="exact", 3e-7 of the reference on its golden outputs) WITH THE WEIGHTS THE MODEL HOLDS NOW, and say which tier to use.
+
+        Why: the distance of a 16-bit tier to the fp32 reference depends on the checkpoint.  Default-init-like and N(0, 1 / fan_in) weights keep
+        "high" (the default) within 3e-4; a noise-amplifying set (heavy-tailed weights, LayerNorm gains spread over a decade) measured 2.5e-3 with
+        "high" and 3.6e-4 with "robust" (DESIGN.md section 3).  Nobody can test the released `Fast3R.from_pretrained("jedyang97/Fast3R_ViT_Large_512")`
+        weights offline, so the model measures itself: ~2 s for 8 views of 512 x 512 at ViT-L size (the exact pass is most of it).
+
+        Returns (and keeps in `self.calibration`) {"per_tier": {tier: {output: rel-L2 vs exact}}, "worst": {tier: max}, "recommended": the cheapest
+        tier within `tol` (or "exact"), "tol", "n_views", ...}.  Does not change `self.precision`: set it from the answer, or pass
+        `inference(..., dtype=...)` as before.  Reference context: fast3r/croco/models/blocks.py:158-190 (bf16 autocast there), README.md:84."""
+        views = list(views)[:max(1, int(max_views))]
+        if not views:
+            raise ValueError("calibrate_precision needs at least one view")
+        if self.sharding is not None:
+            raise ValueError("calibrate_precision runs on one GPU: call it before shard_views()")
+        dev = next(self.parameters()).device
+        views = [dict(v, img=v["img"].to(dev)) for v in views]
+        saved = (self.precision, self.use_graphs)
+        rng = torch.get_rng_state()
+        per_tier, ms = {}, {}
+        try:
+            self.use_graphs = False
+
+            def run(p):
+                self.precision = p
+                torch.manual_seed(seed)   # the image ids consume the global CPU RNG (fast3r.py:702-743): the same ids for every tier
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = self._forward_eager(views)
+                torch.cuda.synchronize(dev)
+                ms[p] = (time.perf_counter() - t0) * 1e3
+                return out
+            ref = run("exact")
+            for p in tiers:
+                if p not in self.PRECISION_TIERS[:-1]:
+                    raise ValueError(f"unknown precision tier {p!r}")
+                out = run(p)
+                worst = {}
+                for o, r in zip(out, ref):
+                    for k in r:
+                        e = float((o[k].double() - r[k].double()).norm() / r[k].double().norm().clamp_min(1e-30))
+                        worst[k] = max(worst.get(k, 0.0), e)
+                per_tier[p] = worst
+                del out
+            del ref
+        finally:
+            self.precision, self.use_graphs = saved
+            torch.set_rng_state(rng)
+        worst = {p: max(v.values()) for p, v in per_tier.items()}
+        order = [p for p in self.PRECISION_TIERS if p in worst]
+        ok = [p for p in order if worst[p] <= tol and math.isfinite(worst[p])]
+        self.calibration = dict(per_tier=per_tier, worst=worst, recommended=ok[0] if ok else "exact", tol=tol, n_views=len(views),
+                                ms_incl_weight_packing=ms, compute_dtype=str(self.compute_dtype), params_version=self._params_version(),
+                                checker="precision='exact' on the same views and weights")
+        return self.calibration
+
+    def precision_is_calibrated(self):
+        """True when calibrate_precision() ran on the weights the model holds now and the tier in use is at least the recommended one."""
+        c = self.calibration
+        if c is None or c.get("params_version") != self._params_version():
+            return False
+        t = self.PRECISION_TIERS
+        return t.index(self.precision) >= t.index(c["recommended"])
 
     def _apply(self, fn, *a, **k):
         self.invalidate_packed_weights()
@@ -765,8 +838,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
 
     @property
     def _hp(self):
-        """split (hi + lo) weight planes and head activations: "high" and "exact"."""
-        return self.precision in ("high", "exact")
+        """split (hi + lo) weight planes and head activations: "high", "robust" and "exact"."""
+        return self.precision in ("high", "robust", "exact")
+
+    @property
+    def _x3(self):
+        """both operands of every GEMM / conv as hi + lo planes (three MFMA products): "robust" and "exact"."""
+        return self.precision in ("robust", "exact")
 
     # "fp8" (the default; precision "high" with fp16 operands): the correction products A W_lo of the transformer's MLPs (fc1, fc2) run on the
     # block-scaled fp8 MFMA (f3r.h F3R_SPLIT_W2F8: 1.4x the matrix-pipe rate of a second fp16 plane; LayerNorm and fc1's GELU epilogue write the
@@ -784,7 +862,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     @property
     def _sp(self):
         """split mode of the transformer's linear layers: weights only ("w2") in "high", both operands ("x3") in "exact"."""
-        return {"fast": None, "high": "w2", "exact": "x3"}[self.precision]
+        return {"fast": None, "high": "w2", "robust": "x3", "exact": "x3"}[self.precision]
 
     def _pair(self, x_f32):
         """fp32 -> (hi, lo) lowp planes."""
@@ -846,14 +924,15 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         """Workspace of the blocks of one encoder pass / decoder sample: ONE allocation shared by all of its layers.  external_kv: K / V^T
         are written into the buffers of a KVExchange (view-sharded path), the workspace keeps no room for them."""
         hidden = pb.fc1_w.shape[0]  # rows of the (possibly stacked [w1; w3]) up-projection
-        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=0 if external_kv else pb.kv_dim)
+        f8_rows = (pb.fc1_w8 is not None or pb.qk_w8 is not None) and T % 256 == 0   # the pass may take the fp8-low-plane GEMMs (_block decides per GEMM)
+        return ops.BlockWorkspace(T, D, hidden, n_seq, seq_len, self.compute_dtype, dev, kv_dim=0 if external_kv else pb.kv_dim, f8_rows=f8_rows)
 
     def _block(self, x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange=None, ws=None, kv_tap=None):
         """x: fp32 residual stream [n_seq*seq_len][D], updated in place.  blocks.py:236-239.  precision "high": every projection runs
         with split weights (hi + lo planes, split="w2"); the activations (LN output, attention output, MLP hidden) stay single.
         ws: the pass's BlockWorkspace (made here when absent): no per-layer allocation."""
         lp = self.compute_dtype
-        if self.precision == "exact":
+        if self._x3:
             return self._block_exact(x, pb, n_heads, scale, seq_len, n_seq, rope, kv_exchange)
         sp = "w2" if self.precision == "high" else None
         D = x.shape[1]
@@ -953,7 +1032,16 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if rope is not None and T:
             ops.rope_f32(qkv, n_heads + n_kv, max(1, seq_len), rope, pb.rope_mode)
         gqa = dict(head_dim=pb.head_dim, kv_group=pb.kv_group, causal=pb.causal)
-        if kv_exchange is None:
+        if kv_exchange is None and self.precision == "robust" and self._qk3_ok(pb, n_seq, seq_len):
+            # precision "robust": Q and K as hi + lo fp16 planes, three products per score block on the hand-scheduled kernel (f3r_attn_args.qk_planes),
+            # P and V single fp16; the launch parks its softmax state and a small pass turns it into the planes of the attention output
+            qp, kp, vt = ops.qkv_planes(qkv, n_heads, n_kv, n_seq, seq_len, scale * ops.LOG2E, lp)
+            state = ops.attention_state(T, n_heads, x.device, pb.head_dim)
+            ops.attention(qp, state[0], n_heads, scale, [(kp, vt.view(n_kv * 64, vt.shape[-1]), seq_len, 0, 0)], tq=seq_len, q_prescaled=True, state=state,
+                          state_out=True, kv_group=pb.kv_group, head_dim=64, qk_planes=2, kernel_sel=2)
+            o, ol = ops.attention_state_finish(state, n_heads, 64, lp)
+            del qp, kp, vt, state
+        elif kv_exchange is None:
             o, ol = ops.attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, **gqa)
         else:
             Dq, Dkv = n_heads * pb.head_dim, n_kv * pb.head_dim
@@ -972,6 +1060,15 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             _, hid, hid_lo = ops.gemm(h, pb.fc1_w, bias=pb.fc1_b, act="gelu", want_lp=True, want_lo=True, split="x3", a_lo=hl)
         ops.gemm(hid, pb.fc2_w, bias=pb.fc2_b, res_f32=x, out_f32=x, split="x3", a_lo=hid_lo)
         return x
+
+    def _qk3_ok(self, pb, n_seq, seq_len):
+        """can this block's attention take the three-product kernel (f3r_attn_asm_qk3_f16)?  One sequence (the fusion decoder: the kernel parks its
+        softmax state per launch), head_dim 64, fp16, no causal mask, whole 64-key tiles, at least one wave of queries, a power-of-two head group.
+        Everything else in precision "robust" -- the encoder's per-view attention, odd token counts, sharded models -- runs the fp32 attention of
+        precision "exact" (more exact, slower)."""
+        g = pb.kv_group
+        return (self.compute_dtype == torch.float16 and pb.head_dim == 64 and not pb.causal and n_seq == 1 and seq_len >= 64 and seq_len % 64 == 0
+                and g >= 1 and (g & (g - 1)) == 0)
 
     def _planes(self, x_f32):
         """fp32 -> the operand format of the DPT heads: (hi, lo) planes in "high" precision, (lowp, None) otherwise."""
@@ -1042,7 +1139,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def _patch_lo(self, imgs, ps, ld_out):
         """precision "exact": the low plane of the im2col rows = the im2col rows of the image's low plane (patchify only moves and rounds:
         its output is lowp(img), so lowp(img - lowp(img)) patchified is exactly the remainder plane); None otherwise."""
-        if self.precision != "exact":
+        if not self._x3:
             return None
         _, lo = ops.cast_lp(imgs.contiguous(), self.compute_dtype, want_lo=True)
         return ops.patchify(lo.float(), ps, self.compute_dtype, ld_out=ld_out)
@@ -1171,7 +1268,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             enc_lo = None
             if self._hp and not isinstance(self.decoder, LlamaDecoder):
                 enc_lo = torch.zeros_like(enc_tokens) if enc_tokens_lo is None else enc_tokens_lo.contiguous()
-            out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None, f32_hooks=return_f32)
+            with ops.family("transformer_linears"):
+                out = self._decode_sample(pk, enc_tokens.contiguous(), enc_lo, list(tokens_per_view), emb_rows, 0, None, f32_hooks=return_f32)
             return [t[0] for t in out]
 
     # ---------------------------------------------------------------- DPT head on the HIP kernels
@@ -1249,7 +1347,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if len(views) == 0:
             return ([], {}) if profiling else []
         if (self.use_graphs and not profiling and self.sharding is None and self.debug_taps is None and not isinstance(self.decoder, LlamaDecoder)
-                and self.precision != "exact"):  # (the validation mode allocates per layer: it always runs eagerly)
+                and not self._x3):  # (the plane modes allocate per layer: they always run eagerly)
             dev = views[0]["img"].device
             if dev.type == "cuda":  # (anything else: the eager path raises its F3RError)
                 with torch.cuda.device(dev):  # capture and replay on the tensors' device, whatever the caller's current device is
@@ -1331,7 +1429,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         Ps, feats = [], [[None] * B for _ in range(n_loc)]  # feats[i][b] = (hi [P][D], lo or None)
         if not plan["any_portrait"] and all(tuple(v["img"].shape[-2:]) == tuple(my_views[0]["img"].shape[-2:]) for v in my_views) and n_loc > 0:
             imgs = torch.cat([v["img"] for v in my_views], dim=0).float()
-            f, flo, P, grid = self._encode(imgs, pk)
+            with ops.family("transformer_linears"):   # (bench.py roofline.others: which family a GEMM-like launch is booked under)
+                f, flo, P, grid = self._encode(imgs, pk)
             f = f.view(n_loc, B, P, -1)
             flo = None if flo is None else flo.view(n_loc, B, P, -1)
             for i in range(n_loc):
@@ -1360,7 +1459,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 head_swap.append(list(pl["head_swap"]))
             untranspose = isinstance(enc, DinoEncoder)  # its portrait tokens go back to the stored (landscape) order (fast3r.py:601-622)
             for _, items in groups.items():
-                f, flo, P, (gh_, gw_) = self._encode(torch.stack([im for _, _, im in items]).contiguous(), pk)
+                with ops.family("transformer_linears"):
+                    f, flo, P, (gh_, gw_) = self._encode(torch.stack([im for _, _, im in items]).contiguous(), pk)
                 f = f.view(len(items), P, -1)
                 flo = None if flo is None else flo.view(len(items), P, -1)
                 for j, (i, b, _) in enumerate(items):
@@ -1406,7 +1506,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 t_all = [sum(tok[slice(*split_range(N_total, sh.world, r))]) for r in range(sh.world)]
                 assert t_all[sh.rank] == T_loc
                 kvx = sh.make_kv_exchange(T_loc, kv_dim, lp, dev, n_heads=dec.num_heads, q_dim=D, t_all=t_all)
-            hook_toks.append(self._decode_sample(pk, enc_hi, enc_lo, Ps, emb_rows[b], v_lo, kvx))
+            with ops.family("transformer_linears"):
+                hook_toks.append(self._decode_sample(pk, enc_hi, enc_lo, Ps, emb_rows[b], v_lo, kvx))
             if self.debug_taps is not None:
                 self.debug_taps.setdefault("hooks", []).append([t[0].float().cpu() for t in hook_toks[-1]])
         del feats
@@ -1436,7 +1537,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 for i in range(i0, i1):
                     per_view[i][b] = {}
                 for pname, cname, hk in heads:
-                    pts, conf = self._dpt(hk, toks, i1 - i0, gh, gw)
+                    with ops.family("head_convs"):
+                        pts, conf = self._dpt(hk, toks, i1 - i0, gh, gw)
                     for i in range(i0, i1):
                         sw = head_swap[i][b]
                         per_view[i][b][pname] = pts[i - i0].swapaxes(0, 1) if sw else pts[i - i0]  # transposed(): misc.py:105-106

@@ -81,6 +81,7 @@ def check_if_same_size(imgs):
 ALIAS_HOST_INPUTS = True
 _warned_fp32 = False
 _warned_exact_size = False
+_warned_uncalibrated = False
 EXACT_WARN_VIEWS = 48  # above this the "exact" mode costs seconds: every product is three MFMAs and the attention is O(T^2) (N = 100: 4 s, N = 320: 36 s)
 
 
@@ -110,6 +111,21 @@ def _operand_format(precision, model, n_views=0):
     return model.compute_dtype, model.precision
 
 
+def _warn_if_uncalibrated(net):
+    """once per process: a LOADED checkpoint running a 16-bit operand tier nobody measured on it.  The 1e-3 parity of fp16 / "high" is established
+    on default-init-like and N(0, 1 / fan_in) weights; a noise-amplifying checkpoint measured 2.5e-3 there and needs
+    "robust".  Fast3R.calibrate_precision(views[:8]) measures the tiers on the weights actually loaded (~2 s) and silences this."""
+    global _warned_uncalibrated
+    if _warned_uncalibrated or not getattr(net, "weights_loaded", False) or net.precision == "exact":
+        return
+    if hasattr(net, "precision_is_calibrated") and not net.precision_is_calibrated():
+        _warned_uncalibrated = True
+        warnings.warn(f"fast3r_amd.inference: this checkpoint runs with 16-bit operands (precision={net.precision!r}) and was never calibrated: the 1e-3 "
+                      "distance to the fp32 reference is measured on default-init-like weights, a noise-amplifying checkpoint can be 2-3 x further out.  "
+                      "Run `model.calibrate_precision(views[:8])` once (about 2 s; it reports every tier's distance to the fp32-equivalent mode on THESE "
+                      "weights and recommends the cheapest one within 1e-3: 'high' -> 'robust' costs about 2 x), or pass dtype='32'.", stacklevel=4)
+
+
 def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_batch=False, use_amp=False, ret=None,
                       profiling=False, host_outputs=False):
     """host_outputs (set by inference(), which returns everything on the CPU anyway): the predictions arrive in pinned host memory through
@@ -125,6 +141,7 @@ def loss_of_one_batch(batch, model, criterion, device, precision, symmetrize_bat
     net = getattr(model, "net", model)  # accept the MultiViewDUSt3RLitModule shim too
     saved = (net.compute_dtype, net.precision)
     net.compute_dtype, net.precision = _operand_format(precision, net, n_views=len(batch))
+    _warn_if_uncalibrated(net)
     try:
         kw = dict(host_outputs=True) if host_outputs else {}
         out = model(batch, profiling=profiling, **kw) if net is model else (net(batch, profiling=profiling, **kw))

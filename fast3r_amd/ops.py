@@ -64,6 +64,54 @@ def _sched_counter(dev):
     return t
 
 
+# Optional per-family timing of EVERY launch (bench.py's roofline.others): when OP_TIMER is a dict, each wrapper below brackets its C call with
+# events on the launch stream and appends (start, end, algorithmic FLOP, algorithmic HBM bytes) to OP_TIMER[family]; the family is OP_FAMILY (set by
+# the model around its phases: "transformer_linears", "head_convs", ...) or, for the bandwidth-bound wrappers, "elementwise".  None = no events.
+OP_TIMER = None
+OP_FAMILY = "other"
+
+
+class _timed:
+    __slots__ = ("fam", "flops", "nbytes", "e0")
+
+    def __init__(self, flops=0.0, nbytes=0.0, family=None):
+        self.fam = (family or OP_FAMILY) if OP_TIMER is not None else None
+        self.flops, self.nbytes = flops, nbytes
+
+    def __enter__(self):
+        if self.fam is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.fam is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            OP_TIMER.setdefault(self.fam, []).append((self.e0, e1, float(self.flops), float(self.nbytes)))
+        return False
+
+
+class family:
+    """`with ops.family("head_convs"):` -- the GEMM-like launches inside are booked under that family while OP_TIMER is on"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global OP_FAMILY
+        self.prev, OP_FAMILY = OP_FAMILY, self.name
+
+    def __exit__(self, *exc):
+        global OP_FAMILY
+        OP_FAMILY = self.prev
+        return False
+
+
+def _nb(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -154,7 +202,8 @@ def patchify(img: torch.Tensor, ps: int, lp: torch.dtype, ld_out: int = 0) -> to
     assert C == 3
     ld = ld_out if ld_out else 3 * ps * ps
     out = torch.empty((B * (H // ps) * (W // ps), ld), dtype=lp, device=img.device)
-    check(_lib.lib().f3r_patchify(ptr(img), ptr(out), B, H, W, ps, ld_out, dtype_id(lp), stream_ptr()), "f3r_patchify")
+    with _timed(0.0, _nb(img, out), "elementwise"):
+        check(_lib.lib().f3r_patchify(ptr(img), ptr(out), B, H, W, ps, ld_out, dtype_id(lp), stream_ptr()), "f3r_patchify")
     return out
 
 
@@ -167,8 +216,9 @@ def layernorm(x, gamma, beta, eps, lp, out_lp=None, out_f32=None, want_lp=True, 
         out_lp = torch.empty(x.shape, dtype=lp, device=x.device)
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty_like(x)
-    check(_lib.lib().f3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out_lp), ptr(out_f32), rows, D, float(eps),
-                                   int(rms), dtype_id(lp), stream_ptr()), "f3r_layernorm")
+    with _timed(0.0, _nb(x, out_lp, out_f32), "elementwise"):
+        check(_lib.lib().f3r_layernorm(ptr(x), ptr(gamma), ptr(beta), ptr(out_lp), ptr(out_f32), rows, D, float(eps),
+                                       int(rms), dtype_id(lp), stream_ptr()), "f3r_layernorm")
     return out_lp, out_f32
 
 
@@ -182,8 +232,9 @@ def layernorm_f8(x, gamma, beta, eps, out_rows=None, rms=False):
     if out_rows is None:
         out_rows = torch.empty((rows, 3 * D // 2), dtype=torch.float16, device=x.device)
     assert out_rows.dtype == torch.float16 and out_rows.stride(1) == 1 and out_rows.shape[1] == 3 * D // 2
-    check(_lib.lib().f3r_layernorm_f8(ptr(x), ptr(gamma), ptr(beta), ptr(out_rows), out_rows.stride(0), rows, D, float(eps), int(rms), stream_ptr()),
-          "f3r_layernorm_f8")
+    with _timed(0.0, _nb(x, out_rows), "elementwise"):
+        check(_lib.lib().f3r_layernorm_f8(ptr(x), ptr(gamma), ptr(beta), ptr(out_rows), out_rows.stride(0), rows, D, float(eps), int(rms), stream_ptr()),
+              "f3r_layernorm_f8")
     return out_rows
 
 
@@ -255,7 +306,8 @@ def gemm(a, w, *, K=None, bias=None, act=None, rowadd=None, rowadd_div=1, res_f3
     if w_scale is not None:
         g.w_scale = ptr(w_scale)
     g.out_lp_f8 = int(bool(out_f8_rows))
-    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
+    with _timed(2.0 * M * N * K):
+        check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm")
     if out_lp_lo is not None:
         return out_f32, out_lp, out_lp_lo
     return out_f32, out_lp
@@ -265,16 +317,20 @@ class BlockWorkspace:
     """The intermediates of a transformer block -- LN / attention output, q, k, V^T, MLP hidden -- as views of ONE allocation laid out by
     f3r_block_workspace_bytes (include/f3r.h): made once per encoder pass / decoder sample, reused by every block of it."""
 
-    def __init__(self, tokens, D, hidden, n_seq, seq_len, lp, device, kv_dim=None):
+    def __init__(self, tokens, D, hidden, n_seq, seq_len, lp, device, kv_dim=None, f8_rows=False):
+        """f8_rows: the pass runs GEMMs with the fp8 low plane (Fast3R.low_plane): the LayerNorm-output and hidden-state regions are sized for rows
+        [w fp16 | w fp8] (rows8 / hid8) and the plain 16-bit forms (h, hid) alias their heads (f3r_block_workspace_bytes_ex) -- no second copy of
+        either intermediate (~5 GB at N = 320, ~16 GB at N = 1500 on one GPU)."""
         kv_dim = D if kv_dim is None else kv_dim
         offs = (ctypes.c_size_t * 5)()
-        total = _lib.lib().f3r_block_workspace_bytes(tokens, D, kv_dim, hidden, n_seq, seq_len, offs)
+        f8_rows = bool(f8_rows) and lp == torch.float16 and D % 8 == 0 and hidden % 8 == 0
+        total = _lib.lib().f3r_block_workspace_bytes_ex(tokens, D, kv_dim, hidden, n_seq, seq_len, int(f8_rows), offs)
         if total == 0:
             raise ValueError(f"f3r_block_workspace_bytes: bad sizes ({tokens=}, {D=}, {hidden=}, {n_seq=}, {seq_len=})")
         self.buf = torch.empty((total,), dtype=torch.uint8, device=device)
         ld = vt_ld(seq_len)
 
-        def view(i, shape):
+        def view(i, shape, wide=False):
             n = 1
             for d in shape:
                 n *= d
@@ -284,18 +340,23 @@ class BlockWorkspace:
         if ld != seq_len and kv_dim:
             self.vt.zero_()  # the pad columns are read by the last key tile and never written by the QKV epilogue
         self.key = (tokens, D, hidden, n_seq, seq_len, lp, str(device))
-        self._rows8 = None
+        self._rows8 = view(0, (tokens, 3 * D // 2)) if f8_rows else None
+        self._hid8 = view(4, (tokens, 3 * hidden // 2)) if f8_rows else None
 
     def hid8(self):
-        """[tokens][3 hidden / 2]: the MLP hidden state as rows [hidden fp16 | hidden fp8] (fc1's GELU epilogue writes both, fc2 reads both)"""
-        if getattr(self, "_hid8", None) is None:
+        """[tokens][3 hidden / 2]: the MLP hidden state as rows [hidden fp16 | hidden fp8] (fc1's GELU epilogue writes both, fc2 reads both).  With
+        f8_rows it IS the hidden-state region (self.hid aliases its head: a pass uses one form or the other)."""
+        if self._hid8 is None:
             self._hid8 = torch.empty((self.hid.shape[0], 3 * self.hid.shape[1] // 2), dtype=torch.float16, device=self.buf.device)
         return self._hid8
 
     def rows8(self, D):
-        """[tokens][3 D / 2] float16-typed rows [D fp16 | D fp8] for the LayerNorm output of the fp8-low-plane GEMMs (made on first use)"""
+        """[tokens][3 D / 2] float16-typed rows [D fp16 | D fp8] for the LayerNorm output of the fp8-low-plane GEMMs.  With f8_rows it IS region 0:
+        self.h (the attention output) aliases its head -- the LayerNorm rows are dead once the QKV / fc1 launch that reads them has run, the
+        attention output is dead before the next LayerNorm writes."""
         if self._rows8 is None:
             self._rows8 = torch.empty((self.h.shape[0], 3 * D // 2), dtype=torch.float16, device=self.buf.device)
+        assert self._rows8.shape[1] == 3 * D // 2
         return self._rows8
 
 
@@ -340,7 +401,8 @@ def gemm_qkv(a, w, bias, q, k, vt, seq_len, rope=None, q_scale=0.0, rope_mode=0,
     g.kernel_sel = kernel_sel
     _split_operand(g, a, split, a_lo)
     g.dtype = dtype_id(lp)
-    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
+    with _timed(2.0 * M * N * K):
+        check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(qkv)")
 
 
 def silu_mul(ab, hidden, out=None):
@@ -349,7 +411,8 @@ def silu_mul(ab, hidden, out=None):
     assert ab.dim() == 2 and ab.shape[1] == 2 * hidden and ab.is_contiguous()
     if out is None:
         out = torch.empty((ab.shape[0], hidden), dtype=ab.dtype, device=ab.device)
-    check(_lib.lib().f3r_silu_mul(ptr(ab), ptr(out), ab.shape[0], hidden, dtype_id(ab.dtype), stream_ptr()), "f3r_silu_mul")
+    with _timed(0.0, _nb(ab, out), "elementwise"):
+        check(_lib.lib().f3r_silu_mul(ptr(ab), ptr(out), ab.shape[0], hidden, dtype_id(ab.dtype), stream_ptr()), "f3r_silu_mul")
     return out
 
 
@@ -402,7 +465,8 @@ def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, r
         g.res_lp2, g.ldr_lp2 = ptr(res_lp2), N
     g.out_lp, g.ldo_lp = ptr(out), N
     g.dtype = dtype_id(lp)
-    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(conv3x3)")
+    with _timed(2.0 * B * OH * OW * N * 9 * C):
+        check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(conv3x3)")
     if extra:
         extra["out"] = out
         return extra
@@ -428,7 +492,8 @@ def convT(x, w, bias_tiled, s, cout, split=None, x_lo=None, want_lo=False, kerne
     g.out_lp, g.ldo_lp = ptr(out), cout
     g.ct_s, g.ct_h, g.ct_w, g.ct_cout = s, h, wd, cout
     g.dtype = dtype_id(lp)
-    check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(convT)")
+    with _timed(2.0 * B * h * wd * s * s * cout * cin):
+        check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(convT)")
     return (out, out_lo) if want_lo else out
 
 
@@ -439,11 +504,12 @@ def attention_state(tq_total: int, n_heads: int, device, head_dim: int = 64):
 
 
 def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
-              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0, head_dim=64):
+              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0, head_dim=64, qk_planes=1):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][kv_heads*64][ldvt].  kv_group: query heads per K / V head (grouped-query attention).
     causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices).
-    kernel_sel: 0 = automatic, 1 = the general HIP kernel, 2 = the hand-scheduled kernel (include/f3r.h, f3r_attn_args.kernel_sel)."""
+    kernel_sel: 0 = automatic, 1 = the general HIP kernel, 2 = the hand-scheduled kernel (include/f3r.h, f3r_attn_args.kernel_sel).
+    qk_planes = 2: q and k rows hold [hi 64 | lo 64] per head (qkv_planes): three products per score block (precision "robust"; fp16, head_dim 64)."""
     require_gpu(q, "q")
     lp = q.dtype
     assert 1 <= len(segments) <= F3R_MAX_SEG
@@ -464,6 +530,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     a.kv_group, a.causal, a.q_pos0 = int(kv_group), int(bool(causal)), int(q_pos0)
     a.kernel_sel = int(kernel_sel)
     a.head_dim = int(head_dim)
+    a.qk_planes = int(qk_planes)
     if causal:
         pos = [0] * len(segments)
         if seg_pos0 is None:  # consecutive segments of one sequence starting at position 0
@@ -486,13 +553,45 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     if ATTN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().f3r_attn_fwd(ctypes.byref(a), stream_ptr()), "f3r_attn_fwd")
+    with _timed(4.0 * a.tq * sum(int(s_[2]) for s_ in segments) * head_dim * n_heads * batch, 0.0, "attention"):   # (algorithmic: one product per score)
+        check(_lib.lib().f3r_attn_fwd(ctypes.byref(a), stream_ptr()), "f3r_attn_fwd")
     if ATTN_TIMER is not None:
         e1.record()
         t_k = sum(int(s[2]) for s in segments)
         ATTN_TIMER.append((e0, e1, 4.0 * a.tq * t_k * head_dim * n_heads * batch, int(a.tq), int(t_k),
                            _lib.lib().f3r_attn_kernel_name(ctypes.byref(a)).decode()))
     return out
+
+
+def qkv_planes(qkv, n_heads, kv_heads, n_seq, seq_len, q_scale, lp):
+    """precision "robust": fp32 qkv [n_seq * seq_len][Dq + 2 Dkv] (rotary embedding applied) -> (q rows [T][n_heads * 128] = per head [hi 64 | lo 64] of
+    q * q_scale, k rows [T][kv_heads * 128], V^T [n_seq][kv_heads * 64][ldvt] one plane): the operands of attention(..., qk_planes=2)."""
+    require_gpu(qkv, "qkv")
+    assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[0] == n_seq * seq_len
+    T = qkv.shape[0]
+    qp = torch.empty((T, n_heads * 128), dtype=lp, device=qkv.device)
+    kp = torch.empty((T, kv_heads * 128), dtype=lp, device=qkv.device)
+    ld = vt_ld(seq_len)
+    vt = torch.empty((n_seq, kv_heads * 64, ld), dtype=lp, device=qkv.device)
+    with _timed(0.0, _nb(qkv, qp, kp, vt), "elementwise"):
+        check(_lib.lib().f3r_qkv_planes(ptr(qkv), qkv.stride(0), n_seq, seq_len, n_heads, kv_heads, float(q_scale), ptr(qp), ptr(kp), ptr(vt), ld, dtype_id(lp),
+                                        stream_ptr()), "f3r_qkv_planes")
+    return qp, kp, vt
+
+
+def attention_state_finish(state, n_heads, head_dim, lp, want_lo=True, want_f32=False):
+    """the parked online-softmax state of an attention launch (state_out) -> O / l as (hi, lo) lowp planes [T][n_heads * head_dim] [, fp32]"""
+    st_o, st_ml = state
+    require_gpu(st_o, "st_o")
+    T, D = st_o.shape[0], n_heads * head_dim
+    assert st_o.shape == (T, D) and st_ml.shape == (T, n_heads, 4) and st_o.is_contiguous() and st_ml.is_contiguous()
+    o_hi = torch.empty((T, D), dtype=lp, device=st_o.device)
+    o_lo = torch.empty((T, D), dtype=lp, device=st_o.device) if want_lo else None
+    o32 = torch.empty((T, D), dtype=torch.float32, device=st_o.device) if want_f32 else None
+    with _timed(0.0, _nb(st_o, st_ml, o_hi, o_lo, o32), "elementwise"):
+        check(_lib.lib().f3r_attn_state_finish(ptr(st_o), ptr(st_ml), T, n_heads, head_dim, ptr(o_hi), ptr(o_lo), ptr(o32), D, dtype_id(lp), stream_ptr()),
+              "f3r_attn_state_finish")
+    return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 
 def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
@@ -503,7 +602,8 @@ def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
     oh, ow = (2 * h, 2 * w) if out_hw is None else out_hw
     out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
     out_lo = torch.empty_like(out) if want_lo else None
-    check(_lib.lib().f3r_upsample2x(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
+    with _timed(0.0, _nb(x, x_lo, out, out_lo), "elementwise"):
+        check(_lib.lib().f3r_upsample2x(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
     return (out, out_lo) if want_lo else out
 
 
@@ -518,8 +618,9 @@ def interp_bilinear(x, full_hw, x_lo=None, want_lo=False):
     oh, ow = full_hw
     out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
     out_lo = torch.empty_like(out) if want_lo else None
-    check(_lib.lib().f3r_interp_bilinear(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, oh, ow, dtype_id(x.dtype), stream_ptr()),
-          "f3r_interp_bilinear")
+    with _timed(0.0, _nb(x, x_lo, out, out_lo), "elementwise"):
+        check(_lib.lib().f3r_interp_bilinear(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, oh, ow, dtype_id(x.dtype), stream_ptr()),
+              "f3r_interp_bilinear")
     return (out, out_lo) if want_lo else out
 
 
@@ -542,8 +643,9 @@ def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.
             raise ValueError(f"bad mode={conf_mode[0]!r}")  # :64
         conf = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
         cmode, vmin, vmax = CONF_MODES[conf_mode[0]], float(conf_mode[1]), float(conf_mode[2])
-    check(_lib.lib().f3r_dpt_final(ptr(x), ptr(x_lo), ptr(w), ptr(b), n_out, ptr(pts), ptr(conf), B * H * W, Cin, DEPTH_MODES[dmode], cmode,
-                                   vmin, vmax, dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
+    with _timed(2.0 * B * H * W * Cin * n_out, _nb(x, x_lo, pts, conf), "elementwise"):
+        check(_lib.lib().f3r_dpt_final(ptr(x), ptr(x_lo), ptr(w), ptr(b), n_out, ptr(pts), ptr(conf), B * H * W, Cin, DEPTH_MODES[dmode], cmode,
+                                       vmin, vmax, dtype_id(x.dtype), stream_ptr()), "f3r_dpt_final")
     return pts, conf
 
 
@@ -619,5 +721,6 @@ def cast_lp(x, lp, out=None, want_lo=False):
     if out is None:
         out = torch.empty(x.shape, dtype=lp, device=x.device)
     out_lo = torch.empty(x.shape, dtype=lp, device=x.device) if want_lo else None
-    check(_lib.lib().f3r_cast_f32_to_lp(ptr(x), ptr(out), ptr(out_lo), x.numel(), dtype_id(lp), stream_ptr()), "f3r_cast_f32_to_lp")
+    with _timed(0.0, _nb(x, out, out_lo), "elementwise"):
+        check(_lib.lib().f3r_cast_f32_to_lp(ptr(x), ptr(out), ptr(out_lo), x.numel(), dtype_id(lp), stream_ptr()), "f3r_cast_f32_to_lp")
     return (out, out_lo) if want_lo else out

@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 330 = 0.3.3, round 5 (f3r_attn_args.dbg_counters is uint32[8] incl. two clock sums; f3r_wall_clock_khz); 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
+int f3r_version(void);  /* 340 = 0.3.4, round 6 (+ f3r_block_workspace_bytes_ex; the library clears sched_counter per launch); 330 = 0.3.3, round 5 (f3r_attn_args.dbg_counters is uint32[8] incl. two clock sums; f3r_wall_clock_khz); 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
@@ -205,6 +205,11 @@ int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
  * MLP hidden (lowp [tokens][hidden]) }.  Returns 0 on bad arguments.
  */
 size_t f3r_block_workspace_bytes(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, size_t offsets[5]);
+/* ABI 340: the same layout for passes that run the F3R_SPLIT_W2F8 GEMMs (f8_rows != 0): regions 0 and 4 are sized for rows [w fp16 | w fp8]
+   (3 w bytes per row, w = D / hidden; both multiples of 8) -- what f3r_layernorm_f8 and the GELU epilogue (out_lp_f8) write -- and the plain
+   [tokens][w] 16-bit forms of the same intermediates (attention output; a hidden state kept on fp16 planes) alias the head of those regions: the
+   wide and the plain form of a region are never live at the same time inside a block.  f8_rows = 0 is f3r_block_workspace_bytes. */
+size_t f3r_block_workspace_bytes_ex(int64_t tokens, int D, int kv_dim, int hidden, int64_t n_seq, int64_t seq_len, int f8_rows, size_t offsets[5]);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_attn_fwd: O = softmax(scale * Q K^T) V, head_dim 64 (other widths: f3r_attn_args.head_dim), flash-style (never forms
@@ -288,6 +293,14 @@ typedef struct f3r_attn_args {
      items from `next`: the hardware deals workgroup ids round-robin over the 8 XCDs whatever their clocks (up to 6 % apart under the power
      cap), which left the faster XCDs idle for ~2.4 % of every fusion-attention launch (profiles/r05_*per_xcd*).  Other launches ignore it. */
   uint32_t* sched_counter;
+  /* Operand planes of Q and K (ABI 340, precision "robust"): 0 / 1 = one 16-bit number per element, as described above.  2 = every head of a q row
+     and of a K row holds [hi (64) | lo (64)] fp16 (x = hi + lo to ~22 bits; f3r_qkv_planes writes such rows): ldq / ldk / the batch strides count
+     elements of these 128-wide heads (ldq >= n_heads * 128), and the scores are q_hi k_hi + q_lo k_hi + q_hi k_lo with fp32 accumulation -- three
+     MFMA products per score block, P V unchanged (V^T, o, the parked state: head_dim 64 layouts).  Only the hand-scheduled kernel
+     f3r_attn_asm_qk3_f16 reads this layout (csrc/asm/attn_gen.py AttnGen(qk_planes = 2): 256-query workgroups): fp16, head_dim 64, q_prescaled, and
+     the eligibility rules of kernel_sel 0 with tq >= 64 and no minimum number of keys -- anything else is F3R_ERR_UNSUPPORTED, never a fallback. */
+  int32_t qk_planes;
+  int32_t reserved0;
 } f3r_attn_args;
 #define F3R_ATTN_ASM_MIN_KEYS 2048
 
@@ -454,6 +467,23 @@ int f3r_attn_f32_ex(const f3r_attn_f32_args* args, f3r_stream_t stream);
  * mask: f3r_attn_f32_mfma_workspace returns 0 for anything else, and the bytes of caller-owned scratch (the planes of q, k and V^T) otherwise. */
 int64_t f3r_attn_f32_mfma_workspace(const f3r_attn_f32_args* args);
 int f3r_attn_f32_mfma(const f3r_attn_f32_args* args, void* workspace, int64_t workspace_bytes, f3r_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * precision "robust" (ABI 340) -- between "high" (every operand one fp16 number, weights hi + lo) and "exact": every GEMM / conv as in "exact"
+ * (F3R_SPLIT_X3), the attention core (blocks.py:158-190) with Q and K as hi + lo planes (f3r_attn_args.qk_planes = 2: three products per score
+ * block) and P, V single fp16 -- the cheapest operand set that keeps a noise-amplifying checkpoint within 1e-3 of the fp32 path
+ * (oracle/precision_study.py --study robust_vitl).  The two passes around that attention launch:
+ * f3r_qkv_planes: qkv fp32 [n_seq * seq_len][ld] = q | k | v column blocks of n_heads * 64 | kv_heads * 64 | kv_heads * 64 (the output of the QKV
+ *   projection; rotary embedding already applied) -> q_planes [rows][n_heads][hi 64 | lo 64] (values multiplied by q_scale = softmax scale x
+ *   log2(e) BEFORE the split), k_planes [rows][kv_heads][hi 64 | lo 64], vt [n_seq][kv_heads * 64][ldvt] one plane (key columns >= seq_len zero).
+ * f3r_attn_state_finish: the state an attention launch parked (f3r_attn_args.state_out: st_o fp32 [rows][n_heads * head_dim] un-normalised,
+ *   st_ml fp32 [rows][n_heads][4] = {m, l of lane half 0, of lane half 1, -}) -> O / (l0 + l1) as hi + lo planes [rows][ldo] (the A operand of the
+ *   X3 output projection; o_lo may be NULL) and / or fp32 (o_f32).
+ */
+int f3r_qkv_planes(const float* qkv, int64_t ld, int64_t n_seq, int64_t seq_len, int n_heads, int kv_heads, float q_scale, void* q_planes, void* k_planes,
+                   void* vt, int64_t ldvt, int dtype, f3r_stream_t stream);
+int f3r_attn_state_finish(const float* st_o, const float* st_ml, int64_t rows, int n_heads, int head_dim, void* o_hi, void* o_lo, float* o_f32,
+                          int64_t ldo, int dtype, f3r_stream_t stream);
 
 #ifdef __cplusplus
 }

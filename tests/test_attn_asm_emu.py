@@ -146,3 +146,26 @@ def test_emulated_work_stealing_form_computes_every_item_and_leaves_the_counter_
     err = emu_attn.run_case(kw.get("dtype", "f16"), kw["tiles"], n_heads=kw["n_heads"], wgs=kw["wgs"], tq=kw["tq"], split_state=kw.get("split", False),
                             steal=kw["steal"], head_dim=kw.get("head_dim", 64))
     assert err < 6e-4
+
+
+@pytest.mark.parametrize("kw", [dict(n_tiles=1), dict(n_tiles=3), dict(n_tiles=6, spike=True), dict(n_tiles=[2, 1, 3], spike=True), dict(n_tiles=[2, 3], split_state=True),
+                                dict(tq=300, q_blocks=2, wgs=((1, 0, 0), (0, 1, 0))), dict(tq=64, wgs=((0, 0, 0),), n_tiles=2),
+                                dict(kv_shift=1, n_heads=4, batch=2, wgs=((0, 3, 1),)), dict(tq=700, n_heads=1, n_tiles=[1, 1], split_state=True, wgs=((0, 0, 0), (2, 0, 0)), steal=3)])
+def test_emulated_three_product_form(kw):
+    """AttnGen(qk_planes=2) (round 6, precision "robust"; f3r_attn_args.qk_planes): Q and K rows hold [hi | lo] fp16 planes per head and every score
+    block is q_hi k_hi + q_lo k_hi + q_hi k_lo (twelve MFMA k-steps, fp32 accumulate); P V is the head_dim-64 form.  Two query blocks per wave like
+    the head_dim-80 / 128 kernels: tiles, segments, the two-launch state form, partial workgroups, grouped heads + batch, work stealing.  The
+    reference is float64 on hi + lo."""
+    import emu_attn
+    assert emu_attn.run_case(qk_planes=2, **kw) < 6e-4
+
+
+def test_emulated_three_product_form_uses_its_low_planes():
+    """the kernel really multiplies its low planes: its output is closer to the float64 softmax of hi + lo than to the one computed from the hi planes
+    alone (a kernel that ignored them would sit at the latter, one rounding of P away), and the two references are further apart than the kernel
+    is from the right one"""
+    import emu_attn
+    errs = []
+    emu_attn.run_case(qk_planes=2, n_tiles=4, n_heads=2, wgs=((0, 1, 0),), spike=True, errs=errs)
+    err, one_product_distance, err_vs_one_product = errs[0]
+    assert err < 6e-4 and one_product_distance > 1.5 * err and err_vs_one_product > 1.5 * err, errs

@@ -109,7 +109,7 @@ def test_vit_large_depth_with_heavy_tailed_weights_vs_cpu_oracle(built_lib):
         O.ATTN_IMPL = "naive"
     gv = views_to(views, DEV)
     report = {}
-    for dt, precision in ((torch.float16, "high"), (torch.float16, "fast"), (torch.bfloat16, "fast"), (torch.float16, "exact")):
+    for dt, precision in ((torch.float16, "high"), (torch.float16, "robust"), (torch.float16, "fast"), (torch.bfloat16, "fast"), (torch.float16, "exact")):
         m = Fast3R(enc, dec, head, compute_dtype=dt, precision=precision).eval()
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV)
@@ -120,9 +120,12 @@ def test_vit_large_depth_with_heavy_tailed_weights_vs_cpu_oracle(built_lib):
         print(f"[parity] ViT-L HEAVY-TAILED N=3 512^2 {dt} {precision} vs CPU oracle: " + ", ".join(f"{k}={v:.2e}" for k, v in w.items()))
         del m, out
         torch.cuda.empty_cache()
-    hi, fast, exact = (max(report[("float16", p)].values()) for p in ("high", "fast", "exact"))
+    hi, fast, exact, robust = (max(report[("float16", p)].values()) for p in ("high", "fast", "exact", "robust"))
     assert exact <= 3e-5, report
     assert hi <= fast and hi <= 5e-3, report
+    # round 6: precision "robust" (linear layers X3, Q K^T from hi + lo planes on f3r_attn_asm_qk3_f16) is the 16-bit-operand tier that DOES hold the
+    # bar on this distribution (CPU emulation of the same operand set: 3.6e-4, oracle/precision_study.py --study robust_vitl)
+    assert robust <= TOL, report
 
 
 def test_vit_large_n100_stress_weights_vs_fp32_equivalent_path(built_lib):

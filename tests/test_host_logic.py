@@ -408,3 +408,47 @@ def test_magic_number_division_is_exact_under_the_bound_the_launchers_check():
             assert (a * magic(d)) >> 32 == a // d, (a, d)
     # beyond it the trick does break: d = 3, a = 2^31 (a * d = 1.5 x 2^32) comes out one too high
     assert ((1 << 31) * magic(3)) >> 32 == (1 << 31) // 3 + 1
+
+
+def test_uncalibrated_checkpoint_warning_logic():
+    """round 6: `inference()` warns ONCE when a LOADED checkpoint runs a 16-bit operand tier that Fast3R.calibrate_precision() never measured on
+    those weights (the 1e-3 parity of fp16 / "high" is a statement about default-init-like weights: DESIGN.md section 3); a freshly constructed
+    model, the fp32-equivalent mode and a calibrated model stay silent; new weights make the calibration stale."""
+    import warnings
+    from fast3r_amd import inference_multiview as im
+    m = Fast3R(*tiny_args())
+    assert m.weights_loaded is False and m.calibration is None and "robust" in m.PRECISION_TIERS
+    assert Fast3R(*tiny_args(), precision="robust").precision == "robust"
+
+    def warned(net):
+        im._warned_uncalibrated = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            im._warn_if_uncalibrated(net)
+        return any("calibrate_precision" in str(x.message) for x in w)
+    assert not warned(m)                                   # default init: nothing was loaded
+    m.load_state_dict(m.state_dict())
+    assert m.weights_loaded and warned(m)                  # a checkpoint, never calibrated
+    assert not im._warned_uncalibrated is False and not _second_warning(im, m)   # ... once per process
+    m.precision = "exact"
+    assert not warned(m)                                   # the fp32-equivalent mode needs no calibration
+    m.precision = "high"
+    m.calibration = dict(recommended="high", params_version=m._params_version())
+    assert m.precision_is_calibrated() and not warned(m)
+    m.calibration = dict(recommended="robust", params_version=m._params_version())
+    assert not m.precision_is_calibrated() and warned(m)   # calibrated, but running a cheaper tier than recommended
+    m.precision = "robust"
+    assert m.precision_is_calibrated()
+    with torch.no_grad():
+        next(m.parameters()).add_(1.0)                     # the weights changed: the report is about other weights
+    assert not m.precision_is_calibrated()
+    m.load_state_dict(m.state_dict())
+    assert m.calibration is None
+
+
+def _second_warning(im, net):
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        im._warn_if_uncalibrated(net)
+    return len(w) > 0

@@ -70,7 +70,7 @@ def test_integration_md_binding_runs_and_matches_the_library(built_lib, tmp_path
     doc_struct = ns["F3RAttnArgs"]
     assert built_lib.f3r_sizeof(1) == ctypes.sizeof(doc_struct) == ctypes.sizeof(_lib.AttnArgs)
     offs = _check_struct(tmp_path, "f3r_attn_args", doc_struct)
-    assert offs["sched_counter"] == 592 and offs["sizeof"] == 600   # ABI 330
+    assert offs["sched_counter"] == 592 and offs["qk_planes"] == 600 and offs["sizeof"] == 608   # ABI 340
     # same field list, same order as the product's own binding
     assert [f[0] for f in doc_struct._fields_] == [f[0] for f in _lib.AttnArgs._fields_]
     assert callable(ns["sdpa_f3r"])

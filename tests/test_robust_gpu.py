@@ -1,0 +1,203 @@
+"""precision "robust" (round 6): the tier between "high" (8.9 s at N = 320) and "exact" (36 s) for checkpoints that amplify
+rounding noise.  oracle/precision_study.py --study robust_vitl priced the operand sets on ViT-L with heavy-tailed weights (N = 3, 512^2; worst
+output): every operand one fp16 number 2.5e-3, linear layers X3 alone 1.3e-3, attention exact alone 1.6e-3, **linear layers X3 + Q K^T from hi + lo
+planes (three products), P V one fp16 product: 3.6e-4** -- the cheapest set under the 1e-3 bar, and what this mode runs:
+
+  * every GEMM / conv as in "exact" (F3R_SPLIT_X3);
+  * the fusion attention on f3r_attn_asm_qk3_f16 (csrc/asm/attn_gen.py AttnGen(qk_planes = 2)): q, k rows [hi 64 | lo 64] per head written by
+    f3r_qkv_planes, S = q_hi k_hi + q_lo k_hi + q_hi k_lo, softmax / P V as in the head_dim-64 kernel, output through the parked state and
+    f3r_attn_state_finish as hi + lo planes;
+  * attention launches that kernel cannot take (the encoder's per-view sequences, odd token counts) run the fp32 attention of "exact".
+
+Kernel level: against fp64 on the kernel's own planes; model level: tiny model with heavy-tailed weights against the CPU oracle, and the ViT-L
+case of tests/test_depth_parity_gpu.py asserts robust <= 1e-3.  Reference: fast3r/croco/models/blocks.py:158-190."""
+import math
+
+import pytest
+import torch
+
+from fast3r_amd import Fast3R, ops
+from fast3r_amd.synthetic import make_views, synth_state_dict, tiny_args
+from helpers import rel_l2, views_to
+from oracle import fast3r_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOG2E = 1.4426950408889634
+
+
+def _qkv(T, H, Hkv, seed, amp=1.5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((T, (H + 2 * Hkv) * 64), generator=g) * amp
+
+
+def _softmax_ref(q64, k64, v64, H, Hkv):
+    """q64 (pre-scaled, base-2 logits), k64, v64 float64 [T][heads * 64] -> float64 [Tq][H * 64]"""
+    Tq = q64.shape[0]
+    qh = q64.reshape(Tq, H, 64).transpose(0, 1)
+    kh = k64.reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    vh = v64.reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
+    s = (qh @ kh.transpose(1, 2)) * math.log(2.0)
+    return (s.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+def _split(x32):
+    hi = x32.to(torch.float16)
+    lo = (x32 - hi.float()).to(torch.float16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("T,H,Hkv", [(64, 2, 2), (4096, 4, 4), (3072 + 64, 3, 3), (2048, 8, 2), (20480, 16, 16)])
+def test_qkv_planes_three_product_attention_and_state_finish(built_lib, T, H, Hkv):
+    """f3r_qkv_planes -> f3r_attn_fwd(qk_planes = 2, state_out) -> f3r_attn_state_finish on one sequence of T tokens.  (a) the planes are the exact
+    split of the scaled fp32 values, V^T is the rounded transpose with zero padding; (b) the attention output equals float64 softmax on hi + lo to
+    the rounding of P / V / the output planes; (c) it is CLOSER to the fp32 inputs' softmax than the one-product kernel on the same inputs."""
+    scale = 0.160192
+    qkv = _qkv(T, H, Hkv, 7 + T)
+    qd = qkv.to(DEV)
+    qp, kp, vt = ops.qkv_planes(qd, H, Hkv, 1, T, scale * LOG2E, torch.float16)
+    Dq, Dk = H * 64, Hkv * 64
+    q32, k32, v32 = qkv[:, :Dq] * (scale * LOG2E), qkv[:, Dq:Dq + Dk], qkv[:, Dq + Dk:]
+    q_hi, q_lo = _split(q32)
+    k_hi, k_lo = _split(k32)
+    qpc, kpc = qp.cpu().view(T, H, 2, 64), kp.cpu().view(T, Hkv, 2, 64)
+    assert torch.equal(qpc[:, :, 0].reshape(T, Dq), q_hi) and torch.equal(qpc[:, :, 1].reshape(T, Dq), q_lo)
+    assert torch.equal(kpc[:, :, 0].reshape(T, Dk), k_hi) and torch.equal(kpc[:, :, 1].reshape(T, Dk), k_lo)
+    vtc = vt.cpu()[0]
+    assert torch.equal(vtc[:, :T], v32.to(torch.float16).t()) and not vtc[:, T:].any()
+    state = ops.attention_state(T, H, DEV)
+    ops.ATTN_TIMER = []
+    try:
+        ops.attention(qp, state[0], H, scale, [(kp, vt.view(Dk, vt.shape[-1]), T, 0, 0)], q_prescaled=True, state=state, state_out=True, kv_group=H // Hkv,
+                      qk_planes=2, kernel_sel=2)
+        names = [r[5] for r in ops.ATTN_TIMER]
+    finally:
+        ops.ATTN_TIMER = None
+    assert all("f3r_attn_asm_qk3_f16" in n for n in names), names
+    o_hi, o_lo, o32 = ops.attention_state_finish(state, H, 64, torch.float16, want_f32=True)
+    torch.cuda.synchronize()
+    got = o_hi.double().cpu() + o_lo.double().cpu()
+    assert float((got - o32.double().cpu()).abs().max()) <= 2.0 ** -20 * float(o32.abs().max())          # the planes carry the fp32 result to ~22 bits
+    v16 = v32.to(torch.float16).double()
+    ref_planes = _softmax_ref(q_hi.double() + q_lo.double(), k_hi.double() + k_lo.double(), v16, H, Hkv)
+    e_planes = float((got - ref_planes).abs().max() / ref_planes.abs().max())
+    assert e_planes <= 2.0 ** -9, e_planes                                                                  # P is rounded to fp16 before P V
+    # (c) against the softmax of the UNROUNDED q, k (V rounded once in both kernels): three products vs one
+    ref_true = _softmax_ref(q32.double(), k32.double(), v16, H, Hkv)
+    one = torch.empty((T, Dq), dtype=torch.float16, device=DEV)
+    vt1 = torch.zeros((Dk, ops.vt_ld(T)), dtype=torch.float16, device=DEV)
+    vt1[:, :T] = v32.to(torch.float16).t().to(DEV)
+    ops.attention(q_hi.to(DEV), one, H, scale, [(k_hi.to(DEV), vt1, T, 0, 0)], q_prescaled=True, kv_group=H // Hkv)
+    e3 = rel_l2(got, ref_true)
+    e1 = rel_l2(one.double().cpu(), ref_true)
+    print(f"[robust] T={T} H={H}/{Hkv}: three products {e3:.2e}, one product {e1:.2e} (rel-L2 vs the softmax of the fp32 q, k)")
+    assert e3 < 0.6 * e1, (e3, e1)
+
+
+def test_three_product_kernel_segments_and_resumed_state(built_lib):
+    """K / V^T as three segments in one launch == one launch over the concatenation, bit for bit (same tiles, same order); local launch (state_out) +
+    remote launch (state_in) -- the sharded form -- equals them up to the rounding of the resumed launch's first half tile, which goes through the
+    re-base path (tests/test_attn_asm_gpu.py::test_asm_kernel_segments_and_carried_state holds the one-product kernel to the same bar)"""
+    T, H = 2048, 4
+    qkv = _qkv(T, H, H, 3).to(DEV)
+    qp, kp, vt = ops.qkv_planes(qkv, H, H, 1, T, 0.125 * LOG2E, torch.float16)
+    D = H * 64
+    cuts = [(0, 512), (512, 1280), (1280, 2048)]
+    segs = []
+    for a, b in cuts:
+        v = torch.zeros((D, 768), dtype=torch.float16, device=DEV)     # one ldvt for all segments (the exchange buffers' layout)
+        v[:, :b - a] = vt[0][:, a:b]
+        segs.append((kp[a:b], v, b - a, 0, 0))
+
+    def launch(sg, **kw):
+        st = kw.pop("state", None) or ops.attention_state(T, H, DEV)
+        ops.attention(qp, st[0], H, 0.125, sg, q_prescaled=True, state=st, qk_planes=2, kernel_sel=2, **kw)
+        return st
+    full = launch([(kp, vt.view(D, -1), T, 0, 0)], state_out=True)
+    one = launch(segs, state_out=True)
+    two = launch(segs[:1], state_out=True)
+    launch(segs[1:], state=two, state_in=True, state_out=True)
+    torch.cuda.synchronize()
+    fo = ops.attention_state_finish(full, H, 64, torch.float16)
+    oo = ops.attention_state_finish(one, H, 64, torch.float16)
+    to = ops.attention_state_finish(two, H, 64, torch.float16)
+    assert torch.equal(fo[0], oo[0]) and torch.equal(fo[1], oo[1])    # same tiles in the same order
+    a, b = oo[0].double() + oo[1].double(), to[0].double() + to[1].double()
+    assert float((a - b).abs().max()) <= 2.0 ** -10 * float(a.abs().max())
+
+
+def test_three_product_form_refuses_what_it_cannot_take(built_lib):
+    T, H = 256, 2
+    qkv = _qkv(T, H, H, 5).to(DEV)
+    qp, kp, vt = ops.qkv_planes(qkv, H, H, 1, T, 0.2, torch.float16)
+    st = ops.attention_state(T, H, DEV)
+    with pytest.raises(ValueError, match="qk_planes 2"):      # the general HIP kernel does not read the plane layout
+        ops.attention(qp, st[0], H, 0.125, [(kp, vt.view(H * 64, -1), T, 0, 0)], q_prescaled=True, state=st, state_out=True, qk_planes=2, kernel_sel=1)
+    with pytest.raises(ValueError, match="qk_planes 2"):      # bf16 planes: no such kernel
+        ops.attention(qp.view(torch.bfloat16), st[0], H, 0.125, [(kp.view(torch.bfloat16), vt.view(H * 64, -1).view(torch.bfloat16), T, 0, 0)], q_prescaled=True,
+                      state=st, state_out=True, qk_planes=2)
+    with pytest.raises(ValueError, match="qk_planes 2"):      # q not pre-scaled
+        ops.attention(qp, st[0], H, 0.125, [(kp, vt.view(H * 64, -1), T, 0, 0)], state=st, state_out=True, qk_planes=2)
+
+
+def test_tiny_model_with_heavy_tailed_weights_robust_vs_oracle(built_lib):
+    """4 views of 64 x 64 = 64 fusion tokens (a whole key tile: the three-product kernel runs, asserted from the launch records), heavy-tailed
+    weights (synthetic.py dist="heavy").  The tiny network amplifies rounding ~2x more than ViT-L does (oracle/precision_study.py --study robust: this
+    operand set 2.0e-3 where "high" gives 5.4e-3; on ViT-L 3.6e-4 against 2.5e-3, asserted <= 1e-3 in tests/test_depth_parity_gpu.py): here the bar is
+    "at least twice as close as high, within 3e-3"; "exact" is the anchor."""
+    enc, dec, head = tiny_args()
+    shapes = {k: tuple(v.shape) for k, v in Fast3R(enc, dec, head).state_dict().items()}
+    sd = synth_state_dict(shapes, 0, dist="heavy")
+    views = make_views(4, 64, 64)
+    with torch.no_grad():
+        torch.manual_seed(1234)
+        ref = O.forward(views, sd, enc, dec, head)
+    gv = views_to(views, DEV)
+    worst = {}
+    for precision in ("high", "robust", "exact"):
+        m = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision=precision).eval()
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV)
+        ops.ATTN_TIMER = []
+        try:
+            with torch.no_grad():
+                torch.manual_seed(1234)
+                out = m(gv)
+            names = {r[5] for r in ops.ATTN_TIMER}
+        finally:
+            ops.ATTN_TIMER = None
+        if precision == "robust":
+            assert any("f3r_attn_asm_qk3_f16" in n for n in names), names
+        worst[precision] = max(rel_l2(o[k].cpu(), r[k]) for o, r in zip(out, ref) for k in r)
+    print("[parity] tiny HEAVY-TAILED 4 x 64^2 vs CPU oracle: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+    assert worst["exact"] <= 5e-5 and worst["robust"] <= 3e-3 and worst["robust"] < 0.5 * worst["high"], worst
+
+
+def test_calibrate_precision_reports_every_tier_and_recommends_the_cheapest_within_tol(built_lib):
+    """Fast3R.calibrate_precision (round 6): on the caller's views and the weights the model holds, every 16-bit tier against the fp32-equivalent mode;
+    the recommendation is the cheapest tier within tol; the model's own precision, its RNG state and its graphs setting are left as they were; the
+    report goes stale when the weights change."""
+    enc, dec, head = tiny_args()
+    shapes = {k: tuple(v.shape) for k, v in Fast3R(enc, dec, head).state_dict().items()}
+    views = views_to(make_views(4, 64, 64), DEV)
+    for dist, expect in (("default", ("fast",)), ("heavy", ("robust", "exact"))):
+        m = Fast3R(enc, dec, head).eval()
+        m.load_state_dict(synth_state_dict(shapes, 0, dist=dist), strict=True)
+        m = m.to(DEV)
+        assert not m.precision_is_calibrated()
+        torch.manual_seed(5)
+        before = torch.get_rng_state()
+        rep = m.calibrate_precision(views)
+        assert torch.equal(before, torch.get_rng_state()) and m.precision == "high" and m.calibration is rep
+        assert set(rep["per_tier"]) == {"fast", "high", "robust"} and rep["n_views"] == 4 and rep["tol"] == 1e-3
+        w = rep["worst"]
+        print(f"[calibrate] tiny {dist}: " + ", ".join(f"{k}={v:.2e}" for k, v in w.items()) + f" -> {rep['recommended']}")
+        assert w["robust"] <= w["high"] <= w["fast"] * 1.05 and all(math.isfinite(v) for v in w.values())
+        assert rep["recommended"] in expect, rep
+        cheaper = [t for t in ("fast", "high", "robust") if t != rep["recommended"] and m.PRECISION_TIERS.index(t) < m.PRECISION_TIERS.index(rep["recommended"])]
+        assert all(w[t] > 1e-3 for t in cheaper)
+        m.precision = rep["recommended"]
+        assert m.precision_is_calibrated()
+        with torch.no_grad():
+            next(m.parameters()).mul_(1.0)
+        assert not m.precision_is_calibrated()   # the weights' version counter moved: the report is about other weights

@@ -35,15 +35,17 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2).  steal = G > 0: the work-stealing form -- G
     persistent workgroups share the launch's {next, done} counter (emulated one after the other: the first one takes every item, the others
-    find the counter exhausted, the last one to leave zeroes it); `wgs` then lists the work items whose output is compared."""
+    find the counter exhausted, the last one to leave zeroes it); `wgs` then lists the work items whose output is compared.
+    qk_planes = 2: the three-product form (AttnGen(qk_planes=2), precision "robust"): Q and K rows hold [hi (64) | lo (64)] fp16 per head; the reference
+    is float64 on hi + lo; errs (a list) also receives the distance to the reference computed from the hi planes alone (what one product gives)."""
     rng = np.random.default_rng(seed)
     HD = head_dim
-    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
+    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, qk_planes=qk_planes, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
     WQ = g.WG_Q   # query rows of a workgroup (512 at head_dim 64, 256 otherwise)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
     tq, tk = (WQ * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
@@ -59,6 +61,21 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         k[:, tk - 40, :] = q[:, 7, :Dk] * 3.0 if kv_shift == 0 else k[:, tk - 40, :] * 6.0
     qh = f32_to_half(q * (scale * LOG2E), dtype)            # pre-scaled, as the QKV epilogue writes it
     kh = f32_to_half(k, dtype)
+    DQ, DKm = D, Dk                                          # widths of a q / k row in memory
+    q_ref, k_ref = qh, kh
+    if qk_planes == 2:   # rows [hi | lo] per head: lo = half(x - float(hi))
+        def planes(x32, heads):
+            hi = f32_to_half(x32, dtype)
+            lo = f32_to_half(x32 - half_to_f32(hi, dtype), dtype)
+            out = np.empty(x32.shape[:2] + (heads, 2, HD), np.uint16)
+            out[:, :, :, 0] = hi.reshape(x32.shape[:2] + (heads, HD))
+            out[:, :, :, 1] = lo.reshape(x32.shape[:2] + (heads, HD))
+            return out.reshape(x32.shape[:2] + (heads * 2 * HD,)), hi, lo
+        qmem, q_hi, q_lo = planes(q * (scale * LOG2E), n_heads)
+        kmem, k_hi, k_lo = planes(k, kv_heads)
+        q_ref, k_ref = (q_hi, q_lo), (k_hi, k_lo)
+        qh, kh = qmem, kmem
+        DQ, DKm = 2 * D, 2 * Dk
     ldvt = 64 * max(seg_tiles)
     mem = Memory()
     a_q = mem.alloc(qh)
@@ -81,15 +98,15 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     nx = -(-tq // WQ)
     a_sched = mem.alloc(np.zeros(2, np.uint32)) if steal else 0
     sched_kw = dict(sched=a_sched, n_work=nx * n_heads * batch, nx=nx, nxy=nx * n_heads, grid=steal) if steal else {}
-    common = dict(dbg=a_dbg, q_bs=tq * D * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * Dk * 2, vt_bs=Dk * ldvt * 2,
+    common = dict(dbg=a_dbg, q_bs=tq * DQ * 2, o_bs=tq * D * 2, kv_shift=kv_shift, st_o=st_o, st_ml=st_ml, k_bs=segs[0][3] * DKm * 2, vt_bs=Dk * ldvt * 2,
                   st_o_ld=D * 4, st_ml_ld=n_heads * 16, tq=tq, **sched_kw)
     launches = []
     if split_state:
         assert len(segs) >= 2 and batch == 1
-        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[:1]], flags=attn_gen.FLAG_STATE_OUT, **common))
-        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
+        launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs[:1]], flags=attn_gen.FLAG_STATE_OUT, **common))
+        launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
     else:
-        launches.append(pack_args(a_q, a_o, D * 2, Dk * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
+        launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
     prog = g.build()
     problems = prog.check_hazards()
     assert not problems, "\n".join(problems[:20])
@@ -112,14 +129,26 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         x, head, b = wg
         kvh = head >> kv_shift
         r1 = min(tq, (x + 1) * WQ)
-        qf = half_to_f32(qh[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
-        kf = half_to_f32(kh[b, :, kvh * HD:(kvh + 1) * HD], dtype).astype(np.float64)
+        def f64(t, rows, hh):
+            return half_to_f32(t[b, rows, hh * HD:(hh + 1) * HD], dtype).astype(np.float64)
+        rows_q, all_k = slice(x * WQ, r1), slice(None)
         vf = half_to_f32(vth_all[b, kvh * HD:(kvh + 1) * HD, :], dtype).astype(np.float64).T
-        s = qf @ kf.T
-        p = np.exp2(s - s.max(axis=1, keepdims=True))
-        ref = (p @ vf) / p.sum(axis=1, keepdims=True)
+
+        def softmax_ref(qf, kf):
+            s = qf @ kf.T
+            p = np.exp2(s - s.max(axis=1, keepdims=True))
+            return (p @ vf) / p.sum(axis=1, keepdims=True)
+        if qk_planes == 2:
+            qf = f64(q_ref[0], rows_q, head) + f64(q_ref[1], rows_q, head)
+            kf = f64(k_ref[0], all_k, kvh) + f64(k_ref[1], all_k, kvh)
+        else:
+            qf, kf = f64(q_ref, rows_q, head), f64(k_ref, all_k, kvh)
+        ref = softmax_ref(qf, kf)
         got = half_to_f32(og[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        if qk_planes == 2 and errs is not None:
+            ref1 = softmax_ref(f64(q_ref[0], rows_q, head), f64(k_ref[0], all_k, kvh))
+            errs.append((err, np.linalg.norm(ref1 - ref) / np.linalg.norm(ref), np.linalg.norm(got - ref1) / np.linalg.norm(ref1)))
         worst = err if not np.isfinite(err) else max(worst, err)   # a NaN anywhere fails the case
         if not np.isfinite(worst):
             break
@@ -141,6 +170,7 @@ if __name__ == "__main__":
     ap.add_argument("--split-state", action="store_true")
     ap.add_argument("--layout", type=int, default=2)
     ap.add_argument("--head-dim", type=int, default=64)
+    ap.add_argument("--qk-planes", type=int, default=1)
     a = ap.parse_args()
     tiles = [int(x) for x in a.tiles.split(",")]
-    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout, head_dim=a.head_dim)
+    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout, head_dim=a.head_dim, qk_planes=a.qk_planes)
