@@ -345,6 +345,9 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if world > 1 and not dry:   # the first multi-GPU run must explain itself if it stalls: RCCL's own log per rank, read back by the watchdog
+            # one RCCL workgroup per channel must find a free CU while the persistent local-shard attention launch runs: the sharded model leaves
+            # ViewSharding.reserve_cus (32) CUs free, so RCCL is capped at as many channels (profiles/r06_exchange_under_persistent_attention.json)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/f3r_bench_rccl_rank{rank}_%p.log")
         try:

@@ -63,7 +63,7 @@ class AttnArgs(ctypes.Structure):
         ("kernel_sel", _c_i32), ("head_dim", _c_i32),
         ("dbg_counters", _c_vp),
         ("sched_counter", _c_vp),
-        ("qk_planes", _c_i32), ("reserved0", _c_i32),
+        ("qk_planes", _c_i32), ("reserve_cus", _c_i32),
     ]
 
 

@@ -409,6 +409,7 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(hd >= 16 && hd <= 128 && hd % 16 == 0, "f3r_attn_fwd: head_dim %d (a multiple of 16 up to 128)", a.head_dim);
   F3R_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "f3r_attn_fwd: ldq/ldk must be multiples of 8, ldo of 4");
   F3R_REQUIRE(a.qk_planes >= 0 && a.qk_planes <= 2, "f3r_attn_fwd: qk_planes %d", a.qk_planes);
+  F3R_REQUIRE(a.reserve_cus >= 0, "f3r_attn_fwd: reserve_cus %d", a.reserve_cus);
   const int qkp = a.qk_planes == 2 ? 2 : 1;   // elements of a q / k row per head = qkp * head_dim
   F3R_REQUIRE(a.ldq >= a.n_heads * hd * qkp && a.ldo >= a.n_heads * hd, "f3r_attn_fwd: row strides < heads*head_dim");
   F3R_REQUIRE((((uintptr_t)a.q) & 15) == 0 && (((uintptr_t)a.o) & 7) == 0, "f3r_attn_fwd: q/o alignment");

@@ -185,8 +185,13 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   const unsigned nx = (unsigned)((a.tq + 4 * wave_rows(hd, qkp) - 1) / (4 * wave_rows(hd, qkp)));
   unsigned gx = nx, gy = (unsigned)a.n_heads, gz = (unsigned)a.batch;
   const uint64_t n_work = (uint64_t)nx * gy * gz, nxy = (uint64_t)nx * gy;
-  const unsigned cus = (unsigned)num_cus();
-  if (a.sched_counter && n_work >= 2ull * cus && n_work * nxy < (1ull << 32)) {
+  unsigned cus = (unsigned)num_cus();
+  // f3r_attn_args.reserve_cus: leave that many CUs to whatever else must become resident while this launch runs (a rank's local-shard launch
+  // next to the exchange of the other ranks' K / V^T); the persistent form is then taken whenever there are more items than workgroups
+  const unsigned reserve = a.reserve_cus > 0 ? (unsigned)a.reserve_cus : 0u;
+  const bool reserving = a.sched_counter && reserve > 0 && reserve < cus && n_work > (uint64_t)(cus - reserve);
+  if (reserving) cus -= reserve;
+  if (a.sched_counter && (reserving || n_work >= 2ull * cus) && n_work * nxy < (1ull << 32)) {
     k.sched = a.sched_counter;
     k.n_work = (uint32_t)n_work;
     k.nx = nx;

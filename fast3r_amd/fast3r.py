@@ -727,21 +727,23 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def set_max_parallel_views_for_head(self, n):
         self.max_parallel_views_for_head = n
 
-    def shard_views(self, process_group=None, exchange="allgather", p2p_channels=3):
+    def shard_views(self, process_group=None, exchange="allgather", p2p_channels=3, reserve_cus=32):
         """Enable the view-sharded multi-GPU path: this rank encodes / decodes / regresses only its contiguous range of
         views and exchanges K / V^T per fusion layer over RCCL (fast3r_amd/dist.py).  exchange: "allgather" (one collective per tensor
         and layer, one remote attention launch), "p2p" (pairwise rounds dealt onto p2p_channels communicators, one remote launch per
         arrived shard) or "auto" (three fusion layers with each on the first forward, then the one that exposed less)."""
-        self.sharding = ViewSharding(process_group, exchange=exchange, p2p_channels=p2p_channels)
+        self.sharding = ViewSharding(process_group, exchange=exchange, p2p_channels=p2p_channels, reserve_cus=reserve_cus)
         return self
 
-    def emulate_rank(self, rank, world, kv_source=None, exchange="allgather"):
+    def emulate_rank(self, rank, world, kv_source=None, exchange="allgather", reserve_cus=0):
         """ONE GPU runs exactly rank `rank`'s share of a `world`-rank view-sharded forward -- its views through the encoder, the fusion
         layers as local launch (parking the softmax state) + remote launch over world - 1 K / V^T segments, its heads -- with no
         collective (dist.EmulatedSharding).  kv_source fills the remote segments per layer (parity test); without it they hold random
         operands (bench.py --emulate-rank: a per-rank step time, clearly not a multi-GPU measurement).  `emulate_rank(None, 0)` undoes it."""
         from .dist import EmulatedSharding
         self.sharding = None if rank is None else EmulatedSharding(world, rank, kv_source, exchange=exchange)
+        if self.sharding is not None:
+            self.sharding.reserve_cus = int(reserve_cus)   # what ViewSharding.reserve_cus costs the local launch, measurable on one GPU
         return self
 
     # ---------------------------------------------------------------- packed weights
@@ -974,8 +976,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                 kv_exchange.finish()  # a rank without tokens still takes part in the collective
             elif kv_exchange.has_remote:
                 pos = kv_exchange.positions()  # global token index of the first row of every rank's shard (causal attention only)
+                # (reserve_cus: the persistent launch leaves a few CUs to the kernels that move the other ranks' shards meanwhile -- ViewSharding.reserve_cus)
                 ops.attention(q, o, n_heads, scale, [kv_exchange.local_segment()], tq=seq_len, q_prescaled=True,
-                              state=kv_exchange.state, state_out=True, q_pos0=pos[kv_exchange.rank], seg_pos0=[pos[kv_exchange.rank]], **gqa)
+                              state=kv_exchange.state, state_out=True, q_pos0=pos[kv_exchange.rank], seg_pos0=[pos[kv_exchange.rank]],
+                              reserve_cus=getattr(sharding, "reserve_cus", 0), **gqa)
                 kv_exchange.mark_local_done()
                 # the remote shards, as ONE group once the all-gathers have landed or ("p2p" exchange) shard by shard in arrival order
                 groups = [(w, sg) for w, sg in kv_exchange.remote_groups()]

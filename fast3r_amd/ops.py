@@ -504,7 +504,8 @@ def attention_state(tq_total: int, n_heads: int, device, head_dim: int = 64):
 
 
 def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride=0, o_batch_stride=0, q_prescaled=False,
-              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0, head_dim=64, qk_planes=1):
+              state=None, state_in=False, state_out=False, kv_group=1, causal=False, q_pos0=0, seg_pos0=None, kernel_sel=0, head_dim=64, qk_planes=1,
+              reserve_cus=0):
     """O = softmax(scale Q K^T) V.  q/out: lowp [batch][tq][ld].  segments: list of (k, vt, seg_len, k_bstride, vt_bstride)
     with k [..][seg_len][ldk] and vt [..][kv_heads*64][ldvt].  kv_group: query heads per K / V head (grouped-query attention).
     causal: key position <= query position only, positions = q_pos0 + row / seg_pos0[s] + row (global token indices).
@@ -531,6 +532,7 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     a.kernel_sel = int(kernel_sel)
     a.head_dim = int(head_dim)
     a.qk_planes = int(qk_planes)
+    a.reserve_cus = int(reserve_cus)   # CUs the persistent form leaves free (f3r_attn_args.reserve_cus): a rank's local-shard launch next to the exchange
     if causal:
         pos = [0] * len(segments)
         if seg_pos0 is None:  # consecutive segments of one sequence starting at position 0

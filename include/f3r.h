@@ -300,7 +300,13 @@ typedef struct f3r_attn_args {
      f3r_attn_asm_qk3_f16 reads this layout (csrc/asm/attn_gen.py AttnGen(qk_planes = 2): 256-query workgroups): fp16, head_dim 64, q_prescaled, and
      the eligibility rules of kernel_sel 0 with tq >= 64 and no minimum number of keys -- anything else is F3R_ERR_UNSUPPORTED, never a fallback. */
   int32_t qk_planes;
-  int32_t reserved0;
+  /* Compute units the persistent (work-stealing) form leaves FREE (ABI 340; 0 = none; needs sched_counter).  The hand-scheduled kernels hold a
+     CU completely -- one 488-register wave per SIMD -- so while a launch of one persistent workgroup per CU runs, no other kernel of more than a
+     few registers can become resident anywhere on the chip until it ends.  A view-sharded rank launches its local-shard attention next to the
+     RCCL kernels (or copy kernels) that move the other ranks' K / V^T: with reserve_cus = r the launch runs cus - r persistent workgroups
+     (whenever it has more work items than that), so a kernel that arrives late still finds r CUs -- at the price of r / cus of this launch's rate
+     (tools/ubench/exchange_overlap.hip measures both sides: profiles/r06_exchange_under_persistent_attention.json). */
+  int32_t reserve_cus;
 } f3r_attn_args;
 #define F3R_ATTN_ASM_MIN_KEYS 2048
 

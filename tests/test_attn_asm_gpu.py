@@ -341,6 +341,14 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
             scoped = run(qs, k, v, H, hd=hd)
         torch.cuda.synchronize()
         assert mine.tolist() == [0, 0] and torch.equal(scoped.view(torch.int16), plain.view(torch.int16))
+        # f3r_attn_args.reserve_cus (round 6): the persistent form on fewer workgroups (a rank leaves CUs to the exchange kernels) computes the same
+        # items with the same instruction stream -- also when the launch is below the two-rounds threshold of the plain work-stealing form
+        for rsv in (16, 200):
+            o_r = torch.full((qs.shape[0], H * hd), float("nan"), dtype=dt, device=DEV)
+            ops.attention(qs.to(DEV), o_r, H, 1.0, [(k.to(DEV), vt_of(v, H, hd).to(DEV), k.shape[0], 0, 0)], q_prescaled=True, kernel_sel=2, head_dim=hd,
+                          reserve_cus=rsv)
+            torch.cuda.synchronize()
+            assert ctr.tolist() == [0, 0] and torch.equal(o_r.view(torch.int16), plain.view(torch.int16)), rsv
         ops.ATTN_COUNTERS = saved_ctrs
         c = [int(x) & 0xFFFFFFFF for x in ops.ATTN_COUNTERS.tolist()]
         wq = 512 if hd == 64 else 256
