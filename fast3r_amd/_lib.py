@@ -113,7 +113,7 @@ SYMBOLS = {
     "f3r_attn_f32_ex": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp]),
     "f3r_attn_f32_mfma_workspace": (ctypes.c_int64, [ctypes.POINTER(AttnF32Args)]),
     "f3r_attn_f32_mfma": (ctypes.c_int, [ctypes.POINTER(AttnF32Args), _c_vp, ctypes.c_int64, _c_vp]),
-    "f3r_qkv_planes": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
+    "f3r_qkv_planes": (ctypes.c_int, [_c_vp, _c_i64, _c_i64, _c_i64, ctypes.c_int, ctypes.c_int, _c_f32, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_attn_state_finish": (ctypes.c_int, [_c_vp, _c_vp, _c_i64, ctypes.c_int, ctypes.c_int, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_vp]),
     "f3r_estimate_poses": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32, _c_f32,
                                           _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),

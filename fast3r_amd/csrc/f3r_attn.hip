@@ -389,6 +389,7 @@ extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   const char* why = "";
   if (a.qk_planes == 2) return f3r_attn_asm_eligible(a, 0, &why) ? "f3r_attn_asm_qk3_f16 (hand-scheduled, three products per score block, csrc/asm/attn_gen.py)" : "";
+  if (a.qk_planes == 3) return f3r_attn_asm_eligible(a, 0, &why) ? "f3r_attn_asm_qk3f8_f16 (hand-scheduled, three products per score block, the corrections on the fp8 MFMA, csrc/asm/attn_gen.py)" : "";
   if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, (a.kernel_sel == 2 || hd != 64) ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) {
     if (hd == 80) return a.dtype == F3R_F16 ? "f3r_attn_asm_d80_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d80_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
     if (hd == 128) return a.dtype == F3R_F16 ? "f3r_attn_asm_d128_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d128_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
@@ -408,9 +409,9 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   F3R_REQUIRE(hd >= 16 && hd <= 128 && hd % 16 == 0, "f3r_attn_fwd: head_dim %d (a multiple of 16 up to 128)", a.head_dim);
   F3R_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 4 == 0, "f3r_attn_fwd: ldq/ldk must be multiples of 8, ldo of 4");
-  F3R_REQUIRE(a.qk_planes >= 0 && a.qk_planes <= 2, "f3r_attn_fwd: qk_planes %d", a.qk_planes);
+  F3R_REQUIRE(a.qk_planes >= 0 && a.qk_planes <= 3, "f3r_attn_fwd: qk_planes %d", a.qk_planes);
   F3R_REQUIRE(a.reserve_cus >= 0, "f3r_attn_fwd: reserve_cus %d", a.reserve_cus);
-  const int qkp = a.qk_planes == 2 ? 2 : 1;   // elements of a q / k row per head = qkp * head_dim
+  const int qkp = a.qk_planes >= 2 ? 2 : 1;   // elements of a q / k row per head = qkp * head_dim
   F3R_REQUIRE(a.ldq >= a.n_heads * hd * qkp && a.ldo >= a.n_heads * hd, "f3r_attn_fwd: row strides < heads*head_dim");
   F3R_REQUIRE((((uintptr_t)a.q) & 15) == 0 && (((uintptr_t)a.o) & 7) == 0, "f3r_attn_fwd: q/o alignment");
   F3R_REQUIRE(a.q_batch_stride % 8 == 0 && a.o_batch_stride % 4 == 0, "f3r_attn_fwd: batch strides alignment");
@@ -437,10 +438,10 @@ extern "C" int f3r_attn_fwd(const f3r_attn_args* args, f3r_stream_t stream) {
   F3R_REQUIRE(a.kernel_sel >= 0 && a.kernel_sel <= 2, "f3r_attn_fwd: kernel_sel %d", a.kernel_sel);
   if (a.tq == 0) return F3R_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (a.qk_planes == 2) {   // hi + lo planes of Q and K: one kernel reads that layout
+  if (a.qk_planes >= 2) {   // hi + lo planes of Q and K: one kernel per layout reads them
     const char* why = "";
     if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, 0, &why)) return f3r_attn_asm_launch(a, s);
-    f3r_set_error("f3r_attn_fwd: qk_planes 2 but the launch is not eligible for the hand-scheduled three-product kernel: %s", a.kernel_sel == 1 ? "kernel_sel 1" : why);
+    f3r_set_error("f3r_attn_fwd: qk_planes 2 / 3 but the launch is not eligible for the hand-scheduled three-product kernel: %s", a.kernel_sel == 1 ? "kernel_sel 1" : why);
     return F3R_ERR_UNSUPPORTED;
   }
   if (a.kernel_sel != 1) {  // the hand-scheduled one-wave-per-SIMD kernel where the launch allows it (include/f3r.h)

@@ -52,13 +52,14 @@ int hd_index(int hd) {
     if (kHd[i] == hd) return i;
   return -1;
 }
-int wave_rows(int hd, int qk_planes = 1) { return (hd == 64 && qk_planes != 2) ? 128 : 64; }  // query rows of a wave (32 x the query blocks per wave)
+int wave_rows(int hd, int qk_planes = 1) { return (hd == 64 && qk_planes < 2) ? 128 : 64; }  // query rows of a wave (32 x the query blocks per wave)
 
 struct DevKernels {
   bool tried = false;
   hipModule_t mod = nullptr;
   hipFunction_t fn[kNumHd][2] = {};  // [head_dim index][F3R_F16, F3R_BF16]
   hipFunction_t fn_qk3 = nullptr;    // head_dim 64, fp16, Q and K as hi + lo planes (f3r_attn_args.qk_planes = 2)
+  hipFunction_t fn_qk3f8 = nullptr;  // ... with the correction products on the fp8 MFMA (qk_planes = 3)
 };
 std::map<int, DevKernels> g_dev;
 std::mutex g_mu;
@@ -67,7 +68,7 @@ hipFunction_t get_fn(int dtype, int hd, int qk_planes = 1) {
   int dev = 0;
   const int hi = hd_index(hd);
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dtype < 0 || dtype > 1 || hi < 0) return nullptr;
-  if (qk_planes == 2 && (hd != 64 || dtype != F3R_F16)) return nullptr;
+  if (qk_planes >= 2 && (hd != 64 || dtype != F3R_F16)) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
   DevKernels& d = g_dev[dev];
   if (!d.tried) {
@@ -83,10 +84,11 @@ hipFunction_t get_fn(int dtype, int hd, int qk_planes = 1) {
           if (hipModuleGetFunction(&d.fn[i][t], d.mod, name) != hipSuccess) d.fn[i][t] = nullptr;
         }
       if (hipModuleGetFunction(&d.fn_qk3, d.mod, "f3r_attn_asm_qk3_f16") != hipSuccess) d.fn_qk3 = nullptr;
+      if (hipModuleGetFunction(&d.fn_qk3f8, d.mod, "f3r_attn_asm_qk3f8_f16") != hipSuccess) d.fn_qk3f8 = nullptr;
     }
     (void)hipGetLastError();
   }
-  return qk_planes == 2 ? d.fn_qk3 : d.fn[hi][dtype];
+  return qk_planes == 3 ? d.fn_qk3f8 : qk_planes == 2 ? d.fn_qk3 : d.fn[hi][dtype];
 }
 
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -105,8 +107,8 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   *why = none;
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   if (hd_index(hd) < 0) { *why = "no generated kernel for this head_dim (64, 80, 128)"; return false; }
-  const int qkp = a.qk_planes == 2 ? 2 : 1;
-  if (qkp == 2 && (hd != 64 || a.dtype != F3R_F16)) { *why = "qk_planes 2 needs head_dim 64 and fp16"; return false; }
+  const int qkp = a.qk_planes >= 2 ? a.qk_planes : 1;
+  if (qkp >= 2 && (hd != 64 || a.dtype != F3R_F16)) { *why = "qk_planes 2 / 3 need head_dim 64 and fp16"; return false; }
   const int64_t wrows = wave_rows(hd, qkp);
   if (a.causal) { *why = "causal mask"; return false; }
   if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
@@ -143,7 +145,7 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
 
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
-  const int qkp = a.qk_planes == 2 ? 2 : 1;
+  const int qkp = a.qk_planes >= 2 ? a.qk_planes : 1;
   hipFunction_t fn = get_fn(a.dtype, hd, qkp);
   if (!fn) {
     f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");

@@ -15,7 +15,7 @@
 namespace {
 
 // q / k part: one thread per 4 consecutive columns of a head
-template <class T>
+template <class T, bool F8>
 __global__ void planes_rows_kernel(const float* __restrict__ in, int64_t ld, int64_t rows, int n_heads, float scale, uint16_t* __restrict__ out) {
   const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;   // element index in [rows][n_heads * 64]
   const int64_t n = (int64_t)n_heads * 64;
@@ -32,7 +32,26 @@ __global__ void planes_rows_kernel(const float* __restrict__ in, int64_t ld, int
   lo[1] = pack2<T>(v[2] - lo_f<T>(hi[1]), v[3] - hi_f<T>(hi[1]));
   uint16_t* o = out + (r * n_heads + h) * 128 + d;
   *(u32x2*)o = hi;
-  *(u32x2*)(o + 64) = lo;
+  if constexpr (!F8) {
+    *(u32x2*)(o + 64) = lo;
+  } else {
+    // planes mode 3: bytes [128, 192) of the head = e4m3(hi), [192, 256) = e4m3(lo * 2^12): the operands of the two correction products on the
+    // block-scaled fp8 MFMA (f3r_attn_asm_qk3f8_f16).  v_cvt_pk_fp8_f32 does not saturate (out of range -> NaN): clamp to +-448 first.
+    float h4[4] = {lo_f<T>(hi[0]), hi_f<T>(hi[0]), lo_f<T>(hi[1]), hi_f<T>(hi[1])};
+    float l4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      l4[i] = fminf(fmaxf((v[i] - h4[i]) * 4096.0f, -448.f), 448.f);
+      h4[i] = fminf(fmaxf(h4[i], -448.f), 448.f);
+    }
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(h4[0], h4[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(h4[2], h4[3], w, true);
+    int wl = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
+    wl = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], wl, true);
+    uint8_t* ob = (uint8_t*)(out + (r * n_heads + h) * 128) + 128 + d;   // d is a multiple of 4
+    *(int*)ob = w;
+    *(int*)(ob + 64) = wl;
+  }
 }
 
 // V fp32 [n_seq * tk][ld] (columns 0 .. n of `in`) -> V^T [n_seq][n][ldvt], one plane; 64 x 64 tiles through LDS
@@ -86,7 +105,8 @@ inline bool al8(const void* p) { return (((uintptr_t)p) & 7) == 0; }
 }  // namespace
 
 extern "C" int f3r_qkv_planes(const float* qkv, int64_t ld, int64_t n_seq, int64_t seq_len, int n_heads, int kv_heads, float q_scale, void* q_planes,
-                              void* k_planes, void* vt, int64_t ldvt, int dtype, f3r_stream_t stream) {
+                              void* k_planes, void* vt, int64_t ldvt, int dtype, int planes, f3r_stream_t stream) {
+  F3R_REQUIRE(planes == 2 || (planes == 3 && dtype == F3R_F16), "f3r_qkv_planes: planes %d (2 = [hi | lo] 16-bit; 3 = [hi fp16 | e4m3(hi) | e4m3(lo 2^12)], fp16 only)", planes);
   F3R_REQUIRE(qkv && q_planes && k_planes && vt, "f3r_qkv_planes: null pointer");
   F3R_REQUIRE(n_seq > 0 && seq_len >= 0 && n_heads > 0 && kv_heads > 0 && n_heads % kv_heads == 0, "f3r_qkv_planes: bad sizes");
   F3R_REQUIRE(dtype == F3R_F16 || dtype == F3R_BF16, "f3r_qkv_planes: bad dtype %d", dtype);
@@ -99,11 +119,11 @@ extern "C" int f3r_qkv_planes(const float* qkv, int64_t ld, int64_t n_seq, int64
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq((unsigned)((rows * Dq / 4 + 255) / 256)), gk((unsigned)((rows * Dk / 4 + 255) / 256));
   const dim3 gv((unsigned)(ldvt / 64), (unsigned)kv_heads, (unsigned)n_seq);
-#define F3R_QP(TT)                                                                                                                              \
-  hipLaunchKernelGGL(planes_rows_kernel<TT>, gq, dim3(256), 0, s, qkv, ld, rows, n_heads, q_scale, (uint16_t*)q_planes);                        \
-  hipLaunchKernelGGL(planes_rows_kernel<TT>, gk, dim3(256), 0, s, qkv + Dq, ld, rows, kv_heads, 1.0f, (uint16_t*)k_planes);                     \
+#define F3R_QP(TT, F8)                                                                                                                          \
+  hipLaunchKernelGGL((planes_rows_kernel<TT, F8>), gq, dim3(256), 0, s, qkv, ld, rows, n_heads, q_scale, (uint16_t*)q_planes);                  \
+  hipLaunchKernelGGL((planes_rows_kernel<TT, F8>), gk, dim3(256), 0, s, qkv + Dq, ld, rows, kv_heads, 1.0f, (uint16_t*)k_planes);               \
   hipLaunchKernelGGL(transpose_rows_kernel<TT>, gv, dim3(256), 0, s, qkv + Dq + Dk, ld, seq_len, (int)Dk, ldvt, (uint16_t*)vt)
-  if (dtype == F3R_F16) { F3R_QP(F16); } else { F3R_QP(BF16); }
+  if (planes == 3) { F3R_QP(F16, true); } else if (dtype == F3R_F16) { F3R_QP(F16, false); } else { F3R_QP(BF16, false); }
 #undef F3R_QP
   return f3r_check_launch("f3r_qkv_planes");
 }

@@ -855,6 +855,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     # 2.39e-4 at N = 3, 2.76e-4 both at N = 100), +0.7 % views/s at N = 320, +1.7 % at N = 100, +3.9 % fusion-only at N = 20.  Changing it
     # needs invalidate_packed_weights().
     low_plane = "fp8"
+    # precision "robust": where the two correction products of the fusion attention's scores (q_lo k_hi + q_hi k_lo) run -- "fp8": the block-scaled
+    # fp8 MFMA (f3r_attn_asm_qk3f8_f16: 256 matrix-pipe cycles per score block; the fp8 copies move the softmax by ~2e-5), "fp16": two more fp16
+    # products (f3r_attn_asm_qk3_f16: 384 cycles).  Read per forward: no re-packing needed.
+    robust_corrections = "fp8"
     high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
 
     @property
@@ -1039,10 +1043,12 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if kv_exchange is None and self.precision == "robust" and self._qk3_ok(pb, n_seq, seq_len):
             # precision "robust": Q and K as hi + lo fp16 planes, three products per score block on the hand-scheduled kernel (f3r_attn_args.qk_planes),
             # P and V single fp16; the launch parks its softmax state and a small pass turns it into the planes of the attention output
-            qp, kp, vt = ops.qkv_planes(qkv, n_heads, n_kv, n_seq, seq_len, scale * ops.LOG2E, lp)
+            # (robust_corrections "fp8": the two correction products on the block-scaled fp8 MFMA -- rows [hi fp16 | e4m3(hi) | e4m3(lo 2^12)])
+            planes = 3 if self.robust_corrections == "fp8" else 2
+            qp, kp, vt = ops.qkv_planes(qkv, n_heads, n_kv, n_seq, seq_len, scale * ops.LOG2E, lp, planes=planes)
             state = ops.attention_state(T, n_heads, x.device, pb.head_dim)
             ops.attention(qp, state[0], n_heads, scale, [(kp, vt.view(n_kv * 64, vt.shape[-1]), seq_len, 0, 0)], tq=seq_len, q_prescaled=True, state=state,
-                          state_out=True, kv_group=pb.kv_group, head_dim=64, qk_planes=2, kernel_sel=2)
+                          state_out=True, kv_group=pb.kv_group, head_dim=64, qk_planes=planes, kernel_sel=2)
             o, ol = ops.attention_state_finish(state, n_heads, 64, lp)
             del qp, kp, vt, state
         elif kv_exchange is None:

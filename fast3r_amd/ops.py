@@ -565,9 +565,10 @@ def attention(q, out, n_heads, scale, segments, tq=None, batch=1, q_batch_stride
     return out
 
 
-def qkv_planes(qkv, n_heads, kv_heads, n_seq, seq_len, q_scale, lp):
+def qkv_planes(qkv, n_heads, kv_heads, n_seq, seq_len, q_scale, lp, planes=2):
     """precision "robust": fp32 qkv [n_seq * seq_len][Dq + 2 Dkv] (rotary embedding applied) -> (q rows [T][n_heads * 128] = per head [hi 64 | lo 64] of
-    q * q_scale, k rows [T][kv_heads * 128], V^T [n_seq][kv_heads * 64][ldvt] one plane): the operands of attention(..., qk_planes=2)."""
+    q * q_scale, k rows [T][kv_heads * 128], V^T [n_seq][kv_heads * 64][ldvt] one plane): the operands of attention(..., qk_planes=2).  planes = 3
+    (fp16): the lo half of every head holds [e4m3(hi) 64 B | e4m3(lo 2^12) 64 B] instead -- attention(..., qk_planes=3), corrections on the fp8 MFMA."""
     require_gpu(qkv, "qkv")
     assert qkv.dtype == torch.float32 and qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[0] == n_seq * seq_len
     T = qkv.shape[0]
@@ -577,7 +578,7 @@ def qkv_planes(qkv, n_heads, kv_heads, n_seq, seq_len, q_scale, lp):
     vt = torch.empty((n_seq, kv_heads * 64, ld), dtype=lp, device=qkv.device)
     with _timed(0.0, _nb(qkv, qp, kp, vt), "elementwise"):
         check(_lib.lib().f3r_qkv_planes(ptr(qkv), qkv.stride(0), n_seq, seq_len, n_heads, kv_heads, float(q_scale), ptr(qp), ptr(kp), ptr(vt), ld, dtype_id(lp),
-                                        stream_ptr()), "f3r_qkv_planes")
+                                        int(planes), stream_ptr()), "f3r_qkv_planes")
     return qp, kp, vt
 
 

@@ -293,7 +293,11 @@ typedef struct f3r_attn_args {
      items from `next`: the hardware deals workgroup ids round-robin over the 8 XCDs whatever their clocks (up to 6 % apart under the power
      cap), which left the faster XCDs idle for ~2.4 % of every fusion-attention launch (profiles/r05_*per_xcd*).  Other launches ignore it. */
   uint32_t* sched_counter;
-  /* Operand planes of Q and K (ABI 340, precision "robust"): 0 / 1 = one 16-bit number per element, as described above.  2 = every head of a q row
+  /* Operand planes of Q and K (ABI 340, precision "robust"): 0 / 1 = one 16-bit number per element, as described above.  3 = like 2 with the two
+     CORRECTION products on the block-scaled fp8 MFMA: a head of a q / K row is [hi fp16 (128 bytes) | e4m3(hi) (64 bytes) | e4m3(lo 2^12) (64 bytes)]
+     (f3r_qkv_planes with planes = 3; the same 256 bytes per head) and a score block is q_hi k_hi on fp16 + q_lo8 k_hi8 + q_hi8 k_lo8 on
+     v_mfma_scale_f32_32x32x64_f8f6f4 (kernel f3r_attn_asm_qk3f8_f16: 256 matrix-pipe cycles per block instead of 384; the fp8 copies move the
+     softmax by ~2e-5, csrc/asm/attn_gen.py corr = "f8").  2 = every head of a q row
      and of a K row holds [hi (64) | lo (64)] fp16 (x = hi + lo to ~22 bits; f3r_qkv_planes writes such rows): ldq / ldk / the batch strides count
      elements of these 128-wide heads (ldq >= n_heads * 128), and the scores are q_hi k_hi + q_lo k_hi + q_hi k_lo with fp32 accumulation -- three
      MFMA products per score block, P V unchanged (V^T, o, the parked state: head_dim 64 layouts).  Only the hand-scheduled kernel
@@ -487,7 +491,7 @@ int f3r_attn_f32_mfma(const f3r_attn_f32_args* args, void* workspace, int64_t wo
  *   X3 output projection; o_lo may be NULL) and / or fp32 (o_f32).
  */
 int f3r_qkv_planes(const float* qkv, int64_t ld, int64_t n_seq, int64_t seq_len, int n_heads, int kv_heads, float q_scale, void* q_planes, void* k_planes,
-                   void* vt, int64_t ldvt, int dtype, f3r_stream_t stream);
+                   void* vt, int64_t ldvt, int dtype, int planes /* 2 or 3: the row layout of f3r_attn_args.qk_planes */, f3r_stream_t stream);
 int f3r_attn_state_finish(const float* st_o, const float* st_ml, int64_t rows, int n_heads, int head_dim, void* o_hi, void* o_lo, float* o_f32,
                           int64_t ldo, int dtype, f3r_stream_t stream);
 

@@ -169,3 +169,24 @@ def test_emulated_three_product_form_uses_its_low_planes():
     emu_attn.run_case(qk_planes=2, n_tiles=4, n_heads=2, wgs=((0, 1, 0),), spike=True, errs=errs)
     err, one_product_distance, err_vs_one_product = errs[0]
     assert err < 6e-4 and one_product_distance > 1.5 * err and err_vs_one_product > 1.5 * err, errs
+
+
+@pytest.mark.parametrize("kw", [dict(n_tiles=1), dict(n_tiles=3), dict(n_tiles=6, spike=True), dict(n_tiles=[2, 1, 3], spike=True), dict(n_tiles=[2, 3], split_state=True),
+                                dict(tq=300, q_blocks=2, wgs=((1, 0, 0), (0, 1, 0))), dict(kv_shift=1, n_heads=4, batch=2, wgs=((0, 3, 1),)),
+                                dict(tq=700, n_heads=1, n_tiles=[1, 1], split_state=True, wgs=((0, 0, 0), (2, 0, 0)), steal=3)])
+def test_emulated_three_product_form_with_fp8_corrections(kw):
+    """AttnGen(qk_planes=2, corr="f8") (f3r_attn_args.qk_planes = 3): rows [hi fp16 | e4m3(hi) | e4m3(lo 2^12)] per head; a score block is four fp16
+    MFMAs (q_hi k_hi) + two block-scaled fp8 MFMAs over the whole head (q_lo8 k_hi8 with the Q scale 2^-12, q_hi8 k_lo8 with the K scale 2^-12); the
+    8-register fp8 fragments are the SAME LDS reads / global loads as the fp16 lo plane's (two consecutive 16-byte chunks = the hardware's native
+    k order).  Reference: float64 on exactly those planes."""
+    import emu_attn
+    assert emu_attn.run_case(qk_planes=2, corr="f8", **kw) < 6e-4
+
+
+def test_emulated_fp8_corrections_stay_close_to_the_exact_planes():
+    """what the fp8 copies cost: the softmax computed from the kernel's planes (fp16 hi product + fp8 corrections) against the one from hi + lo
+    (~22 bits) -- an order of magnitude inside the kernel's own rounding of P"""
+    import emu_attn
+    errs = []
+    assert emu_attn.run_case(qk_planes=2, corr="f8", n_tiles=4, n_heads=2, wgs=((0, 1, 0),), spike=True, errs=errs) < 6e-4
+    assert errs and errs[0][1] < 1e-4, errs

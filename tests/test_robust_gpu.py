@@ -31,14 +31,24 @@ def _qkv(T, H, Hkv, seed, amp=1.5):
     return torch.randn((T, (H + 2 * Hkv) * 64), generator=g) * amp
 
 
-def _softmax_ref(q64, k64, v64, H, Hkv):
-    """q64 (pre-scaled, base-2 logits), k64, v64 float64 [T][heads * 64] -> float64 [Tq][H * 64]"""
+def _softmax_ref(q64, k64, v64, H, Hkv, extra=None):
+    """q64 (pre-scaled, base-2 logits), k64, v64 float64 [T][heads * 64] -> float64 [Tq][H * 64], head by head ON THE DEVICE (float64 there is fast; the
+    20 480-token case is 6.7e9 scores).  extra: further (q, k) pairs whose products are added to the scores (the fp8 correction planes)."""
     Tq = q64.shape[0]
-    qh = q64.reshape(Tq, H, 64).transpose(0, 1)
-    kh = k64.reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
-    vh = v64.reshape(-1, Hkv, 64).transpose(0, 1).repeat_interleave(H // Hkv, 0)
-    s = (qh @ kh.transpose(1, 2)) * math.log(2.0)
-    return (s.softmax(-1) @ vh).transpose(0, 1).reshape(Tq, H * 64)
+    g = H // Hkv
+    out = torch.empty((Tq, H * 64), dtype=torch.float64)
+    pairs = [(q64, k64)] + list(extra or [])
+    vd = v64.to(DEV)
+    for h in range(H):
+        kv = h // g
+        sc = None
+        for qq, kk in pairs:
+            t = qq[:, h * 64:(h + 1) * 64].to(DEV) @ kk[:, kv * 64:(kv + 1) * 64].to(DEV).t()
+            sc = t if sc is None else sc + t
+        p = torch.exp2(sc - sc.amax(dim=1, keepdim=True))
+        out[:, h * 64:(h + 1) * 64] = ((p @ vd[:, kv * 64:(kv + 1) * 64]) / p.sum(dim=1, keepdim=True)).cpu()
+        del sc, p
+    return out
 
 
 def _split(x32):
@@ -47,39 +57,56 @@ def _split(x32):
     return hi, lo
 
 
+def _e4m3(x64):
+    return x64.float().clamp(-448, 448).to(torch.float8_e4m3fn).double()
+
+
+@pytest.mark.parametrize("planes", [2, 3])
 @pytest.mark.parametrize("T,H,Hkv", [(64, 2, 2), (4096, 4, 4), (3072 + 64, 3, 3), (2048, 8, 2), (20480, 16, 16)])
-def test_qkv_planes_three_product_attention_and_state_finish(built_lib, T, H, Hkv):
+def test_qkv_planes_three_product_attention_and_state_finish(built_lib, T, H, Hkv, planes):
     """f3r_qkv_planes -> f3r_attn_fwd(qk_planes = 2, state_out) -> f3r_attn_state_finish on one sequence of T tokens.  (a) the planes are the exact
     split of the scaled fp32 values, V^T is the rounded transpose with zero padding; (b) the attention output equals float64 softmax on hi + lo to
     the rounding of P / V / the output planes; (c) it is CLOSER to the fp32 inputs' softmax than the one-product kernel on the same inputs."""
     scale = 0.160192
     qkv = _qkv(T, H, Hkv, 7 + T)
     qd = qkv.to(DEV)
-    qp, kp, vt = ops.qkv_planes(qd, H, Hkv, 1, T, scale * LOG2E, torch.float16)
+    qp, kp, vt = ops.qkv_planes(qd, H, Hkv, 1, T, scale * LOG2E, torch.float16, planes=planes)
     Dq, Dk = H * 64, Hkv * 64
     q32, k32, v32 = qkv[:, :Dq] * (scale * LOG2E), qkv[:, Dq:Dq + Dk], qkv[:, Dq + Dk:]
     q_hi, q_lo = _split(q32)
     k_hi, k_lo = _split(k32)
     qpc, kpc = qp.cpu().view(T, H, 2, 64), kp.cpu().view(T, Hkv, 2, 64)
-    assert torch.equal(qpc[:, :, 0].reshape(T, Dq), q_hi) and torch.equal(qpc[:, :, 1].reshape(T, Dq), q_lo)
-    assert torch.equal(kpc[:, :, 0].reshape(T, Dk), k_hi) and torch.equal(kpc[:, :, 1].reshape(T, Dk), k_lo)
+    assert torch.equal(qpc[:, :, 0].reshape(T, Dq), q_hi) and torch.equal(kpc[:, :, 0].reshape(T, Dk), k_hi)
+    if planes == 2:
+        assert torch.equal(qpc[:, :, 1].reshape(T, Dq), q_lo) and torch.equal(kpc[:, :, 1].reshape(T, Dk), k_lo)
+    else:   # planes 3: the lo half of a head = [e4m3(hi) 64 bytes | e4m3(lo 2^12) 64 bytes]
+        q_lo, k_lo = (q32 - q_hi.float()).double(), (k32 - k_hi.float()).double()   # this layout never rounds the remainder to fp16: e4m3 of the exact fp32 difference
+        for mem, hi, lo, heads in ((qpc, q_hi, q_lo, H), (kpc, k_hi, k_lo, Hkv)):
+            b = mem[:, :, 1].contiguous().view(torch.uint8).view(T, heads, 128)
+            got_hi8 = b[:, :, :64].contiguous().view(torch.float8_e4m3fn).double().reshape(T, heads * 64)
+            got_lo8 = b[:, :, 64:].contiguous().view(torch.float8_e4m3fn).double().reshape(T, heads * 64)
+            assert torch.equal(got_hi8, _e4m3(hi.double()))
+            assert torch.equal(got_lo8, _e4m3(lo * 4096.0))
     vtc = vt.cpu()[0]
     assert torch.equal(vtc[:, :T], v32.to(torch.float16).t()) and not vtc[:, T:].any()
     state = ops.attention_state(T, H, DEV)
     ops.ATTN_TIMER = []
     try:
         ops.attention(qp, state[0], H, scale, [(kp, vt.view(Dk, vt.shape[-1]), T, 0, 0)], q_prescaled=True, state=state, state_out=True, kv_group=H // Hkv,
-                      qk_planes=2, kernel_sel=2)
+                      qk_planes=planes, kernel_sel=2)
         names = [r[5] for r in ops.ATTN_TIMER]
     finally:
         ops.ATTN_TIMER = None
-    assert all("f3r_attn_asm_qk3_f16" in n for n in names), names
+    assert all(("f3r_attn_asm_qk3_f16" if planes == 2 else "f3r_attn_asm_qk3f8_f16") in n for n in names), names
     o_hi, o_lo, o32 = ops.attention_state_finish(state, H, 64, torch.float16, want_f32=True)
     torch.cuda.synchronize()
     got = o_hi.double().cpu() + o_lo.double().cpu()
     assert float((got - o32.double().cpu()).abs().max()) <= 2.0 ** -20 * float(o32.abs().max())          # the planes carry the fp32 result to ~22 bits
     v16 = v32.to(torch.float16).double()
     ref_planes = _softmax_ref(q_hi.double() + q_lo.double(), k_hi.double() + k_lo.double(), v16, H, Hkv)
+    if planes == 3:   # the scores the kernel computes from ITS planes: q_hi k_hi + dq(q_lo8) dq(k_hi8) + dq(q_hi8) dq(k_lo8)
+        ref_planes = _softmax_ref(q_hi.double(), k_hi.double(), v16, H, Hkv,
+                                  extra=[(_e4m3(q_lo.double() * 4096.0) / 4096.0, _e4m3(k_hi.double())), (_e4m3(q_hi.double()), _e4m3(k_lo.double() * 4096.0) / 4096.0)])
     e_planes = float((got - ref_planes).abs().max() / ref_planes.abs().max())
     assert e_planes <= 2.0 ** -9, e_planes                                                                  # P is rounded to fp16 before P V
     # (c) against the softmax of the UNROUNDED q, k (V rounded once in both kernels): three products vs one
@@ -90,17 +117,18 @@ def test_qkv_planes_three_product_attention_and_state_finish(built_lib, T, H, Hk
     ops.attention(q_hi.to(DEV), one, H, scale, [(k_hi.to(DEV), vt1, T, 0, 0)], q_prescaled=True, kv_group=H // Hkv)
     e3 = rel_l2(got, ref_true)
     e1 = rel_l2(one.double().cpu(), ref_true)
-    print(f"[robust] T={T} H={H}/{Hkv}: three products {e3:.2e}, one product {e1:.2e} (rel-L2 vs the softmax of the fp32 q, k)")
+    print(f"[robust] T={T} H={H}/{Hkv} planes={planes}: three products {e3:.2e}, one product {e1:.2e} (rel-L2 vs the softmax of the fp32 q, k)")
     assert e3 < 0.6 * e1, (e3, e1)
 
 
-def test_three_product_kernel_segments_and_resumed_state(built_lib):
+@pytest.mark.parametrize("planes", [2, 3])
+def test_three_product_kernel_segments_and_resumed_state(built_lib, planes):
     """K / V^T as three segments in one launch == one launch over the concatenation, bit for bit (same tiles, same order); local launch (state_out) +
     remote launch (state_in) -- the sharded form -- equals them up to the rounding of the resumed launch's first half tile, which goes through the
     re-base path (tests/test_attn_asm_gpu.py::test_asm_kernel_segments_and_carried_state holds the one-product kernel to the same bar)"""
     T, H = 2048, 4
     qkv = _qkv(T, H, H, 3).to(DEV)
-    qp, kp, vt = ops.qkv_planes(qkv, H, H, 1, T, 0.125 * LOG2E, torch.float16)
+    qp, kp, vt = ops.qkv_planes(qkv, H, H, 1, T, 0.125 * LOG2E, torch.float16, planes=planes)
     D = H * 64
     cuts = [(0, 512), (512, 1280), (1280, 2048)]
     segs = []
@@ -111,7 +139,7 @@ def test_three_product_kernel_segments_and_resumed_state(built_lib):
 
     def launch(sg, **kw):
         st = kw.pop("state", None) or ops.attention_state(T, H, DEV)
-        ops.attention(qp, st[0], H, 0.125, sg, q_prescaled=True, state=st, qk_planes=2, kernel_sel=2, **kw)
+        ops.attention(qp, st[0], H, 0.125, sg, q_prescaled=True, state=st, qk_planes=planes, kernel_sel=2, **kw)
         return st
     full = launch([(kp, vt.view(D, -1), T, 0, 0)], state_out=True)
     one = launch(segs, state_out=True)
@@ -131,12 +159,12 @@ def test_three_product_form_refuses_what_it_cannot_take(built_lib):
     qkv = _qkv(T, H, H, 5).to(DEV)
     qp, kp, vt = ops.qkv_planes(qkv, H, H, 1, T, 0.2, torch.float16)
     st = ops.attention_state(T, H, DEV)
-    with pytest.raises(ValueError, match="qk_planes 2"):      # the general HIP kernel does not read the plane layout
+    with pytest.raises(ValueError, match="qk_planes 2 / 3"):      # the general HIP kernel does not read the plane layout
         ops.attention(qp, st[0], H, 0.125, [(kp, vt.view(H * 64, -1), T, 0, 0)], q_prescaled=True, state=st, state_out=True, qk_planes=2, kernel_sel=1)
-    with pytest.raises(ValueError, match="qk_planes 2"):      # bf16 planes: no such kernel
+    with pytest.raises(ValueError, match="qk_planes 2 / 3"):      # bf16 planes: no such kernel
         ops.attention(qp.view(torch.bfloat16), st[0], H, 0.125, [(kp.view(torch.bfloat16), vt.view(H * 64, -1).view(torch.bfloat16), T, 0, 0)], q_prescaled=True,
                       state=st, state_out=True, qk_planes=2)
-    with pytest.raises(ValueError, match="qk_planes 2"):      # q not pre-scaled
+    with pytest.raises(ValueError, match="qk_planes 2 / 3"):      # q not pre-scaled
         ops.attention(qp, st[0], H, 0.125, [(kp, vt.view(H * 64, -1), T, 0, 0)], state=st, state_out=True, qk_planes=2)
 
 
@@ -154,8 +182,9 @@ def test_tiny_model_with_heavy_tailed_weights_robust_vs_oracle(built_lib):
         ref = O.forward(views, sd, enc, dec, head)
     gv = views_to(views, DEV)
     worst = {}
-    for precision in ("high", "robust", "exact"):
-        m = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision=precision).eval()
+    for precision in ("high", "robust", "robust+fp16", "exact"):
+        m = Fast3R(enc, dec, head, compute_dtype=torch.float16, precision=precision.split("+")[0]).eval()
+        m.robust_corrections = "fp16" if precision.endswith("+fp16") else "fp8"
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV)
         ops.ATTN_TIMER = []
@@ -166,11 +195,11 @@ def test_tiny_model_with_heavy_tailed_weights_robust_vs_oracle(built_lib):
             names = {r[5] for r in ops.ATTN_TIMER}
         finally:
             ops.ATTN_TIMER = None
-        if precision == "robust":
-            assert any("f3r_attn_asm_qk3_f16" in n for n in names), names
+        if precision.startswith("robust"):
+            assert any(("f3r_attn_asm_qk3_f16" if precision.endswith("+fp16") else "f3r_attn_asm_qk3f8_f16") in n for n in names), names
         worst[precision] = max(rel_l2(o[k].cpu(), r[k]) for o, r in zip(out, ref) for k in r)
     print("[parity] tiny HEAVY-TAILED 4 x 64^2 vs CPU oracle: " + ", ".join(f"{k}={v:.2e}" for k, v in worst.items()))
-    assert worst["exact"] <= 5e-5 and worst["robust"] <= 3e-3 and worst["robust"] < 0.5 * worst["high"], worst
+    assert worst["exact"] <= 5e-5 and worst["robust"] <= 3e-3 and worst["robust"] < 0.5 * worst["high"] and worst["robust+fp16"] <= 3e-3, worst
 
 
 def test_calibrate_precision_reports_every_tier_and_recommends_the_cheapest_within_tol(built_lib):

@@ -15,7 +15,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(here, "..", "fast3r_amd", "csrc", "asm"))
 sys.path.insert(0, here)
 import attn_gen  # noqa: E402
-from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32  # noqa: E402
+from gfx950_emu import Memory, Workgroup, f32_to_half, half_to_f32, fp8_e4m3_to_f64, f64_to_fp8_e4m3  # noqa: E402
 
 
 def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags=0, st_o=0, st_ml=0, k_bs=0, vt_bs=0, st_o_ld=0, st_ml_ld=0, tq=0, dbg=0, sched=0, n_work=0, nx=0, nxy=0, grid=0):
@@ -35,17 +35,19 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None, corr="f16"):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2).  steal = G > 0: the work-stealing form -- G
     persistent workgroups share the launch's {next, done} counter (emulated one after the other: the first one takes every item, the others
     find the counter exhausted, the last one to leave zeroes it); `wgs` then lists the work items whose output is compared.
     qk_planes = 2: the three-product form (AttnGen(qk_planes=2), precision "robust"): Q and K rows hold [hi (64) | lo (64)] fp16 per head; the reference
-    is float64 on hi + lo; errs (a list) also receives the distance to the reference computed from the hi planes alone (what one product gives)."""
+    is float64 on hi + lo; errs (a list) also receives the distance to the reference computed from the hi planes alone (what one product gives).
+    corr = "f8" (with qk_planes = 2): rows [hi fp16 | e4m3(hi) | e4m3(lo 2^12)] per head, the correction products on the block-scaled fp8 MFMA; the
+    reference is float64 on EXACTLY those planes: q_hi k_hi + dq(q_lo8) dq(k_hi8) + dq(q_hi8) dq(k_lo8)."""
     rng = np.random.default_rng(seed)
     HD = head_dim
-    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, qk_planes=qk_planes, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
+    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, qk_planes=qk_planes, corr=corr, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
     WQ = g.WG_Q   # query rows of a workgroup (512 at head_dim 64, 256 otherwise)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
     tq, tk = (WQ * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
@@ -74,6 +76,16 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         qmem, q_hi, q_lo = planes(q * (scale * LOG2E), n_heads)
         kmem, k_hi, k_lo = planes(k, kv_heads)
         q_ref, k_ref = (q_hi, q_lo), (k_hi, k_lo)
+        if corr == "f8":   # the lo half of a head's row becomes [e4m3(hi) 64 B | e4m3(lo * 2^12) 64 B]
+            def f8_rows(mem, hi, lo, heads):
+                m = mem.reshape(mem.shape[:2] + (heads, 2, HD)).copy()
+                hi8 = f64_to_fp8_e4m3(half_to_f32(hi, dtype).astype(np.float64)).reshape(hi.shape[:2] + (heads, HD))
+                lo8 = f64_to_fp8_e4m3(half_to_f32(lo, dtype).astype(np.float64) * 4096.0).reshape(lo.shape[:2] + (heads, HD))
+                both = np.concatenate([hi8, lo8], axis=-1).astype(np.uint8)              # 128 bytes
+                m[:, :, :, 1] = np.ascontiguousarray(both).view(np.uint16)
+                return m.reshape(mem.shape), fp8_e4m3_to_f64(hi8).reshape(hi.shape), (fp8_e4m3_to_f64(lo8) / 4096.0).reshape(lo.shape)
+            qmem, q_hi8, q_lo8 = f8_rows(qmem, q_hi, q_lo, n_heads)
+            kmem, k_hi8, k_lo8 = f8_rows(kmem, k_hi, k_lo, kv_heads)
         qh, kh = qmem, kmem
         DQ, DKm = 2 * D, 2 * Dk
     ldvt = 64 * max(seg_tiles)
@@ -143,10 +155,20 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
             kf = f64(k_ref[0], all_k, kvh) + f64(k_ref[1], all_k, kvh)
         else:
             qf, kf = f64(q_ref, rows_q, head), f64(k_ref, all_k, kvh)
-        ref = softmax_ref(qf, kf)
+        if corr == "f8":   # the scores the kernel computes, from its own planes
+            hs = slice(head * HD, (head + 1) * HD)
+            ks_ = slice(kvh * HD, (kvh + 1) * HD)
+            s8 = (f64(q_ref[0], rows_q, head) @ f64(k_ref[0], all_k, kvh).T + q_lo8[b, rows_q, hs] @ k_hi8[b, :, ks_].T + q_hi8[b, rows_q, hs] @ k_lo8[b, :, ks_].T)
+            p8 = np.exp2(s8 - s8.max(axis=1, keepdims=True))
+            ref = (p8 @ vf) / p8.sum(axis=1, keepdims=True)
+            if errs is not None:
+                true = softmax_ref(qf, kf)
+                errs.append(("f8 planes vs hi + lo", np.linalg.norm(ref - true) / np.linalg.norm(true)))
+        else:
+            ref = softmax_ref(qf, kf)
         got = half_to_f32(og[b, x * WQ:r1, head * HD:(head + 1) * HD], dtype).astype(np.float64)
         err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-        if qk_planes == 2 and errs is not None:
+        if qk_planes == 2 and errs is not None and corr != "f8":
             ref1 = softmax_ref(f64(q_ref[0], rows_q, head), f64(k_ref[0], all_k, kvh))
             errs.append((err, np.linalg.norm(ref1 - ref) / np.linalg.norm(ref), np.linalg.norm(got - ref1) / np.linalg.norm(ref1)))
         worst = err if not np.isfinite(err) else max(worst, err)   # a NaN anywhere fails the case
@@ -171,6 +193,7 @@ if __name__ == "__main__":
     ap.add_argument("--layout", type=int, default=2)
     ap.add_argument("--head-dim", type=int, default=64)
     ap.add_argument("--qk-planes", type=int, default=1)
+    ap.add_argument("--corr", default="f16")
     a = ap.parse_args()
     tiles = [int(x) for x in a.tiles.split(",")]
-    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout, head_dim=a.head_dim, qk_planes=a.qk_planes)
+    run_case(a.dtype, tiles if len(tiles) > 1 else tiles[0], a.heads, spike=a.spike, rowsum=a.rowsum, gen_kwargs=dict(cvt=a.cvt), split_state=a.split_state, layout=a.layout, head_dim=a.head_dim, qk_planes=a.qk_planes, corr=a.corr)

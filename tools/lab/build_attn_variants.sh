@@ -25,7 +25,7 @@ with open(sys.argv[2], "w") as f:
 PY
   g++ -O1 -fPIC -std=c++17 -c "$w/blob.cpp" -o "$w/blob.o"
   objs=""
-  for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_gemm_asm f3r_gemm_asm_blob f3r_attn f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_capi; do objs="$objs $src/obj/$f.o"; done
+  for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_gemm_asm f3r_gemm_asm_blob f3r_attn f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_exact_mfma f3r_robust f3r_capi; do objs="$objs $src/obj/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$w/blob.o" -o "$here/var/libf3r_$name.so"
   echo "built $here/var/libf3r_$name.so ($flags)"
 done
