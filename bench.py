@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other operand format (bf16 / fast)")
     ap.add_argument("--fusion-only", action="store_true",
                     help="BASELINE configs[1]: time only the fusion decoder on frozen random encoder features")
-    ap.add_argument("--weights", default="default", choices=["default", "hot"],
+    ap.add_argument("--weights", default="default", choices=["default", "hot", "heavy"],
                     help="synthetic weight distribution (fast3r_amd/synthetic.py): default = the reference's own random init (near-uniform softmax); "
                          "hot = N(0, 1/fan_in): sharp attention, the lazy softmax reference of the attention kernel really moves")
     ap.add_argument("--no-hot", action="store_true", help="skip the short second measurement on the hot weights (default-weights runs only)")
