@@ -527,6 +527,10 @@ def main():
         lp = torch.float16 if dtype_name == "fp16" else torch.bfloat16
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
         model.low_plane = args.low_plane
+        if os.environ.get("F3R_ROBUST_ENCODER"):      # measurement: "planes" = the encoder's attention on the three-product kernel too
+            model.robust_encoder_attention = os.environ["F3R_ROBUST_ENCODER"]
+        if os.environ.get("F3R_ROBUST_CORR"):         # measurement: "fp16" = the score corrections as two more fp16 products
+            model.robust_corrections = os.environ["F3R_ROBUST_CORR"]
         model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
         if emu:

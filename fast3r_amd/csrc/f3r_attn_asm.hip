@@ -114,7 +114,8 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   if (!a.q_prescaled) { *why = "q not pre-scaled"; return false; }
   if (a.tq < wrows) { *why = "fewer query rows than one wave takes (128 at head_dim 64, 64 otherwise)"; return false; }
   if (a.kv_group > 1 && !pow2(a.kv_group)) { *why = "kv_group not a power of two"; return false; }
-  if ((a.state_in || a.state_out) && a.batch != 1) { *why = "carried softmax state with batch > 1"; return false; }
+  // (the three-product kernels index the parked state by sequence: rows [z tq, (z + 1) tq) -- they park it on every launch; the others at batch 1 only)
+  if ((a.state_in || a.state_out) && a.batch != 1 && a.qk_planes < 2) { *why = "carried softmax state with batch > 1"; return false; }
   int first = -1;
   int64_t keys = 0;
   for (int s = 0; s < a.n_seg; ++s) {

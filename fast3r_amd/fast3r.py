@@ -859,6 +859,11 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     # fp8 MFMA (f3r_attn_asm_qk3f8_f16: 256 matrix-pipe cycles per score block; the fp8 copies move the softmax by ~2e-5), "fp16": two more fp16
     # products (f3r_attn_asm_qk3_f16: 384 cycles).  Read per forward: no re-packing needed.
     robust_corrections = "fp8"
+    # precision "robust": the ENCODER's per-view attention (1024 keys; 0.6 % of the step's attention FLOPs at N = 320) -- "fp32": the fp32 attention of
+    # precision "exact" (0.8 s of a 14.2 s step on the FMA pipe), "planes": the same three-product kernel as the fusion layers, one launch over the
+    # batch of views (59 ms).  Measured on the heavy-tailed ViT-L set (N = 3 vs the CPU oracle): 7.8e-5 with "fp32", 5.2e-4 with "planes" -- both
+    # inside 1e-3, the default keeps the larger margin (a tier people turn to because their checkpoint amplifies noise); N = 320: 14.2 s / 13.7 s.
+    robust_encoder_attention = "fp32"
     high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
 
     @property
@@ -1040,14 +1045,17 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         if rope is not None and T:
             ops.rope_f32(qkv, n_heads + n_kv, max(1, seq_len), rope, pb.rope_mode)
         gqa = dict(head_dim=pb.head_dim, kv_group=pb.kv_group, causal=pb.causal)
-        if kv_exchange is None and self.precision == "robust" and self._qk3_ok(pb, n_seq, seq_len):
+        if (kv_exchange is None and self.precision == "robust" and self._qk3_ok(pb, n_seq, seq_len)
+                and (n_seq == 1 or self.robust_encoder_attention == "planes")):
             # precision "robust": Q and K as hi + lo fp16 planes, three products per score block on the hand-scheduled kernel (f3r_attn_args.qk_planes),
             # P and V single fp16; the launch parks its softmax state and a small pass turns it into the planes of the attention output
             # (robust_corrections "fp8": the two correction products on the block-scaled fp8 MFMA -- rows [hi fp16 | e4m3(hi) | e4m3(lo 2^12)])
             planes = 3 if self.robust_corrections == "fp8" else 2
             qp, kp, vt = ops.qkv_planes(qkv, n_heads, n_kv, n_seq, seq_len, scale * ops.LOG2E, lp, planes=planes)
             state = ops.attention_state(T, n_heads, x.device, pb.head_dim)
-            ops.attention(qp, state[0], n_heads, scale, [(kp, vt.view(n_kv * 64, vt.shape[-1]), seq_len, 0, 0)], tq=seq_len, q_prescaled=True, state=state,
+            ldvt_ = vt.shape[-1]
+            ops.attention(qp, state[0], n_heads, scale, [(kp, vt.view(n_seq * n_kv * 64, ldvt_), seq_len, seq_len * n_kv * 128, n_kv * 64 * ldvt_)], tq=seq_len,
+                          batch=n_seq, q_batch_stride=seq_len * n_heads * 128, o_batch_stride=seq_len * n_heads * 64, q_prescaled=True, state=state,
                           state_out=True, kv_group=pb.kv_group, head_dim=64, qk_planes=planes, kernel_sel=2)
             o, ol = ops.attention_state_finish(state, n_heads, 64, lp)
             del qp, kp, vt, state
@@ -1072,13 +1080,13 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         return x
 
     def _qk3_ok(self, pb, n_seq, seq_len):
-        """can this block's attention take the three-product kernel (f3r_attn_asm_qk3_f16)?  One sequence (the fusion decoder: the kernel parks its
-        softmax state per launch), head_dim 64, fp16, no causal mask, whole 64-key tiles, at least one wave of queries, a power-of-two head group.
-        Everything else in precision "robust" -- the encoder's per-view attention, odd token counts, sharded models -- runs the fp32 attention of
-        precision "exact" (more exact, slower)."""
+        """can this block's attention take the three-product kernels (f3r_attn_asm_qk3{,f8}_f16)?  head_dim 64, fp16, no causal mask, whole 64-key
+        tiles per sequence, at least one wave of queries, a power-of-two head group; any number of sequences (the fusion decoder's one, the
+        encoder's one per view: the kernels park their softmax state per sequence).  Everything else in precision "robust" -- odd token counts
+        (DINOv2's class token), causal Llama decoders, sharded models -- runs the fp32 attention of precision "exact" (more exact, slower)."""
         g = pb.kv_group
-        return (self.compute_dtype == torch.float16 and pb.head_dim == 64 and not pb.causal and n_seq == 1 and seq_len >= 64 and seq_len % 64 == 0
-                and g >= 1 and (g & (g - 1)) == 0)
+        return (self.compute_dtype == torch.float16 and pb.head_dim == 64 and not pb.causal and n_seq >= 1 and seq_len >= 64 and seq_len % 64 == 0
+                and n_seq < 65536 and g >= 1 and (g & (g - 1)) == 0)
 
     def _planes(self, x_f32):
         """fp32 -> the operand format of the DPT heads: (hi, lo) planes in "high" precision, (lowp, None) otherwise."""

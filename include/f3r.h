@@ -302,7 +302,8 @@ typedef struct f3r_attn_args {
      elements of these 128-wide heads (ldq >= n_heads * 128), and the scores are q_hi k_hi + q_lo k_hi + q_hi k_lo with fp32 accumulation -- three
      MFMA products per score block, P V unchanged (V^T, o, the parked state: head_dim 64 layouts).  Only the hand-scheduled kernel
      f3r_attn_asm_qk3_f16 reads this layout (csrc/asm/attn_gen.py AttnGen(qk_planes = 2): 256-query workgroups): fp16, head_dim 64, q_prescaled, and
-     the eligibility rules of kernel_sel 0 with tq >= 64 and no minimum number of keys -- anything else is F3R_ERR_UNSUPPORTED, never a fallback. */
+     the eligibility rules of kernel_sel 0 with tq >= 64 and no minimum number of keys -- anything else is F3R_ERR_UNSUPPORTED, never a fallback.
+     These kernels carry the softmax state at ANY batch: sequence z owns rows [z tq, (z + 1) tq) of st_o / st_ml. */
   int32_t qk_planes;
   /* Compute units the persistent (work-stealing) form leaves FREE (ABI 340; 0 = none; needs sched_counter).  The hand-scheduled kernels hold a
      CU completely -- one 488-register wave per SIMD -- so while a launch of one persistent workgroup per CU runs, no other kernel of more than a

@@ -190,3 +190,12 @@ def test_emulated_fp8_corrections_stay_close_to_the_exact_planes():
     errs = []
     assert emu_attn.run_case(qk_planes=2, corr="f8", n_tiles=4, n_heads=2, wgs=((0, 1, 0),), spike=True, errs=errs) < 6e-4
     assert errs and errs[0][1] < 1e-4, errs
+
+
+@pytest.mark.parametrize("corr", ["f16", "f8"])
+def test_emulated_three_product_form_parks_its_state_per_sequence(corr):
+    """what precision "robust" launches for the encoder: ONE launch over a batch of sequences with state_out; sequence z owns state rows [z tq, (z + 1)
+    tq) (the other kernels carry state at batch 1 only); the output is computed from the parked state as f3r_attn_state_finish does; tq = 300: a
+    partial last workgroup per sequence must not write another sequence's rows"""
+    import emu_attn
+    assert emu_attn.run_case(qk_planes=2, corr=corr, n_tiles=2, n_heads=2, batch=3, wgs=((0, 1, 2), (1, 0, 1), (0, 0, 0)), q_blocks=2, tq=300, finish_state=True) < 6e-4

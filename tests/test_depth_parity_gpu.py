@@ -109,10 +109,11 @@ def test_vit_large_depth_with_heavy_tailed_weights_vs_cpu_oracle(built_lib):
         O.ATTN_IMPL = "naive"
     gv = views_to(views, DEV)
     report = {}
-    for dt, precision in ((torch.float16, "high"), (torch.float16, "robust"), (torch.float16, "robust+fp16"), (torch.float16, "fast"), (torch.bfloat16, "fast"),
-                          (torch.float16, "exact")):
+    for dt, precision in ((torch.float16, "high"), (torch.float16, "robust"), (torch.float16, "robust+fp16"), (torch.float16, "robust+encoder"), (torch.float16, "fast"),
+                          (torch.bfloat16, "fast"), (torch.float16, "exact")):
         m = Fast3R(enc, dec, head, compute_dtype=dt, precision=precision.split("+")[0]).eval()
         m.robust_corrections = "fp16" if precision.endswith("+fp16") else "fp8"   # where the score corrections run: fp8 MFMA (default) or two more fp16 products
+        m.robust_encoder_attention = "planes" if precision.endswith("+encoder") else "fp32"   # the encoder's attention on the three-product kernel too (faster, less margin)
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV)
         with torch.no_grad():
@@ -127,7 +128,8 @@ def test_vit_large_depth_with_heavy_tailed_weights_vs_cpu_oracle(built_lib):
     assert hi <= fast and hi <= 5e-3, report
     # round 6: precision "robust" (linear layers X3, Q K^T from hi + lo planes on f3r_attn_asm_qk3_f16) is the 16-bit-operand tier that DOES hold the
     # bar on this distribution (CPU emulation of the same operand set: 3.6e-4, oracle/precision_study.py --study robust_vitl)
-    assert robust <= TOL and max(report[("float16", "robust+fp16")].values()) <= TOL, report
+    assert robust <= TOL and max(report[("float16", "robust+fp16")].values()) <= TOL and max(report[("float16", "robust+encoder")].values()) <= TOL, report
+    assert robust <= 3e-4, report   # the default (fp32 attention in the encoder) keeps a wide margin: measured 7.8e-5
 
 
 def test_vit_large_n100_stress_weights_vs_fp32_equivalent_path(built_lib):

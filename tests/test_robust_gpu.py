@@ -230,3 +230,24 @@ def test_calibrate_precision_reports_every_tier_and_recommends_the_cheapest_with
         with torch.no_grad():
             next(m.parameters()).mul_(1.0)
         assert not m.precision_is_calibrated()   # the weights' version counter moved: the report is about other weights
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+def test_three_product_kernel_batch_of_sequences_parks_state_per_sequence(built_lib, planes):
+    """the encoder of precision "robust": one launch over a batch of sequences (one per view), state parked per sequence -- bit-identical to one
+    launch per sequence; 1000 tokens of 1024 + a partial last workgroup would be ineligible (64-key tiles), so: 5 sequences of 1088 tokens, 4 heads"""
+    n_seq, S, H = 5, 1088, 4
+    qkv = _qkv(n_seq * S, H, H, 9).to(DEV)
+    qp, kp, vt = ops.qkv_planes(qkv, H, H, n_seq, S, 0.125 * LOG2E, torch.float16, planes=planes)
+    ld = vt.shape[-1]
+    st = ops.attention_state(n_seq * S, H, DEV)
+    ops.attention(qp, st[0], H, 0.125, [(kp, vt.view(n_seq * H * 64, ld), S, S * H * 128, H * 64 * ld)], tq=S, batch=n_seq, q_batch_stride=S * H * 128,
+                  o_batch_stride=S * H * 64, q_prescaled=True, state=st, state_out=True, qk_planes=planes, kernel_sel=2)
+    o_hi, o_lo = ops.attention_state_finish(st, H, 64, torch.float16)
+    for z in range(n_seq):
+        st1 = ops.attention_state(S, H, DEV)
+        rows = slice(z * S, (z + 1) * S)
+        ops.attention(qp[rows], st1[0], H, 0.125, [(kp[rows], vt[z], S, 0, 0)], q_prescaled=True, state=st1, state_out=True, qk_planes=planes, kernel_sel=2)
+        a_hi, a_lo = ops.attention_state_finish(st1, H, 64, torch.float16)
+        assert torch.equal(a_hi, o_hi[rows]) and torch.equal(a_lo, o_lo[rows]), z
+    assert torch.isfinite(o_hi.float()).all()

@@ -35,7 +35,7 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None, corr="f16"):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None, corr="f16", finish_state=False):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2).  steal = G > 0: the work-stealing form -- G
@@ -43,6 +43,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     find the counter exhausted, the last one to leave zeroes it); `wgs` then lists the work items whose output is compared.
     qk_planes = 2: the three-product form (AttnGen(qk_planes=2), precision "robust"): Q and K rows hold [hi (64) | lo (64)] fp16 per head; the reference
     is float64 on hi + lo; errs (a list) also receives the distance to the reference computed from the hi planes alone (what one product gives).
+    finish_state: ONE launch with state_out (what precision "robust" issues, batches included: sequence z owns state rows [z tq, (z + 1) tq)) and
+    the output is computed here from the parked state, O / (l0 + l1), as f3r_attn_state_finish does.
     corr = "f8" (with qk_planes = 2): rows [hi fp16 | e4m3(hi) | e4m3(lo 2^12)] per head, the correction products on the block-scaled fp8 MFMA; the
     reference is float64 on EXACTLY those planes: q_hi k_hi + dq(q_lo8) dq(k_hi8) + dq(q_hi8) dq(k_lo8)."""
     rng = np.random.default_rng(seed)
@@ -104,8 +106,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         assert len(segs) == 1
     o = np.full((batch, tq, D), 0x7E00, np.uint16)
     a_o = mem.alloc(o)
-    st_o = mem.alloc(np.full((tq, D), np.nan, np.float32))
-    st_ml = mem.alloc(np.full((tq, n_heads, 4), np.nan, np.float32))
+    st_o = mem.alloc(np.full((batch * tq, D), np.nan, np.float32))
+    st_ml = mem.alloc(np.full((batch * tq, n_heads, 4), np.nan, np.float32))
     a_dbg = mem.alloc(np.zeros(56, np.uint32)) if counters is not None else 0
     nx = -(-tq // WQ)
     a_sched = mem.alloc(np.zeros(2, np.uint32)) if steal else 0
@@ -117,6 +119,8 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
         assert len(segs) >= 2 and batch == 1
         launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs[:1]], flags=attn_gen.FLAG_STATE_OUT, **common))
         launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs[1:]], flags=attn_gen.FLAG_STATE_IN, **common))
+    elif finish_state:
+        launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs], flags=attn_gen.FLAG_STATE_OUT, **common))
     else:
         launches.append(pack_args(a_q, a_o, DQ * 2, DKm * 2, ldvt * 2, D * 2, [s[:3] for s in segs], **common))
     prog = g.build()
@@ -138,6 +142,11 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
             w = Workgroup(prog, mem, a_arg, wg, 4, g.lds_bytes, dtype)
             steps += w.run()
         og = mem.get(a_o, np.uint16, (batch, tq, D))
+        if finish_state:   # the output from the parked state (rows z tq + r), rounded like the finishing pass rounds its hi plane
+            so = mem.get(st_o, np.float32, (batch, tq, D)).astype(np.float64)
+            ml = mem.get(st_ml, np.float32, (batch, tq, n_heads, 4)).astype(np.float64)
+            l = np.repeat(ml[..., 1] + ml[..., 2], HD, axis=-1)
+            og = f32_to_half((so / l).astype(np.float32), dtype)
         x, head, b = wg
         kvh = head >> kv_shift
         r1 = min(tq, (x + 1) * WQ)
