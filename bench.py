@@ -89,6 +89,9 @@ def parse(argv=None):
                          "communicators) + one remote launch per arrived shard; auto: three fusion layers with each form in the first warm-up "
                          "forward, then the one that exposed less (fast3r_amd/dist.py; the per-peer form has only ever run over gloo)")
     ap.add_argument("--p2p-channels", type=int, default=3)
+    ap.add_argument("--reserve-cus", type=int, default=32,
+                    help="view-sharded runs (and --emulate-rank): CUs the persistent local-shard attention launch leaves to the kernels of the K / V^T "
+                         "exchange (f3r_attn_args.reserve_cus; profiles/r06_exchange_under_persistent_attention.json)")
     return ap.parse_args(argv)
 
 
@@ -347,7 +350,7 @@ def main():
         if world > 1 and not dry:   # the first multi-GPU run must explain itself if it stalls: RCCL's own log per rank, read back by the watchdog
             # one RCCL workgroup per channel must find a free CU while the persistent local-shard attention launch runs: the sharded model leaves
             # ViewSharding.reserve_cus (32) CUs free, so RCCL is capped at as many channels (profiles/r06_exchange_under_persistent_attention.json)
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(1, args.reserve_cus)) if args.reserve_cus > 0 else "32")
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/f3r_bench_rccl_rank{rank}_%p.log")
         try:
@@ -534,7 +537,7 @@ def main():
         model.load_state_dict(state_dict_for(weights), strict=True)
         model = model.to(dev)
         if emu:
-            model.emulate_rank(args.emulate_rank, args.of, exchange="allgather" if args.exchange == "auto" else args.exchange)
+            model.emulate_rank(args.emulate_rank, args.of, exchange="allgather" if args.exchange == "auto" else args.exchange, reserve_cus=args.reserve_cus)
         if fo:
             step_fn = make_fusion_only_step(model, V, lp, dev)
         else:
@@ -543,7 +546,7 @@ def main():
                 return model(vlist)
         def setup_and_warm(exchange):
             if distributed:
-                model.shard_views(exchange=exchange, p2p_channels=args.p2p_channels)
+                model.shard_views(exchange=exchange, p2p_channels=args.p2p_channels, reserve_cus=args.reserve_cus)
             with torch.no_grad():
                 for _ in range(warmup):
                     step_fn()
@@ -609,7 +612,7 @@ def main():
             res_emu = {"comm_bytes_per_layer_into_this_gpu": kvx.comm_bytes_per_layer, "fusion_layers": int(dec["depth"]),
                        "xgmi_link_budget": "7 links x ~153 GB/s per GPU (MI355X_MICROARCH / SURVEY section 5)",
                        "allgather_ms_per_layer_all_links": kvx.comm_bytes_per_layer / (7 * 153e9) * 1e3,
-                       "exchange": args.exchange, "attention_launches_per_layer": len(fus) // max(1, n_layers),
+                       "exchange": args.exchange, "reserve_cus": args.reserve_cus, "attention_launches_per_layer": len(fus) // max(1, n_layers),
                        "attention_ms_per_layer": avg_ms}
         # how often the lazy softmax reference of the hand-scheduled kernel moved (f3r_attn_args.dbg_counters, summed over every launch of
         # the timed steps that took that kernel): per wave and 64-key tile, the forced first re-base of each wave not counted
