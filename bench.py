@@ -623,7 +623,7 @@ def main():
                                           "waves": waves, "tiles_per_wave": tiles_per_wave,
                                           "note": "summed over the timed steps; the forced first re-base of each wave is excluded"}
         live = live_roofline(counters, avg_ms, achieved, int(dec["embed_dim"]) // int(dec["num_heads"]), sampler.summary(),
-                             qk_products=3 if any("qk3" in n for n in kname) else 1)
+                             qk_products=3 if any("qk3" in n for n in kname) else 1, fp8_corrections=any("qk3f8" in n for n in kname))
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "ms_per_step_per_rank": [x / steps * 1e3 for x in per_rank(mine)], "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "weights": weights, "attn_rebase": rebase,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,
@@ -806,7 +806,7 @@ def main():
     shutdown()
 
 
-def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power, qk_products=1):
+def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power, qk_products=1, fp8_corrections=False):
     """What the timed fusion-attention launches THEMSELVES recorded (f3r_attn_args.dbg_counters, ABI 330): every wave of the hand-scheduled
     kernel brackets its life with s_memtime (shader clock) and s_memrealtime (constant clock), and counts the 64-key tiles it walked.  One wave
     per SIMD, so a wave's cycles are its SIMD's cycles: matrix-pipe utilisation = 32 cycles x MFMAs issued / cycles lived; the effective shader
@@ -818,14 +818,16 @@ def live_roofline(counters, avg_launch_ms, achieved_tflops, head_dim, power, qk_
     from fast3r_amd import _lib
     khz = int(_lib.lib().f3r_wall_clock_khz()) or 100000
     qpw = 4 if (head_dim == 64 and qk_products == 1) else 2
-    # Q K^T k-steps (x 3 for the three-product kernel of precision "robust") + P V blocks of one 64-key tile, per wave
-    mfma_per_tile = qpw * (2 * (head_dim // 16) * qk_products + 4 * ((head_dim + 31) // 32))
+    # Q K^T k-steps (x 3 for the three-product kernels of precision "robust") + P V blocks of one 64-key tile, per wave, in units of ONE 32-cycle
+    # MFMA (the two block-scaled fp8 MFMAs that replace eight fp16 k-steps in f3r_attn_asm_qk3f8_f16 take 64 cycles each = 4 units per half tile)
+    nk, ndb = head_dim // 16, (head_dim + 31) // 32
+    qk_units = nk * qk_products if not fp8_corrections else nk + 4
+    mfma_per_tile = qpw * (2 * qk_units + 4 * ndb)
     clock_ghz = cycles / (ticks / (khz * 1e3)) / 1e9
     util = 32.0 * mfma_per_tile * tiles / cycles
     implied = util * clock_ghz * 256 * 4 * 1024 / 1e3   # TFLOP/s EXECUTED on the matrix pipe
     if qk_products != 1:   # `achieved` counts one product per score (algorithmic): scale the implied rate to the same unit
-        nk, ndb = head_dim // 16, (head_dim + 31) // 32
-        implied *= (2 * nk + 4 * ndb) / (2 * nk * qk_products + 4 * ndb)
+        implied *= (2 * nk + 4 * ndb) / (2 * qk_units + 4 * ndb)
     # per XCD: with one item per workgroup id the ids are dealt round-robin over the 8 XCDs (equal work each) and the launch lasts as long as the
     # slowest XCD needs; with work stealing (f3r_attn_args.sched_counter) an XCD takes items as fast as its clock lets it, and the XCDs' busy
     # times (the tick sums) come out equal instead of their wave counts

@@ -709,11 +709,12 @@ def attention_f32(qkv, n_heads, n_seq, seq_len, scale, lp, want_f32=False, head_
     a.n_seq, a.tq, a.q_pos0, a.k_pos0 = n_seq, seq_len, int(q_pos0), int(k_pos0)
     a.n_heads, a.kv_group, a.causal, a.dtype, a.head_dim, a.scale = n_heads, max(1, int(kv_group)), int(bool(causal)), dtype_id(lp), int(head_dim), float(scale)
     ws_bytes = int(_lib.lib().f3r_attn_f32_mfma_workspace(ctypes.byref(a))) if a.tk >= ATTN_F32_MFMA_MIN_KEYS else 0
-    if ws_bytes > 0:  # the same attention as three-plane MFMA products (f3r_exact_mfma.hip): ~1e-6 of the FMA kernel at 10x its speed
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
-        check(_lib.lib().f3r_attn_f32_mfma(ctypes.byref(a), ptr(ws), ws_bytes, stream_ptr()), "f3r_attn_f32_mfma")
-    else:
-        check(_lib.lib().f3r_attn_f32_ex(ctypes.byref(a), stream_ptr()), "f3r_attn_f32_ex")
+    with _timed(4.0 * a.tq * a.tk * head_dim * n_heads * n_seq, 0.0, "attention"):
+        if ws_bytes > 0:  # the same attention as three-plane MFMA products (f3r_exact_mfma.hip): ~1e-6 of the FMA kernel at 10x its speed
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
+            check(_lib.lib().f3r_attn_f32_mfma(ctypes.byref(a), ptr(ws), ws_bytes, stream_ptr()), "f3r_attn_f32_mfma")
+        else:
+            check(_lib.lib().f3r_attn_f32_ex(ctypes.byref(a), stream_ptr()), "f3r_attn_f32_ex")
     return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 
