@@ -4,6 +4,7 @@
 // decides per call whether a launch goes here (f3r_attn_args.kernel_sel, include/f3r.h).
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -60,6 +61,7 @@ struct DevKernels {
   hipFunction_t fn[kNumHd][2] = {};  // [head_dim index][F3R_F16, F3R_BF16]
   hipFunction_t fn_qk3 = nullptr;    // head_dim 64, fp16, Q and K as hi + lo planes (f3r_attn_args.qk_planes = 2)
   hipFunction_t fn_qk3f8 = nullptr;  // ... with the correction products on the fp8 MFMA (qk_planes = 3)
+  hipFunction_t fn_q256[2] = {};     // head_dim 64 with 256-query work items (two query blocks per wave): small launches (f3r_attn_asm_use_q256)
 };
 std::map<int, DevKernels> g_dev;
 std::mutex g_mu;
@@ -85,13 +87,35 @@ hipFunction_t get_fn(int dtype, int hd, int qk_planes = 1) {
         }
       if (hipModuleGetFunction(&d.fn_qk3, d.mod, "f3r_attn_asm_qk3_f16") != hipSuccess) d.fn_qk3 = nullptr;
       if (hipModuleGetFunction(&d.fn_qk3f8, d.mod, "f3r_attn_asm_qk3f8_f16") != hipSuccess) d.fn_qk3f8 = nullptr;
+      if (hipModuleGetFunction(&d.fn_q256[F3R_F16], d.mod, "f3r_attn_asm_q256_f16") != hipSuccess) d.fn_q256[F3R_F16] = nullptr;
+      if (hipModuleGetFunction(&d.fn_q256[F3R_BF16], d.mod, "f3r_attn_asm_q256_bf16") != hipSuccess) d.fn_q256[F3R_BF16] = nullptr;
     }
     (void)hipGetLastError();
   }
+  if (qk_planes == -256) return hd == 64 ? d.fn_q256[dtype] : nullptr;   // (internal code: the 256-query form of the head_dim-64 kernel)
   return qk_planes == 3 ? d.fn_qk3f8 : qk_planes == 2 ? d.fn_qk3 : d.fn[hi][dtype];
 }
 
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+int num_cus();
+
+// Small launches at head_dim 64: 512-query work items do not always fill the chip -- N = 3 views are 96 items on 256 CUs.  The same kernel with two
+// query blocks per wave (256-query items, f3r_attn_asm_q256_*) has twice the items; an item takes 0.545 of a 512-query item's time on random,
+// sharply attending operands (profiles/r06_attn_q256_vs_q512_items_by_n.jsonl: N = 3 1.78x faster, N = 20 +7.5 %) but ~0.64 inside the model
+// on near-uniform attention, where the 512-query kernel never leaves its fast path (fusion-only N = 20 with default-init weights: 65.6 ms against
+// 63.0 ms, profiles/r06_q256_in_model_ab.jsonl).  So the form is taken only where the round count wins at the in-model ratio: launches of less
+// than one round of 512-query items (N <= 7 views: 24.8 -> 24.3 ms end to end at N = 3).
+bool use_q256(const f3r_attn_args& a, int hd, int qkp) {
+  if (hd != 64 || qkp != 1) return false;
+  static const char* force = getenv("F3R_ATTN_Q256");   // measurement only: "0" = never, "1" = always (tools/kernel_bench.py); the product never sets it
+  if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1' && get_fn(a.dtype, hd, -256) != nullptr;
+  const int64_t cus = num_cus();
+  const int64_t hb = (int64_t)a.n_heads * a.batch;
+  const int64_t n512 = (a.tq + 511) / 512 * hb, n256 = (a.tq + 255) / 256 * hb;
+  const double t512 = (double)((n512 + cus - 1) / cus), t256 = 0.64 * (double)((n256 + cus - 1) / cus);
+  return t256 < 0.97 * t512 && get_fn(a.dtype, hd, -256) != nullptr;
+}
 
 int num_cus() {
   int dev = 0, cus = 0;
@@ -100,6 +124,12 @@ int num_cus() {
 }
 
 }  // namespace
+
+// does an (eligible) launch take the 256-query form of the head_dim-64 kernel?  (f3r_attn_kernel_name)
+bool f3r_attn_asm_uses_q256(const f3r_attn_args& a) {
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  return use_q256(a, hd, a.qk_planes >= 2 ? a.qk_planes : 1);
+}
 
 // Can the hand-scheduled kernel take this launch?  *why names the first obstacle.
 bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why) {
@@ -147,7 +177,8 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   const int qkp = a.qk_planes >= 2 ? a.qk_planes : 1;
-  hipFunction_t fn = get_fn(a.dtype, hd, qkp);
+  const bool q256 = use_q256(a, hd, qkp);
+  hipFunction_t fn = get_fn(a.dtype, hd, q256 ? -256 : qkp);
   if (!fn) {
     f3r_set_error("f3r_attn_fwd: the embedded hand-scheduled kernel could not be loaded on this device");
     return F3R_ERR_LAUNCH;
@@ -185,7 +216,8 @@ int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
   // Work stealing (f3r_attn_args.sched_counter): one persistent workgroup per CU takes (q block, head, batch) items from a shared counter, so
   // the XCDs -- which the hardware feeds round-robin by workgroup id whatever their clocks -- finish together.  Worth it from two rounds of
   // workgroups on; the kernel's magic-number division needs item x period < 2^32.
-  const unsigned nx = (unsigned)((a.tq + 4 * wave_rows(hd, qkp) - 1) / (4 * wave_rows(hd, qkp)));
+  const int64_t wg_rows = q256 ? 256 : 4 * wave_rows(hd, qkp);
+  const unsigned nx = (unsigned)((a.tq + wg_rows - 1) / wg_rows);
   unsigned gx = nx, gy = (unsigned)a.n_heads, gz = (unsigned)a.batch;
   const uint64_t n_work = (uint64_t)nx * gy * gz, nxy = (uint64_t)nx * gy;
   unsigned cus = (unsigned)num_cus();

@@ -199,3 +199,15 @@ def test_emulated_three_product_form_parks_its_state_per_sequence(corr):
     partial last workgroup per sequence must not write another sequence's rows"""
     import emu_attn
     assert emu_attn.run_case(qk_planes=2, corr=corr, n_tiles=2, n_heads=2, batch=3, wgs=((0, 1, 2), (1, 0, 1), (0, 0, 0)), q_blocks=2, tq=300, finish_state=True) < 6e-4
+
+
+@pytest.mark.parametrize("kw", [dict(n_tiles=1), dict(n_tiles=3), dict(n_tiles=6, spike=True), dict(dtype="bf16", n_tiles=4, spike=True, tol=5e-3),
+                                dict(n_tiles=[2, 1, 3], spike=True), dict(n_tiles=[2, 3], split_state=True), dict(tq=300, q_blocks=2, wgs=((1, 0, 0), (0, 1, 0))),
+                                dict(kv_shift=1, n_heads=4, batch=2, wgs=((0, 3, 1),)), dict(tq=700, n_heads=1, n_tiles=[1, 1], split_state=True, wgs=((0, 0, 0), (2, 0, 0)), steal=3)])
+def test_emulated_head_dim_64_with_256_query_work_items(kw):
+    """AttnGen(head_dim=64, qpw=2) (round 6, kernels f3r_attn_asm_q256_*): the head_dim-64 kernel with two query blocks per wave -- 256-query work items
+    for launches whose 512-query items do not fill the chip evenly (f3r_attn_asm.hip use_q256).  Same state layout as every other kernel."""
+    import emu_attn
+    kw = dict(kw)
+    tol = kw.pop("tol", 6e-4)
+    assert emu_attn.run_case(qpw=2, **kw) < tol

@@ -351,7 +351,11 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
             assert ctr.tolist() == [0, 0] and torch.equal(o_r.view(torch.int16), plain.view(torch.int16)), rsv
         ops.ATTN_COUNTERS = saved_ctrs
         c = [int(x) & 0xFFFFFFFF for x in ops.ATTN_COUNTERS.tolist()]
-        wq = 512 if hd == 64 else 256
+        ops.ATTN_TIMER = []   # which form did these launches take?  (head_dim 64: 512-query items, or 256-query ones for launches that fill the chip unevenly)
+        run(qs, k, v, H, hd=hd)
+        q256 = "q256" in ops.ATTN_TIMER[0][5]
+        ops.ATTN_TIMER = None
+        wq = 512 if (hd == 64 and not q256) else 256
         waves = 3 * 4 * (-(-Tq // wq)) * H
         per_xcd = [c[8 + 6 * x + 4] | (c[8 + 6 * x + 5] << 32) for x in range(8)]
         assert c[1] == waves and sum(per_xcd) == waves and all(w > 0 for w in per_xcd), (c[:4], per_xcd)
@@ -359,3 +363,28 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
         ops.ATTN_WORK_STEALING = saved
         ops.ATTN_COUNTERS = None
     assert_close(stolen.float()[:1024], ref_prescaled(qs[:1024], k, v, H, hd=hd), 2 * lp_tol(dt), "work-stealing attention vs fp64")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Tq,H,expect", [(3072, 16, "q256"), (20480, 16, "asm_"), (8192, 16, "asm_"), (40960, 16, "asm_"), (3000, 5, "q256"), (6144, 16, "q256")])
+def test_small_launches_take_256_query_work_items(built_lib, dt, Tq, H, expect):
+    """f3r_attn_asm_q256_* (round 6): at head_dim 64 a launch of less than one round of 512-query items -- N = 3 views: 96 items on 256 CUs -- runs the
+    same kernel with two query blocks per wave (twice the items at 0.55 - 0.64 of an item's time); a full round (N = 8: 256 items) or more keeps the
+    512-query form (N = 20: 2.5 rounds would win on paper and on random operands, and loses inside the model: f3r_attn_asm.hip use_q256).  Which form a launch takes is the library's choice (f3r_attn_kernel_name says which); both are held
+    to the same float64 reference."""
+    import ctypes
+    from fast3r_amd import _lib
+    Tk = 2048
+    qs = rnd((Tq, H * 64), dt, 5, 0.125 * LOG2E * 1.5)
+    k, v = rnd((Tk, H * 64), dt, 6, 1.5), rnd((Tk, H * 64), dt, 7)
+    ops.ATTN_TIMER = []
+    try:
+        o = run(qs, k, v, H, sel=2)
+        name = ops.ATTN_TIMER[0][5]
+    finally:
+        ops.ATTN_TIMER = None
+    assert ("f3r_attn_asm_q256_" in name) == (expect == "q256") and "f3r_attn_asm_" in name, name
+    rows = slice(0, 2048)
+    assert_close(o.float()[rows], ref_prescaled(qs[rows], k, v, H), 2 * lp_tol(dt), f"{name} vs fp64")
+    tail = slice(Tq - 300, Tq)
+    assert_close(o.float()[tail], ref_prescaled(qs[tail], k, v, H), 2 * lp_tol(dt), f"{name} vs fp64, last rows")

@@ -35,7 +35,7 @@ def pack_args(q, o, ldq, ldk, ldvt, ldo, segs, q_bs=0, o_bs=0, kv_shift=0, flags
 
 
 def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, rowsum="pkadd", seed=0, batch=1, kv_shift=0, q_blocks=1,
-             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None, corr="f16", finish_state=False):
+             gen_kwargs=None, split_state=False, layout=2, tq=None, counters=None, head_dim=64, steal=0, qk_planes=1, errs=None, corr="f16", finish_state=False, qpw=None):
     """tq: number of query rows when it is not 512 * q_blocks (layout 2: the last workgroup may be partial; the buffers hold exactly tq
     rows, so a store past the end raises in the emulator's memory model).  counters: a list that receives the kernel's debug counters
     {re-base block entries, waves, tiles walked} (f3r_attn_args.dbg_counters; layout 2).  steal = G > 0: the work-stealing form -- G
@@ -49,7 +49,7 @@ def run_case(dtype="f16", n_tiles=3, n_heads=2, wgs=((0, 1, 0),), spike=False, r
     reference is float64 on EXACTLY those planes: q_hi k_hi + dq(q_lo8) dq(k_hi8) + dq(q_hi8) dq(k_lo8)."""
     rng = np.random.default_rng(seed)
     HD = head_dim
-    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, qk_planes=qk_planes, corr=corr, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
+    g = attn_gen.AttnGen(dtype, rowsum=rowsum, head_dim=HD, qk_planes=qk_planes, corr=corr, qpw=qpw, **(gen_kwargs or {}))   # (layout: accepted for old call sites; there is one generator)
     WQ = g.WG_Q   # query rows of a workgroup (512 at head_dim 64, 256 otherwise)
     seg_tiles = list(n_tiles) if isinstance(n_tiles, (list, tuple)) else [n_tiles]
     tq, tk = (WQ * q_blocks if tq is None else tq), 64 * sum(seg_tiles)
