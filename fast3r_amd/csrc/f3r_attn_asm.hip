@@ -105,7 +105,7 @@ int num_cus();
 // sharply attending operands (profiles/r06_attn_q256_vs_q512_items_by_n.jsonl: N = 3 1.78x faster, N = 20 +7.5 %) but ~0.64 inside the model
 // on near-uniform attention, where the 512-query kernel never leaves its fast path (fusion-only N = 20 with default-init weights: 65.6 ms against
 // 63.0 ms, profiles/r06_q256_in_model_ab.jsonl).  So the form is taken only where the round count wins at the in-model ratio: launches of less
-// than one round of 512-query items (N <= 7 views: 24.8 -> 24.3 ms end to end at N = 3).
+// than HALF a round of 512-query items (N <= 4 views: 24.8 -> 24.3 ms end to end at N = 3).
 bool use_q256(const f3r_attn_args& a, int hd, int qkp) {
   if (hd != 64 || qkp != 1) return false;
   static const char* force = getenv("F3R_ATTN_Q256");   // measurement only: "0" = never, "1" = always (tools/kernel_bench.py); the product never sets it

@@ -366,7 +366,7 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Tq,H,expect", [(3072, 16, "q256"), (20480, 16, "asm_"), (8192, 16, "asm_"), (40960, 16, "asm_"), (3000, 5, "q256"), (6144, 16, "q256")])
+@pytest.mark.parametrize("Tq,H,expect", [(3072, 16, "q256"), (20480, 16, "asm_"), (8192, 16, "asm_"), (40960, 16, "asm_"), (3000, 5, "q256"), (4096, 16, "q256"), (6144, 16, "asm_")])
 def test_small_launches_take_256_query_work_items(built_lib, dt, Tq, H, expect):
     """f3r_attn_asm_q256_* (round 6): at head_dim 64 a launch of less than one round of 512-query items -- N = 3 views: 96 items on 256 CUs -- runs the
     same kernel with two query blocks per wave (twice the items at 0.55 - 0.64 of an item's time); a full round (N = 8: 256 items) or more keeps the
