@@ -58,6 +58,10 @@ def parse(argv=None):
     ap.add_argument("--precision", default="high", choices=["fast", "high", "robust"],
                     help="high: split-precision GEMM operands (weights hi+lo in the transformer, both operands in the heads), see DESIGN.md section 3 (Precision modes); "
                          "the default pair (fp16, high) is the operand format that meets the 1e-3 parity bar on the stress fixture")
+    ap.add_argument("--head-corrections", default="fp8", choices=["fp16", "fp8"],
+                    help="precision high: where the correction products of the DPT heads' 3x3 convolutions run -- two more fp16 products, or the "
+                         "block-scaled fp8 MFMA (Fast3R.head_corrections; f3r.h F3R_SPLIT_X3F8)")
+    ap.add_argument("--no-fused-tail", action="store_true", help="head[2] -> f3r_dpt_final as two launches instead of the fused epilogue (f3r_gemm_args.fin_w)")
     ap.add_argument("--low-plane", default="fp8", choices=["fp16", "fp8"],
                     help="precision high: where the MLPs' correction products A W_lo run -- a second fp16 plane, or the block-scaled fp8 MFMA "
                          "(Fast3R.low_plane; f3r.h F3R_SPLIT_W2F8)")
@@ -530,6 +534,9 @@ def main():
         lp = torch.float16 if dtype_name == "fp16" else torch.bfloat16
         model = Fast3R(enc, dec, head, compute_dtype=lp, precision=precision).eval()
         model.low_plane = args.low_plane
+        model.head_corrections = args.head_corrections
+        if args.no_fused_tail:
+            model.head_tail_fused_min_rows = 1 << 62
         if os.environ.get("F3R_ROBUST_ENCODER"):      # measurement: "planes" = the encoder's attention on the three-product kernel too
             model.robust_encoder_attention = os.environ["F3R_ROBUST_ENCODER"]
         if os.environ.get("F3R_ROBUST_CORR"):         # measurement: "fp16" = the score corrections as two more fp16 products
@@ -793,7 +800,8 @@ def main():
             "dtype": main_res["dtype"], "precision": main_res["precision"], "data": "synthetic", "rccl_ranks_seen": ranks_seen,
             "config": {"workload": workload, "views": V, "views_per_gpu": views_per_gpu,
                        "tokens": V * 1024, "image": "512x512", "parallelism": f"view-sharded x{world}, K/V all-gather per fusion layer" if world > 1 else "single GPU",
-                       "operands": main_res["operands"], "low_plane": args.low_plane},
+                       "operands": main_res["operands"], "low_plane": args.low_plane, "head_corrections": args.head_corrections,
+                       "head_tail_fused": not args.no_fused_tail},
             # `live` = this run's own clock / utilisation / power record; `traffic` and `reference_pmc` are read from committed rocprofv3
             # PMC passes of other runs (they carry their source file) and are there to be compared with `live`, not to stand in for it
             "roofline": dict(main_res["roofline"], traffic=load_traffic(V, world), reference_pmc=load_pmc(main_res["dtype"])),

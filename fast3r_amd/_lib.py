@@ -13,7 +13,7 @@ F3R_F16, F3R_BF16 = 0, 1
 F3R_A_PLAIN, F3R_A_CONV3X3 = 0, 1
 F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_EPI_CONVT = 0, 1, 2
 F3R_ACT_NONE, F3R_ACT_GELU, F3R_ACT_RELU = 0, 1, 2
-F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3, F3R_SPLIT_W2F8 = 0, 1, 2, 3
+F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_X3, F3R_SPLIT_W2F8, F3R_SPLIT_X3F8 = 0, 1, 2, 3, 4
 F3R_MAX_SEG = 8
 
 _c_i64, _c_i32, _c_f32, _c_vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
@@ -42,6 +42,9 @@ class GemmArgs(ctypes.Structure):
         ("out_lp_lo", _c_vp), ("res_lp_lo", _c_vp), ("res_lp2_lo", _c_vp), ("out_relu", _c_vp), ("out_relu_lo", _c_vp),
         ("qkv_dq", _c_i32), ("out_lp_f8", _c_i32),
         ("w_scale", _c_vp), ("W_aux", _c_vp),
+        ("out_f8", _c_vp), ("out_relu_f8", _c_vp),
+        ("fin_w", _c_vp), ("fin_b", _c_vp), ("fin_pts", _c_vp), ("fin_conf", _c_vp),
+        ("fin_n_out", _c_i32), ("fin_depth_mode", _c_i32), ("fin_conf_mode", _c_i32), ("fin_vmin", _c_f32), ("fin_vmax", _c_f32), ("reserved0", _c_i32),
     ]
 
 
@@ -85,6 +88,7 @@ SYMBOLS = {
     "f3r_wall_clock_khz": (ctypes.c_int, []),
     "f3r_patchify": (ctypes.c_int, [_c_vp, _c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_interp_bilinear": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp] + [ctypes.c_int] * 9 + [_c_vp]),
+    "f3r_interp_bilinear_f8": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp] + [ctypes.c_int] * 9 + [_c_vp]),
     "f3r_layernorm": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, ctypes.c_int, _c_vp]),
     "f3r_layernorm_f8": (ctypes.c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, ctypes.c_int, _c_f32, ctypes.c_int, _c_vp]),
     "f3r_gemm": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _c_vp]),
@@ -129,7 +133,7 @@ class F3RError(RuntimeError):
     pass
 
 
-ABI_VERSION = 340  # f3r_version() of include/f3r.h this file mirrors
+ABI_VERSION = 350  # f3r_version() of include/f3r.h this file mirrors
 
 
 def lib():

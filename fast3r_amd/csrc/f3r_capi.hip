@@ -24,7 +24,7 @@ int f3r_check_launch(const char* what) {
   return F3R_OK;
 }
 
-extern "C" int f3r_version(void) { return 340; /* 0.3.3: round-5 ABI (dbg_counters widened to uint32[8] with two clock sums, f3r_wall_clock_khz) */ }
+extern "C" int f3r_version(void) { return 350; /* 0.3.5: round-6 ABI (include/f3r.h f3r_version) */ }
 
 extern "C" int f3r_wall_clock_khz(void) {
   int dev = 0, khz = 0;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <class T>
 __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ in_lo, uint16_t* __restrict__ out,
                                   uint16_t* __restrict__ out_lo, int B, int h, int w, int C, int oh, int ow, int full_h, int full_w,
-                                  int64_t n_items) {
+                                  int64_t n_items, uint8_t* __restrict__ out_f8 = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const int cv = C / 8;
@@ -167,6 +167,7 @@ __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_
     q00 = *(const u32x4*)(in_lo + o00); q01 = *(const u32x4*)(in_lo + o01); q10 = *(const u32x4*)(in_lo + o10); q11 = *(const u32x4*)(in_lo + o11);
   }
   u32x4 o, ol;
+  float y[8], yl[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     // torch's upsample_bilinear2d: hy*(hx*p00 + lx*p01) + ly*(hx*p10 + lx*p11)
@@ -175,10 +176,29 @@ __global__ void upsample2x_kernel(const uint16_t* __restrict__ in, const uint16_
     const float bq = hy * (hx * (hi_f<T>(p00[k]) + hi_f<T>(q00[k])) + lx * (hi_f<T>(p01[k]) + hi_f<T>(q01[k]))) +
                      ly * (hx * (hi_f<T>(p10[k]) + hi_f<T>(q10[k])) + lx * (hi_f<T>(p11[k]) + hi_f<T>(q11[k])));
     o[k] = pack2<T>(a, bq);
-    ol[k] = pack2<T>(a - lo_f<T>(o[k]), bq - hi_f<T>(o[k]));
+    y[2 * k] = a;
+    y[2 * k + 1] = bq;
+    yl[2 * k] = a - lo_f<T>(o[k]);
+    yl[2 * k + 1] = bq - hi_f<T>(o[k]);
+    ol[k] = pack2<T>(yl[2 * k], yl[2 * k + 1]);
   }
   *(u32x4*)(out + pix * C + c8 * 8) = o;
   if (out_lo) *(u32x4*)(out_lo + pix * C + c8 * 8) = ol;
+  if (out_f8) {  // the fp8 planes of the next F3R_SPLIT_X3F8 convolution: per pixel [C hi8 | C lo8], lo8 = e4m3((y - fp16(y)) 2^12); both clamped to +-448
+    auto cl = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+    u32x2 h8, l8;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      int wv = __builtin_amdgcn_cvt_pk_fp8_f32(cl(y[4 * k]), cl(y[4 * k + 1]), 0, false);
+      wv = __builtin_amdgcn_cvt_pk_fp8_f32(cl(y[4 * k + 2]), cl(y[4 * k + 3]), wv, true);
+      h8[k] = (uint32_t)wv;
+      int wl = __builtin_amdgcn_cvt_pk_fp8_f32(cl(yl[4 * k] * 4096.f), cl(yl[4 * k + 1] * 4096.f), 0, false);
+      wl = __builtin_amdgcn_cvt_pk_fp8_f32(cl(yl[4 * k + 2] * 4096.f), cl(yl[4 * k + 3] * 4096.f), wl, true);
+      l8[k] = (uint32_t)wl;
+    }
+    *(u32x2*)(out_f8 + pix * C * 2 + c8 * 8) = h8;
+    *(u32x2*)(out_f8 + pix * C * 2 + C + c8 * 8) = l8;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ final 1x1 conv + postprocess
@@ -462,8 +482,14 @@ extern "C" int f3r_layernorm_f8(const float* x, const float* gamma, const float*
 
 extern "C" int f3r_interp_bilinear(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int full_h,
                                    int full_w, int out_h, int out_w, int dtype, f3r_stream_t stream) {
+  return f3r_interp_bilinear_f8(in, in_lo, out, out_lo, nullptr, batch, h, w, C, full_h, full_w, out_h, out_w, dtype, stream);
+}
+
+extern "C" int f3r_interp_bilinear_f8(const void* in, const void* in_lo, void* out, void* out_lo, void* out_f8, int batch, int h, int w, int C, int full_h,
+                                      int full_w, int out_h, int out_w, int dtype, f3r_stream_t stream) {
   F3R_REQUIRE(in && out && al16(in) && al16(out) && al16(in_lo) && al16(out_lo), "f3r_interp_bilinear: null/misaligned pointer");
   F3R_DTYPE_OK(dtype);
+  F3R_REQUIRE(!out_f8 || (dtype == F3R_F16 && (((uintptr_t)out_f8) & 7) == 0), "f3r_interp_bilinear_f8: the fp8 planes go with fp16 outputs (8-byte aligned)");
   F3R_REQUIRE(C > 0 && C % 8 == 0, "f3r_interp_bilinear: C %d must be a multiple of 8", C);
   F3R_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0 && out_h <= full_h && out_w <= full_w, "f3r_interp_bilinear: bad sizes");
   const int64_t n = (int64_t)batch * out_h * out_w * (C / 8);
@@ -471,10 +497,10 @@ extern "C" int f3r_interp_bilinear(const void* in, const void* in_lo, void* out,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == F3R_F16)
     hipLaunchKernelGGL(upsample2x_kernel<F16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
-                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n);
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n, (uint8_t*)out_f8);
   else
     hipLaunchKernelGGL(upsample2x_kernel<BF16>, dim3(nblk(n, 256)), dim3(256), 0, s, (const uint16_t*)in, (const uint16_t*)in_lo, (uint16_t*)out,
-                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n);
+                       (uint16_t*)out_lo, batch, h, w, C, out_h, out_w, full_h, full_w, n, (uint8_t*)nullptr);
   return f3r_check_launch("f3r_interp_bilinear");
 }
 

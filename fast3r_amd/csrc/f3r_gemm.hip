@@ -310,7 +310,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   const f3r_gemm_args& a = *args;
   F3R_REQUIRE(a.A && a.W, "f3r_gemm: null operand");
   F3R_REQUIRE(a.M >= 0 && a.N > 0, "f3r_gemm: bad M/N (%lld, %d)", (long long)a.M, a.N);
-  F3R_REQUIRE(a.split >= F3R_SPLIT_NONE && a.split <= F3R_SPLIT_W2F8, "f3r_gemm: bad split %d", a.split);
+  F3R_REQUIRE(a.split >= F3R_SPLIT_NONE && a.split <= F3R_SPLIT_X3F8, "f3r_gemm: bad split %d", a.split);
   if (a.split == F3R_SPLIT_W2F8) {  // rows of [K fp16 | K fp8] on both operands: one kernel family takes them (f3r_gemm_asm.hip), nothing else does
     F3R_REQUIRE(al16(a.A) && al16(a.W) && a.w_scale && (((uintptr_t)a.w_scale) & 3) == 0, "f3r_gemm: W2F8 needs 16-byte aligned A / W and w_scale");
     F3R_REQUIRE(a.K > 0 && a.K % 128 == 0 && a.Kpad == a.K, "f3r_gemm: W2F8 needs K = Kpad, a multiple of 128 (got %d / %d)", a.K, a.Kpad);
@@ -351,7 +351,10 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   const int planes = a.split ? 2 : 1;
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;
-  F3R_REQUIRE(a.split != F3R_SPLIT_X3 || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 split needs A_lo (16-byte aligned) and no a_relu");
+  F3R_REQUIRE((a.split != F3R_SPLIT_X3 && a.split != F3R_SPLIT_X3F8) || (a.A_lo && al16(a.A_lo) && !a.a_relu), "f3r_gemm: X3 / X3F8 split needs A_lo (16-byte aligned) and no a_relu");
+  if (a.split == F3R_SPLIT_X3F8)  // fp16 high planes + fp8 correction planes: the 3x3 convolutions of the DPT head on the 256-tile kernel only
+    F3R_REQUIRE(a.a_mode == F3R_A_CONV3X3 && a.dtype == F3R_F16 && a.conv_C % 128 == 0 && a.w_scale && (((uintptr_t)a.w_scale) & 3) == 0,
+                "f3r_gemm: X3F8 needs a 3x3 convolution with conv_C %% 128 == 0 (got %d), fp16 planes and w_scale", a.conv_C);
   F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 7) || a.kernel_sel == 9 || a.kernel_sel >= 16, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
   F3R_REQUIRE(a.N % 4 == 0, "f3r_gemm: N %d must be a multiple of 4", a.N);
   F3R_REQUIRE(al16(a.A) && al16(a.W), "f3r_gemm: A/W must be 16-byte aligned");
@@ -372,9 +375,18 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     return F3R_ERR_ARG;
   }
   if (a.epi == F3R_EPI_GENERIC) {
-    F3R_REQUIRE(a.out_f32 || a.out_lp, "f3r_gemm: no output");
+    F3R_REQUIRE(a.out_f32 || a.out_lp || a.fin_w, "f3r_gemm: no output");
     F3R_REQUIRE(!a.out_f32 || (al16(a.out_f32) && a.ldo_f32 % 4 == 0 && a.ldo_f32 >= a.N), "f3r_gemm: out_f32 alignment/ld");
     F3R_REQUIRE(!a.out_lp || (al8(a.out_lp) && a.ldo_lp % 4 == 0 && a.ldo_lp >= a.N), "f3r_gemm: out_lp alignment/ld");
+    F3R_REQUIRE((!a.out_f8 && !a.out_relu_f8) || (a.dtype == F3R_F16 && a.N % 8 == 0 && al8(a.out_f8) && al8(a.out_relu_f8) && !a.out_lp_f8),
+                "f3r_gemm: out_f8 / out_relu_f8 need fp16, N %% 8 == 0 and 8-byte aligned buffers");
+    if (a.fin_w) {
+      F3R_REQUIRE(a.fin_b && a.fin_pts && al16(a.fin_w) && (a.fin_n_out == 3 || a.fin_n_out == 4) && (a.fin_n_out == 4 || !a.fin_conf),
+                  "f3r_gemm: fin_w needs fin_b, fin_pts, a 16-byte aligned [4][N] weight and fin_n_out 3 or 4 (a confidence output needs 4)");
+      F3R_REQUIRE(a.fin_depth_mode >= 0 && a.fin_depth_mode <= 2 && (a.fin_conf_mode == 0 || a.fin_conf_mode == 1), "f3r_gemm: bad fin_depth_mode / fin_conf_mode");
+      F3R_REQUIRE(!a.out_f32 && !a.out_relu && !a.out_f8 && !a.out_relu_f8 && !a.res_lp && !a.res_f32 && !a.rowadd,
+                  "f3r_gemm: the fused head tail writes fin_pts / fin_conf only");
+    }
     F3R_REQUIRE(!a.res_f32 || (al16(a.res_f32) && a.ldr_f32 % 4 == 0), "f3r_gemm: res_f32 alignment/ld");
     F3R_REQUIRE(!a.res_lp || (al8(a.res_lp) && a.ldr_lp % 4 == 0), "f3r_gemm: res_lp alignment/ld");
     F3R_REQUIRE(!a.res_lp2 || (al8(a.res_lp2) && a.ldr_lp2 % 4 == 0), "f3r_gemm: res_lp2 alignment/ld");
@@ -405,6 +417,14 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   // kernel_sel: 0 = by shape (256-tile kernel for the large, regular problems), 1 = 128-tile kernel, 2 / 3 = 256-tile kernel with /
   // without the staggered wave rows (measurement; an ineligible shape is an error, not a silent fallback)
   if (a.kernel_sel >= 16) return f3r_gemm256_lab(a, s);
+  if (a.split == F3R_SPLIT_X3F8 || a.fin_w) {  // one kernel family takes these (f3r_gemm256_f8.hip): no second path, no fallback
+    if (!f3r_gemm256_eligible(a)) {
+      f3r_set_error("f3r_gemm: split X3F8 / fin_w but the launch is not eligible for the 256-tile kernel (stride 1, conv_C %% 64 (X3F8: 128) == 0, "
+                    "N %% 128 == 0 (fin_w: N == 128), operand below 4 GiB)");
+      return F3R_ERR_UNSUPPORTED;
+    }
+    return f3r_gemm256_launch(a, s, 1);
+  }
   // 6 = the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/gemm_gen.py), an ineligible launch is an error; 0 takes it for the launches
   // it is built for (the transformer's big linear layers: enough full 256 x 256 tiles to fill its persistent grid, f3r_gemm_asm_preferred);
   // 7 = automatic WITHOUT it

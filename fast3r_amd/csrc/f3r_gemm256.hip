@@ -3,6 +3,7 @@
 #include "f3r_gemm256_impl.h"
 
 int f3r_gemm256_run_bf16(const f3r_gemm_args& a, hipStream_t stream, int stagger);  // f3r_gemm256_bf16.hip
+int f3r_gemm256_run_conv_f8_fin(const f3r_gemm_args& a, hipStream_t stream);         // f3r_gemm256_f8.hip
 
 // Whether the 256-tile kernel takes this (already validated) problem: everything its LDS-DMA staging cannot express -- K tails, ragged
 // channel counts, strided or pre-activated conv operands, small or narrow outputs -- stays on the 128-tile kernel.
@@ -20,7 +21,10 @@ bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
   } else {
     if (a.conv_stride != 1 || a.a_relu || a.conv_C % 64 != 0) return false;
     if (a.M * (int64_t)a.conv_C * 2 >= (1ll << 32)) return false;  // 32-bit byte offsets into the NHWC operand
+    if (a.split == F3R_SPLIT_X3F8 && (a.conv_C % 128 != 0 || a.dtype != F3R_F16)) return false;
   }
+  if (a.split == F3R_SPLIT_X3F8 && a.a_mode != F3R_A_CONV3X3) return false;
+  if (a.fin_w && (a.a_mode != F3R_A_CONV3X3 || a.N != 128 || a.epi != F3R_EPI_GENERIC)) return false;
   if ((int64_t)256 * a.Kpad * 2 >= (1ll << 32)) return false;
   // additive epilogue terms enter through the accumulators: one kind at a time, no activation in between, and only the kinds the
   // model uses on each operand mode (fp32 residual / image-id rows on plain GEMMs, lowp skip connections on convolutions)
@@ -39,5 +43,6 @@ int f3r_gemm256_launch(const f3r_gemm_args& a, hipStream_t stream, int stagger) 
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + 127) / 128);
   if (tiles <= 0) return F3R_OK;
   F3R_REQUIRE(tiles < (1ll << 31), "f3r_gemm: grid too large");
+  if (a.split == F3R_SPLIT_X3F8 || a.fin_w) return f3r_gemm256_run_conv_f8_fin(a, stream);
   return a.dtype == F3R_F16 ? dispatch256<F16>(a, stream, stagger) : f3r_gemm256_run_bf16(a, stream, stagger);
 }

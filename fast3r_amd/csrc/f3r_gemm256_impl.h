@@ -26,14 +26,13 @@
 //        in phase 2.  Restaged: A0 in phase 2, W0 in phase 3, A1 in phase 0 of the next tile (other buffer: 3 phases), W1 in phase 1.
 //
 // Operand roles, epilogues, the split-precision K segments and the LDS swizzle are those of f3r_gemm.hip; the implicit-GEMM 3x3
-// convolution stages its operand by LDS-DMA too: out-of-image taps read a 16-byte zero line instead of being predicated.
+// convolution stages its operand by LDS-DMA too (buffer_load ... lds): out-of-image taps use an out-of-range offset and arrive as zeros.
 #pragma once
 #include <atomic>
 
 #include "f3r_common.h"
 #include "f3r_gemm_epi.h"
 
-static __device__ __attribute__((aligned(128))) uint32_t f3r_zero_line[32];  // 128 B of zeros: the source of every padded conv tap (one copy per translation unit)
 
 namespace {
 
@@ -82,7 +81,14 @@ struct IC {
 //   epilogue store bursts of the CUs of an XCD no longer coincide
 //   128 s_memtime stamps of wave 0 (entry, main loop start, main loop end, epilogue issued, stores retired) -> (uint64*)p.rope_cos [wg][5]
 // (1, 2, 4, 8 compute garbage by construction: timing only)
-template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0>
+// F8 (F3R_SPLIT_X3F8, CONV3X3 only): the K loop runs on from the nk1 fp16 K-tiles [128 rows][64 k] of A_hi W_hi into 2 x nk1 / 2 fp8 K-tiles
+// [128 rows][128 k] -- A_hi8 W_lo8, then A_lo8 W_hi8 -- of the SAME geometry (128-byte rows, same swizzle, same LDS-DMA pieces, same fragment
+// reads: a lane's two 16-byte pieces, chunks fg and 4 + fg of its row, are the 32 operand bytes of v_mfma_scale_f32_16x16x128_f8f6f4; both
+// operands use the same k positions, which is all the instruction asks for) at the same matrix-pipe time per tile (8 MFMAs of 32 cycles per
+// phase instead of 16 of 16): two units of MFMA work instead of X3's three.  Scales: weights one E8M0 byte per output channel and plane
+// (w_scale), activations 2^0 (hi8) / 2^-12 (lo8).
+// FIN (f3r_gemm_args.fin_w): the epilogue is gemm_epilogue_fin (ReLU -> 1x1 conv to 4 channels -> postprocess), NH == 1 only.
+template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0, bool F8 = false, bool FIN = false>
 __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, const int64_t m0_tile, const int n0_tile, const bool first = true,
                                              const bool has_next = false, const int64_t m0_next = 0, const int n0_next = 0) {
   // PERSISTENT form (gemm256_kernel walks several output tiles per workgroup): `first` = this workgroup's first tile (its opening loads
@@ -118,20 +124,37 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int nseg = p.split == F3R_SPLIT_NONE ? 1 : (p.split == F3R_SPLIT_W2 ? 2 : 3);
   const int Kpad1 = p.split == F3R_SPLIT_NONE ? p.Kpad : p.Kpad / 2;
   const int nk1 = Kpad1 / BK;
-  const int nk = nseg * nk1;
+  const int nk8 = nk1 / 2;                       // F8: fp8 K-tiles per correction segment (conv_C % 128 == 0 -> nk1 % 18 == 0)
+  const int nk = F8 ? nk1 + 2 * nk8 : nseg * nk1;
   const int ctiles = A_MODE == F3R_A_CONV3X3 ? p.conv_C / 64 : 1;
+  const int ctiles8 = A_MODE == F3R_A_CONV3X3 ? p.conv_C / 128 : 1;
+  static_assert(!F8 || (A_MODE == F3R_A_CONV3X3 && !SWAP && LAB == 0), "fp8 correction segments: convolutions only");
+  static_assert(!FIN || (NH == 1 && EPI == F3R_EPI_GENERIC && ADDSRC == 0 && !SWAP), "fused head tail: 256 x 128 tiles, no additive terms");
 
   // ------------------------------------------------------------------ LDS-DMA source addressing
   // wave w, instruction i of a half tile: rows (w*2 + i)*8 + lane/8, physical chunk lane%8 <- logical chunk (lane%8) ^ ((row>>1)&7)
   uint32_t a_off[2][2], w_off[2][2];  // byte offsets of this lane's 16 B inside the tile's operand panel [half][i]
-  uint32_t a_msk[2][2];               // CONV: bit tap = the tap of this lane's pixel lies inside the image
+  uint32_t a_msk[2][2];               // CONV: bit tap = the tap of this lane's pixel lies OUTSIDE the image (or the row is past M)
   const char* const Ab = (const char*)p.A;
   const char* const Alo = (const char*)p.A_lo;
+  // CONV: bytes of an operand plane (stride 1: as many input as output pixels), the range of the buffer descriptors
+  const uint32_t a_bytes = A_MODE == F3R_A_CONV3X3 ? (uint32_t)(p.M / ((int64_t)p.conv_OH * p.conv_OW) * p.conv_H * p.conv_W * p.conv_C * 2) : 0u;
   const char* Wb = nullptr;
+  uint32_t wsc[NH][2];  // F8: the scale word of this lane's weight row in fragment nf of W half h (byte 0: lo8 plane, byte 1: hi8 plane)
   auto setup_tile = [&](int64_t tm0, int tn0) {
   m0 = tm0;
   n0 = tn0;
   Wb = (const char*)p.W + (int64_t)n0 * p.Kpad * 2;
+  if constexpr (F8) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        int n = n0 + h * 128 + (wid & 3) * 32 + (PAIRED ? (fr >> 2) * 8 + (fr & 3) + nf * 4 : fr + nf * 16);
+        if (n >= p.N) n = p.N - 1;
+        wsc[h][nf] = p.w_scale[n];
+      }
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -158,7 +181,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-          if (ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W) msk |= 1u << tap;
+          if (!(ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W)) msk |= 1u << tap;
         }
         a_msk[h][i] = msk;
       }
@@ -167,27 +190,42 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   setup_tile(m0_tile, n0_tile);
 
   // cursors: which K-tile the NEXT A / W half-tile pair is loaded for (wave-uniform; clamped at the last tile, see the loop tail)
-  int a_seg = 0, a_kk = 0, a_tap = 0, a_ct = 0, a_t = 0;
+  // CONV: the A stream walks (segment, tap, channel tile) with ONE running byte offset a_delta relative to the lane's own pixel: a pixel is
+  // pix = 2 C bytes in the fp16 planes and in the fp8 planes ([C hi8 | C lo8]) alike and a K-tile covers 128 of them, so the next channel tile
+  // -- and, after the last one, the next tap to the right -- is + 128 (fp8: + C more at the tap boundary: the other plane's half of the pixel
+  // is skipped), a new tap row + (W - 3) pix, a new segment starts at the top-left tap again.
+  const int pix = A_MODE == F3R_A_CONV3X3 ? p.conv_C * 2 : 0;
+  const int a_delta0 = -(p.conv_W + 1) * pix, a_row_jump = (p.conv_W - 3) * pix;
+  int a_seg = 0, a_kk = 0, a_tap = 0, a_ct = 0, a_dx = 0, a_t = 0, a_delta = a_delta0;
   int w_seg = 0, w_kk = 0, w_t = 0;
   bool dry = false;  // advance the cursors without issuing (the loads were issued by the previous tile of this workgroup)
   auto a_advance = [&]() {
     if (a_t + 1 < nk) {
+      const bool e8 = F8 && a_seg > 0;
       ++a_t; ++a_kk; ++a_ct;
-      if (a_ct == ctiles) { a_ct = 0; ++a_tap; }
-      if (a_kk == nk1) { a_kk = 0; a_tap = 0; a_ct = 0; ++a_seg; }
+      a_delta += 128;
+      if (a_ct == (e8 ? ctiles8 : ctiles)) {
+        a_ct = 0; ++a_tap; ++a_dx;
+        if (e8) a_delta += p.conv_C;
+        if (a_dx == 3) { a_dx = 0; a_delta += a_row_jump; }
+      }
+      if (a_kk == (e8 ? nk8 : nk1)) {
+        a_kk = 0; a_tap = 0; a_ct = 0; a_dx = 0; ++a_seg;
+        a_delta = a_delta0 + ((F8 && a_seg == 2) ? p.conv_C : 0);
+      }
     }
   };
   auto w_advance = [&]() {
     if (w_t + 1 < nk) {
       ++w_t; ++w_kk;
-      if (w_kk == nk1) { w_kk = 0; ++w_seg; }
+      if (w_kk == ((F8 && w_seg > 0) ? nk8 : nk1)) { w_kk = 0; ++w_seg; }
     }
   };
   bool in_loop = false;  // LAB only
   auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
     if (dry) return;
     if ((LAB & 1) && in_loop) return;
-    const char* plane = (a_seg == 2) ? Alo : Ab;
+    const char* plane = (!F8 && a_seg == 2) ? Alo : Ab;
     uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
     if (A_MODE == F3R_A_PLAIN) {
       const char* base = plane + (m0 * p.lda + (int64_t)a_kk * BK) * 2;
@@ -202,13 +240,17 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + a_off[h][i]), (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
     } else {
-      const int dy = a_tap / 3 - 1, dx = a_tap - (a_tap / 3) * 3 - 1;
-      const char* base = plane + (((int64_t)dy * p.conv_W + dx) * p.conv_C + a_ct * 64) * 2;
-      const char* zl = (const char*)f3r_zero_line;
+      // buffer_load ... lds through a descriptor of the whole plane (below 4 GiB: f3r_gemm256_eligible): lane offset = own pixel + a_delta in
+      // 32-bit arithmetic, and a tap outside the image gets the offset 0xFFFFFFFF -- out of range, the hardware writes zeros.  (Until round 6 the
+      // loop formed 64-bit lane addresses and pointed padded taps at a zero line: two s_load + an lgkmcnt(0) that also drained the fragment reads,
+      // and ~25 more scalar instructions per phase -- the load phases, not the MFMAs, set the tile time: profiles/r06_conv_x3_vs_x3f8_pmc.json.)
+      const char* pl = (F8 && a_seg > 0) ? Alo : plane;   // (fp8 planes: the same byte offsets, see a_advance)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pl, 0, a_bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const char* src = ((a_msk[h][i] >> a_tap) & 1u) ? base + a_off[h][i] : zl;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + i * 8 * 64), 16, 0, 0);
+        const int32_t inv = ((int32_t)(a_msk[h][i] << (31 - a_tap))) >> 31;   // v_bfe_i32: -1 = padded tap
+        const uint32_t vo = (a_off[h][i] + (uint32_t)a_delta) | (uint32_t)inv;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)vo, 0, 0, 0);
       }
     }
   };
@@ -216,6 +258,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     if (dry) return;
     if ((LAB & 1) && in_loop) return;
     const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
+    if (F8 && w_seg > 0) base = Wb + (int64_t)(w_seg + 1) * Kpad1 + (int64_t)w_kk * 128;  // rows [2 Kp fp16 | Kp lo8 | Kp hi8] bytes
     uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
     if (LAB & 32) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
@@ -241,94 +284,140 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
 
   float4v acc[16 * NH];
   typename T::vec8 fa0[2][4], fa1[2][4], fw[2][2];
+  // fp8 K-tiles: a fragment is the lane's two 16-byte pieces side by side (8 registers)
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  u32x8 ga0[4], ga1[4], gw[2];
 
-  auto read_a = [&](typename T::vec8 (&f)[2][4], int buf, int mh) {
+  auto read_a = [&](auto e8, auto which, int buf, int mh) {
     if ((LAB & 2) && in_loop) return;
+    if constexpr (decltype(e8)::value) {
+      auto& g = decltype(which)::value ? ga1 : ga0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int mf = 0; mf < 4; ++mf) {
+        const u32x4 c0 = *(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[0] + mf * 16 * 64);
+        const u32x4 c1 = *(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[1] + mf * 16 * 64);
+        g[mf] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    } else {
+      auto& f = decltype(which)::value ? fa1 : fa0;
 #pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
-        f[ks][mf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[ks] + mf * 16 * 64));
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+          f[ks][mf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + mh * HT + a_rd[ks] + mf * 16 * 64));
+    }
   };
-  auto read_w = [&](int buf, int nh) {
+  auto read_w = [&](auto e8, int buf, int nh) {
     if ((LAB & 2) && in_loop) return;
+    if constexpr (decltype(e8)::value) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int nf = 0; nf < 2; ++nf) {
+        const u32x4 c0 = *(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[0] + nf * (PAIRED ? 4 : 16) * 64);
+        const u32x4 c1 = *(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[1] + nf * (PAIRED ? 4 : 16) * 64);
+        gw[nf] = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    } else {
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-        fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * (PAIRED ? 4 : 16) * 64));
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+          fw[ks][nf] = as_vec8<T>(*(const u32x4*)(smem + buf * BUF + (2 + nh) * HT + w_rd[ks] + nf * (PAIRED ? 4 : 16) * 64));
+    }
   };
-  auto mma = [&](const typename T::vec8 (&f)[2][4], int mh, int nh) {
+  // sa_shift / sb (fp8 tiles): bit offset of the weight plane's scale byte in wsc, and the activations' E8M0 scale byte
+  auto mma = [&](auto e8, auto which, int mh, int nh, int sa_shift, int sb) {
     if (LAB & 4) return;
+    if constexpr (decltype(e8)::value) {
+      auto& g = decltype(which)::value ? ga1 : ga0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
+      for (int nf = 0; nf < 2; ++nf) {
+        const int sa = (int)((wsc[nh < NH ? nh : 0][nf] >> sa_shift) & 0xffu);
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
           const int NF = nh * 2 + nf, MF = mh * 4 + mf;
-          if (SWAP) acc[MF * (2 * NH) + NF] = T::mfma16(f[ks][mf], fw[ks][nf], acc[MF * (2 * NH) + NF]);
-          else      acc[NF * 8 + MF] = T::mfma16(fw[ks][nf], f[ks][mf], acc[NF * 8 + MF]);
+          acc[NF * 8 + MF] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8, gw[nf]), __builtin_bit_cast(i32x8, g[mf]),
+                                                                              acc[NF * 8 + MF], 0, 0, 0, sa, 0, sb);
         }
+      }
+      // pin the products to THIS phase: nothing but the next phase's MFMAs uses them, and hipcc's code sinking otherwise moves the MFMAs of
+      // five phases down to the sixth (all their fragments stay live: 700 bytes of scratch per lane, the matrix pipe idle between the barriers)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) asm volatile("" : "+v"(acc[(nh * 2 + nf) * 8 + mh * 4 + mf]));
+    } else {
+      auto& f = decltype(which)::value ? fa1 : fa0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf) {
+            const int NF = nh * 2 + nf, MF = mh * 4 + mf;
+            if (SWAP) acc[MF * (2 * NH) + NF] = T::mfma16(f[ks][mf], fw[ks][nf], acc[MF * (2 * NH) + NF]);
+            else      acc[NF * 8 + MF] = T::mfma16(fw[ks][nf], f[ks][mf], acc[NF * 8 + MF]);
+          }
+    }
   };
 
   // one K-tile out of buffer B (compile-time), 4 phases
-#define F3R_PHASE_MMA(FA, MH, NH)                        \
+#define F3R_PHASE_MMA(WHICH, MH, NH)                     \
   __builtin_amdgcn_sched_barrier(0);                     \
   __builtin_amdgcn_s_barrier();                          \
   F3R_LGKMCNT0();                                        \
   __builtin_amdgcn_sched_barrier(0);                     \
   if (!(LAB & 16)) __builtin_amdgcn_s_setprio(1);        \
-  mma(FA, MH, NH);                                       \
+  mma(e8, IC<WHICH>{}, MH, NH, sa_shift, sb);            \
   if (!(LAB & 16)) __builtin_amdgcn_s_setprio(0);        \
   __builtin_amdgcn_sched_barrier(0);                     \
   __builtin_amdgcn_s_barrier();
-  auto tile = [&](auto bufc) {
+  auto tile = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
     // ---- phase 0: quadrant (A0, W0); A half 1 of the next tile; retire what phase 1 reads (A half 1 of this tile)
-    read_w(B, 0);
+    read_w(e8, B, 0);
     if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
-    read_a(fa0, B, 0);
+    read_a(e8, IC<0>{}, B, 0);
     issue_a(1, B ^ 1);
     a_advance();
     if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa0, 0, 0)
+    F3R_PHASE_MMA(0, 0, 0)
     // ---- phase 1: quadrant (A1, W0); W half 1 of the next tile; retire W half 1 of this tile (phase 2 reads it)
-    read_a(fa1, B, 1);
+    read_a(e8, IC<1>{}, B, 1);
     issue_w(1, B ^ 1);
     w_advance();
     if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa1, 1, 0)
+    F3R_PHASE_MMA(1, 1, 0)
     // ---- phase 2: quadrant (A1, W1); A half 0 two tiles ahead (its slot was last read in phase 0)
-    read_w(B, 1);
+    read_w(e8, B, 1);
     issue_a(0, B);
-    F3R_PHASE_MMA(fa1, 1, 1)
+    F3R_PHASE_MMA(1, 1, 1)
     // ---- phase 3: quadrant (A0, W1); W half 0 two tiles ahead; retire A half 0 and W half 0 of the next tile (its phase 0 reads them)
     issue_w(0, B);
     if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa0, 0, 1)
+    F3R_PHASE_MMA(0, 0, 1)
   };
   // NH == 1 (256 x 128 outputs): a K-tile is 2 phases -- quadrants (A0, W) and (A1, W), 16 MFMAs each -- and 3 half tiles; three
   // buffers, tile t in buffer t % 3.  Reads: A0 and W in phase 0, A1 in phase 1; a slot is restaged two phases after its read:
   //     phase 0 of tile t:  A half 0 + W of tile t+2, then vmcnt(10) (retires A half 1 of tile t, read in phase 1)
   //     phase 1          :  A half 1 of tile t+2,     then vmcnt(8)  (retires A half 0 + W of tile t+1, read in its phase 0)
   // i.e. every half tile is issued 3 phases before the wait that retires it.
-  auto tile1 = [&](auto bufc) {
+  auto tile1 = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
     constexpr int B2 = (B + 2) % 3;
-    read_w(B, 0);
+    read_w(e8, B, 0);
     if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
-    read_a(fa0, B, 0);
+    read_a(e8, IC<0>{}, B, 0);
     issue_a(0, B2);
     issue_w(0, B2);
     w_advance();
     if (!(LAB & 8)) F3R_VMCNT(10);
-    F3R_PHASE_MMA(fa0, 0, 0)
-    read_a(fa1, B, 1);
+    F3R_PHASE_MMA(0, 0, 0)
+    read_a(e8, IC<1>{}, B, 1);
     issue_a(1, B2);
     a_advance();
     if (!(LAB & 8)) F3R_VMCNT(8);
-    F3R_PHASE_MMA(fa1, 1, 0)
+    F3R_PHASE_MMA(1, 1, 0)
   };
 #undef F3R_PHASE_MMA
 
@@ -339,7 +428,8 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int64_t m_base = m0_tile + wm * 64;
   const int n_base = n0_tile + wn * 32;
   auto opening_loads = [&]() {
-    a_seg = a_kk = a_tap = a_ct = a_t = 0;
+    a_seg = a_kk = a_tap = a_ct = a_dx = a_t = 0;
+    a_delta = a_delta0;
     w_seg = w_kk = w_t = 0;
     if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
       issue_a(0, 0);
@@ -376,21 +466,37 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
   if (LAB & 128) stamp[1] = __builtin_amdgcn_s_memtime();
 
+  typedef IC<0> E16;
+  typedef IC<1> E8;
+  const int nk16 = F8 ? nk1 : nk;  // 16-bit K-tiles; F8: followed by nk1 fp8 K-tiles (nk1 % 6 == 0: both loops start at buffer 0)
   if constexpr (NH == 2) {
     if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
-      tile(IC<0>{});
-      if (nk > 1) tile(IC<1>{});
+      tile(IC<0>{}, E16{}, 0, 0);
+      if (nk > 1) tile(IC<1>{}, E16{}, 0, 0);
       in_loop = true;
     }
-    for (int t = LAB ? 2 : 0; t < nk; t += 2) {
-      tile(IC<0>{});
-      if (t + 1 < nk) tile(IC<1>{});
+    for (int t = LAB ? 2 : 0; t < nk16; t += 2) {
+      tile(IC<0>{}, E16{}, 0, 0);
+      if (t + 1 < nk16) tile(IC<1>{}, E16{}, 0, 0);
+    }
+    if constexpr (F8) {  // segment 1 (tiles < nk8): A_hi8 W_lo8, scales (byte 0, 2^0); segment 2: A_lo8 W_hi8, scales (byte 1, 2^-12)
+      for (int t = 0; t < nk1; t += 2) {
+        tile(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
+        tile(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
+      }
     }
   } else {
-    for (int t = 0; t < nk; t += 3) {
-      tile1(IC<0>{});
-      if (t + 1 < nk) tile1(IC<1>{});
-      if (t + 2 < nk) tile1(IC<2>{});
+    for (int t = 0; t < nk16; t += 3) {
+      tile1(IC<0>{}, E16{}, 0, 0);
+      if (t + 1 < nk16) tile1(IC<1>{}, E16{}, 0, 0);
+      if (t + 2 < nk16) tile1(IC<2>{}, E16{}, 0, 0);
+    }
+    if constexpr (F8) {
+      for (int t = 0; t < nk1; t += 3) {
+        tile1(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
+        tile1(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
+        tile1(IC<2>{}, E8{}, t + 2 >= nk8 ? 8 : 0, t + 2 >= nk8 ? 115 : 127);
+      }
     }
   }
   // Past the last tile the cursors stay clamped, so the tail re-loads the last tile into half tiles nobody reads any more; drain them
@@ -404,7 +510,12 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   }
 
   // ------------------------------------------------------------------ epilogue
-  if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
+  if constexpr (FIN) {
+    // every wave is past its own vmcnt(0); the barrier makes that true for ALL waves before K-tile buffer 2 (never a target of the next tile's
+    // opening loads, which use buffers 0 and 1) becomes the scratch of the cross-wave reduction
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_fin<T, Frag>(p, acc, m0_tile, wm, wn, lane, tid, (float*)(smem + 2 * BUF));
+  } else if (SWAP) gemm_epilogue_vt<T, Frag, false>(p, acc, m_base, n_base, lane);
   else gemm_epilogue_default<T, EPI, Frag, false>(p, acc, m_base, n_base, lane);
   if (LAB & 128) {
     __builtin_amdgcn_sched_barrier(0);
@@ -418,7 +529,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false>
 __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int BN = TileCfg<NH>::BN;
@@ -462,15 +573,15 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
         done = true;
       }
     }
-    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH>(p, smem, m0, n0, first, has_next, m0n, n0n);
+    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH, 0, F8, FIN>(p, smem, m0, n0, first, has_next, m0n, n0n);
     first = false;
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false>
 int launch256(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH>;
+  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH, F8, FIN>;
   constexpr int LDS_BYTES = TileCfg<NH>::LDS_BYTES, BN = TileCfg<NH>::BN;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -117,6 +117,31 @@ __device__ __forceinline__ void loadN_lp(const char* ptr, float4v* v) {
   }
 }
 
+// fp8 copies of 4 * STEP consecutive values for the next F3R_SPLIT_X3F8 convolution (f3r_gemm_args.out_f8): e4m3 of v clamped to +-448
+// (v_cvt_pk_fp8_f32 does not saturate) at hi8, e4m3 of (v - float(fp16(v))) * 2^12, clamped, at lo8.  fp16 only.
+__device__ __forceinline__ uint32_t f8x4(float a, float b, float c, float d) {
+  auto cl = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ float f16_rest(float x) { return (x - (float)(_Float16)x) * 4096.f; }
+template <int STEP>
+__device__ __forceinline__ void storeN_f8(char* hi8, char* lo8, const float4v* v) {
+  if constexpr (STEP == 1) {
+    *(uint32_t*)hi8 = f8x4(v[0][0], v[0][1], v[0][2], v[0][3]);
+    *(uint32_t*)lo8 = f8x4(f16_rest(v[0][0]), f16_rest(v[0][1]), f16_rest(v[0][2]), f16_rest(v[0][3]));
+  } else {
+    u32x2 h, l;
+    h[0] = f8x4(v[0][0], v[0][1], v[0][2], v[0][3]);
+    h[1] = f8x4(v[1][0], v[1][1], v[1][2], v[1][3]);
+    l[0] = f8x4(f16_rest(v[0][0]), f16_rest(v[0][1]), f16_rest(v[0][2]), f16_rest(v[0][3]));
+    l[1] = f8x4(f16_rest(v[1][0]), f16_rest(v[1][1]), f16_rest(v[1][2]), f16_rest(v[1][3]));
+    *(u32x2*)hi8 = h;
+    *(u32x2*)lo8 = l;
+  }
+}
+
 // ------------------------------------------------------------------ additive terms of the GENERIC epilogue
 // out = act(acc + bias) + rowadd + res_f32 + res_lp (+lo) + res_lp2 (+lo).  Addresses are clamped into the matrix instead of
 // predicated so the loads are unconditional.  term(i, nf, value) receives every loaded 4-vector.
@@ -365,6 +390,7 @@ __device__ __forceinline__ void gemm_epilogue_generic_interior(const f3r_gemm_ar
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t off_f32 = (uint32_t)(fr * (int)p.ldo_f32 + fg * L::LW) * 4u;
   const uint32_t off_lp = (uint32_t)(fr * (int)p.ldo_lp + fg * L::LW) * 2u;
+  const uint32_t off_f8 = (uint32_t)(fr * p.N * 2 + fg * L::LW);
   const bool relu = p.act == F3R_ACT_RELU;  // wave-uniform branch per fragment; GELU is a compile-time variant of the body
   // KIND: 0 out_lp only, 1 out_lp + out_lp_lo, 2 out_f32 only, 3 any combination (wave-uniform tests per fragment)
   auto run = [&](auto act_c, auto kind_c) {
@@ -378,6 +404,8 @@ __device__ __forceinline__ void gemm_epilogue_generic_interior(const f3r_gemm_ar
       char* const bll = ((KIND == 1 || KIND == 3) && p.out_lp_lo) ? (char*)p.out_lp_lo + lp_row : nullptr;
       char* const br = (KIND == 3 && p.out_relu) ? (char*)p.out_relu + lp_row : nullptr;
       char* const brl = (KIND == 3 && p.out_relu_lo) ? (char*)p.out_relu_lo + lp_row : nullptr;
+      char* const b8 = (KIND == 3 && p.out_f8) ? (char*)p.out_f8 + (mrow * p.N * 2 + n_base) : nullptr;            // rows of [N hi8 | N lo8]
+      char* const br8 = (KIND == 3 && p.out_relu_f8) ? (char*)p.out_relu_f8 + (mrow * p.N * 2 + n_base) : nullptr;
 #pragma unroll
       for (int nf = 0; nf < NF; nf += L::STEP) {
         float4v v[L::STEP];
@@ -393,17 +421,19 @@ __device__ __forceinline__ void gemm_epilogue_generic_interior(const f3r_gemm_ar
           for (int q = 0; q < L::STEP; ++q) *(float4v*)(bf + (cb + q * 4) * 4 + off_f32) = v[q];
         }
         if (KIND != 2 && bl) storeN_split<T, L::STEP>(bl + cb * 2 + off_lp, (KIND == 1 || (KIND == 3 && bll)) ? bll + cb * 2 + off_lp : nullptr, v);
-        if (KIND == 3 && br) {
+        if (KIND == 3 && b8) storeN_f8<L::STEP>(b8 + cb + off_f8, b8 + cb + off_f8 + p.N, v);
+        if (KIND == 3 && (br || br8)) {
           float4v r[L::STEP];
 #pragma unroll
           for (int q = 0; q < L::STEP; ++q) r[q] = float4v{fmaxf(v[q][0], 0.f), fmaxf(v[q][1], 0.f), fmaxf(v[q][2], 0.f), fmaxf(v[q][3], 0.f)};
-          storeN_split<T, L::STEP>(br + cb * 2 + off_lp, brl ? brl + cb * 2 + off_lp : nullptr, r);
+          if (br) storeN_split<T, L::STEP>(br + cb * 2 + off_lp, brl ? brl + cb * 2 + off_lp : nullptr, r);
+          if (br8) storeN_f8<L::STEP>(br8 + cb + off_f8, br8 + cb + off_f8 + p.N, r);
         }
       }
     }
   };
   auto by_kind = [&](auto act_c) {
-    const bool f32 = p.out_f32 != nullptr, lp = p.out_lp != nullptr, lo = p.out_lp_lo != nullptr, rl = p.out_relu != nullptr;
+    const bool f32 = p.out_f32 != nullptr, lp = p.out_lp != nullptr, lo = p.out_lp_lo != nullptr, rl = p.out_relu != nullptr || p.out_f8 != nullptr || p.out_relu_f8 != nullptr;
     if (lp && !f32 && !lo && !rl) run(act_c, EpiC<0>{});
     else if (lp && lo && !f32 && !rl) run(act_c, EpiC<1>{});
     else if (f32 && !lp && !rl) run(act_c, EpiC<2>{});
@@ -540,10 +570,13 @@ __device__ __forceinline__ void gemm_epilogue_default(const f3r_gemm_args& p, co
             if (p.out_lp)
               store4_split<T>((uint16_t*)p.out_lp + m[i] * p.ldo_lp + nb[nf],
                               p.out_lp_lo ? (uint16_t*)p.out_lp_lo + m[i] * p.ldo_lp + nb[nf] : nullptr, v);
-            if (p.out_relu) {
+            if (p.out_f8) storeN_f8<1>((char*)p.out_f8 + m[i] * p.N * 2 + nb[nf], (char*)p.out_f8 + m[i] * p.N * 2 + p.N + nb[nf], &v);
+            if (p.out_relu || p.out_relu_f8) {
               const float4v r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-              store4_split<T>((uint16_t*)p.out_relu + m[i] * p.ldo_lp + nb[nf],
-                              p.out_relu_lo ? (uint16_t*)p.out_relu_lo + m[i] * p.ldo_lp + nb[nf] : nullptr, r);
+              if (p.out_relu)
+                store4_split<T>((uint16_t*)p.out_relu + m[i] * p.ldo_lp + nb[nf],
+                                p.out_relu_lo ? (uint16_t*)p.out_relu_lo + m[i] * p.ldo_lp + nb[nf] : nullptr, r);
+              if (p.out_relu_f8) storeN_f8<1>((char*)p.out_relu_f8 + m[i] * p.N * 2 + nb[nf], (char*)p.out_relu_f8 + m[i] * p.N * 2 + p.N + nb[nf], &r);
             }
           } else {  // CONVT scatter (pixel shuffle): n = (dy*s + dx)*cout + co
             const int tap = nb[nf] / p.ct_cout;
@@ -663,4 +696,90 @@ __device__ __forceinline__ void gemm_epilogue_vt(const f3r_gemm_args& p, const f
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ fused tail of the DPT head (f3r_gemm_args.fin_w; 256 x 128 tile, N = 128)
+// head[2]'s accumulators (bias already in them) -> act (head[3] ReLU) -> head[4]: 1x1 conv to 4 channels on the vector pipe in fp32 ->
+// postprocess (dpt_block.py:375-381, heads/postprocess.py:16-64; the arithmetic of dpt_final_kernel in f3r_elem.hip).  The 128 channels of a
+// pixel are spread over the 4 waves of a wave row (wn) and the 4 lane groups fg of a wave (8 consecutive channels per lane, PAIRED layout):
+// every lane folds its 8 channels into 4 partial outputs per row (256 FMAs), two butterfly steps (lanes +-32, +-16) leave each lane with the
+// fg-complete sums of 2 of its 8 fragment rows, the four wn partials meet in LDS in a fixed order (deterministic), and thread t < 256
+// finishes row t of the tile.
+template <class T, class L>
+__device__ __forceinline__ void gemm_epilogue_fin(const f3r_gemm_args& p, const float4v* acc, int64_t m0_tile, int wm, int wn, int lane, int tid,
+                                                  float* scratch /* LDS: [4 wn][256 rows][4] floats = 16 KiB */) {
+  static_assert(L::NF == 2 && L::MF == 8 && L::PAIRED, "fin epilogue: the 256 x 128 tile's paired fragment layout");
+  const int fr = lane & 15, fg = lane >> 4;
+  const int c0 = wn * 32 + fg * 8;  // this lane's 8 channels (N == 128: one n-tile, n0 == 0)
+  float w[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const float4v w0 = *(const float4v*)(p.fin_w + o * p.N + c0), w1 = *(const float4v*)(p.fin_w + o * p.N + c0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[o][j] = w0[j]; w[o][4 + j] = w1[j]; }
+  }
+  const bool relu = p.act == F3R_ACT_RELU;
+  float s[8][4];
+#pragma unroll
+  for (int mf = 0; mf < 8; ++mf) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = acc[0 * 8 + mf][j]; v[4 + j] = acc[1 * 8 + mf][j]; }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float a = v[0] * w[o][0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) a = __builtin_fmaf(v[j], w[o][j], a);
+      s[mf][o] = a;
+    }
+  }
+  // butterfly over fg: lanes with fg >= 2 keep rows mf 4..7, the others 0..3; then fg odd keeps the upper pair of its four
+  const bool up32 = fg >= 2, up16 = (fg & 1) != 0;
+  float t[4][4], u[2][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float keep = up32 ? s[k + 4][o] : s[k][o], send = up32 ? s[k][o] : s[k + 4][o];
+      t[k][o] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float keep = up16 ? t[k + 2][o] : t[k][o], send = up16 ? t[k][o] : t[k + 2][o];
+      u[k][o] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int mf = (up32 ? 4 : 0) + (up16 ? 2 : 0) + k;
+    const int row = wm * 64 + (mf >> 2) * 128 + (mf & 3) * 16 + fr;
+    *(float4v*)(scratch + (wn * 256 + row) * 4) = float4v{u[k][0], u[k][1], u[k][2], u[k][3]};
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int64_t pix = m0_tile + tid;
+    float4v a = *(const float4v*)(scratch + tid * 4);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) a += *(const float4v*)(scratch + (q * 256 + tid) * 4);
+    if (pix < p.M) {
+      const float a0 = a[0] + p.fin_b[0], a1 = a[1] + p.fin_b[1], a2 = a[2] + p.fin_b[2], a3 = p.fin_n_out > 3 ? a[3] + p.fin_b[3] : 0.f;
+      float sc = 1.f;  // reg_dense_depth (postprocess.py:27-51)
+      if (p.fin_depth_mode != 1 /* F3R_DEPTH_LINEAR */) {
+        const float d = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+        sc = (p.fin_depth_mode == 0 /* F3R_DEPTH_EXP */ ? expm1f(d) : d * d) / fmaxf(d, 1e-8f);
+      }
+      p.fin_pts[pix * 3 + 0] = a0 * sc;
+      p.fin_pts[pix * 3 + 1] = a1 * sc;
+      p.fin_pts[pix * 3 + 2] = a2 * sc;
+      if (p.fin_conf)  // reg_dense_conf (:54-64)
+        p.fin_conf[pix] = p.fin_conf_mode == 0 /* F3R_CONF_EXP */ ? p.fin_vmin + fminf(expf(a3), p.fin_vmax - p.fin_vmin)
+                                                                  : (p.fin_vmax - p.fin_vmin) * (1.f / (1.f + expf(-a3))) + p.fin_vmin;
+    }
+  }
+  __syncthreads();  // the scratch is K-tile buffer 2 again from the next tile's first phase on
 }

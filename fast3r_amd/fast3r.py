@@ -423,12 +423,26 @@ class _PackedHead:
     pass
 
 
-def _pack_head(head: PixelwiseTaskWithDPT, lp, split=False):
+class _ConvW:
+    """A packed 3x3 convolution weight: `w` for split None / "x3" (ops.pack_conv3x3_weight) and, when the head runs its correction products on the
+    fp8 MFMA (Fast3R.head_corrections = "fp8") and Cin % 128 == 0, `w8` / `scale` for split "x3f8" (ops.pack_conv3x3_weight_f8)."""
+    __slots__ = ("w", "w8", "scale")
+
+    def __init__(self, w, w8=None, scale=None):
+        self.w, self.w8, self.scale = w, w8, scale
+
+
+def _pack_head(head: PixelwiseTaskWithDPT, lp, split=False, f8=False):
     d = head.dpt
     h = _PackedHead()
     ap = d.act_postprocess
     lin = lambda w: ops.pack_linear_weight(w.detach().float(), lp, split)
-    c33 = lambda w: ops.pack_conv3x3_weight(w.detach().float(), lp, split)
+
+    def c33(w):
+        w = w.detach().float()
+        if f8 and split and lp == torch.float16 and w.shape[1] % 128 == 0:
+            return _ConvW(ops.pack_conv3x3_weight(w, lp, split), *ops.pack_conv3x3_weight_f8(w))
+        return _ConvW(ops.pack_conv3x3_weight(w, lp, split))
     h.a_w = [lin(ap[i][0].weight) for i in range(4)]
     h.a_b = [_f32(ap[i][0].bias) for i in range(4)]
     h.t0_w, h.t0_b = ops.pack_convT_weight(ap[0][1].weight.detach().float(), ap[0][1].bias.detach(), lp, split)
@@ -451,6 +465,12 @@ def _pack_head(head: PixelwiseTaskWithDPT, lp, split=False):
     h.dims = d.layer_dims
     h.feature_dim, h.last_dim, h.num_channels, h.patch_size = d.feature_dim, d.last_dim, d.num_channels, d.patch_size
     h.depth_mode, h.conf_mode = head.depth_mode, head.conf_mode
+    h.fin = None
+    if d.last_dim == 128 and h.h4_w.shape[1] == 128:  # the fused tail (f3r_gemm_args.fin_w): head[4] as a zero-padded [4][128] matrix
+        try:
+            h.fin = ops.dpt_fin_args(h.h4_w, h.h4_b, h.conf_mode, tuple(h.depth_mode))
+        except (ValueError, AssertionError):
+            h.fin = None  # an unsupported mode raises where the reference raises: in the head's own call (ops.dpt_final)
     return h
 
 
@@ -480,7 +500,8 @@ class _GraphCache:
         # (the operand-format knobs are part of the key: a graph captured with another low_plane / high_fc1_planes would keep replaying the old
         # packed weights after the model re-packed)
         key = (len(views), tuple(imgs[0].shape), str(dev), model.compute_dtype, model.precision, model.max_parallel_views_for_head,
-               model.training, model._params_version(), model.low_plane, model.high_fc1_planes)
+               model.training, model._params_version(), model.low_plane, model.high_fc1_planes, model.head_corrections,
+               model.head_f8_min_rows, model.head_tail_fused_min_rows)
         dec = model.decoder
         B = imgs[0].shape[0]
         if key not in self.entries:
@@ -864,7 +885,23 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     # batch of views (59 ms).  Measured on the heavy-tailed ViT-L set (N = 3 vs the CPU oracle): 7.8e-5 with "fp32", 5.2e-4 with "planes" -- both
     # inside 1e-3, the default keeps the larger margin (a tier people turn to because their checkpoint amplifies noise); N = 320: 14.2 s / 13.7 s.
     robust_encoder_attention = "fp32"
+    # DPT heads in precision "high" with fp16 planes: "fp8" (the default, round 6) runs the two correction products of every 3x3 convolution with
+    # Cin % 128 == 0 and at least head_f8_min_rows output pixels PER VIEW (from the 64 x 64 level on at 512 x 512: refinenet2 / 1, head[0],
+    # head[2]: ~88 % of the heads' FLOPs) on the block-
+    # scaled fp8 MFMA (f3r.h F3R_SPLIT_X3F8: two matrix-pipe units instead of X3's three; the producers write the fp8 planes beside the fp16 high
+    # plane instead of an fp16 low plane nobody else reads); "fp16": three fp16 products everywhere.  oracle/precision_study.py --study heads_f8:
+    # the stress fixture moves from 6.94e-4 to 6.93e-4.  Changing it needs invalidate_packed_weights().
+    head_corrections = "fp8"
+    head_f8_min_rows = 4096
+    # head[2] + ReLU -> head[4] (1x1 conv to 3 / 4 channels) -> postprocess in ONE launch (f3r_gemm_args.fin_w) whenever head[2] has at least
+    # this many output pixels per view and the head's last_dim is 128: the 128-channel activation at full resolution (512 B per pixel with planes) is never
+    # written or read back.  A very large value restores conv -> f3r_dpt_final.
+    head_tail_fused_min_rows = 4096
     high_fc1_planes = True   # False: fc1 weights single-plane in precision "high" (see _pack_block); changing it needs invalidate_packed_weights()
+
+    @property
+    def _head_f8(self):
+        return self.head_corrections == "fp8" and self.precision == "high" and self.compute_dtype == torch.float16
 
     @property
     def _fc1_split(self):
@@ -882,7 +919,7 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
     def _pack(self, device):
         lp = self.compute_dtype
         f8 = self.low_plane == "fp8" and self.precision == "high" and lp == torch.float16
-        key = (lp, self.precision, str(device), self._params_version(), f8, bool(self.high_fc1_planes))
+        key = (lp, self.precision, str(device), self._params_version(), f8, bool(self.high_fc1_planes), self._head_f8)
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
         alt = getattr(self, "_packed_alt", None)
@@ -919,8 +956,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         else:
             pk["dec"] = [_pack_block(b, lp, hp, dec.embed_dim // dec.num_heads, fc1_split=self._fc1_split, f8=f8) for b in dec.dec_blocks]
             pk["dec_norm"] = (_f32(dec.dec_norm.weight), _f32(dec.dec_norm.bias), dec.dec_norm.eps)
-        pk["head"] = _pack_head(self.downstream_head, lp, hp)
-        pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp) if self.downstream_head_local is not None else None
+        pk["head"] = _pack_head(self.downstream_head, lp, hp, self._head_f8)
+        pk["head_local"] = _pack_head(self.downstream_head_local, lp, hp, self._head_f8) if self.downstream_head_local is not None else None
         self._packed = pk
         return pk
 
@@ -1300,60 +1337,94 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         hp = self._hp
         sp = "x3" if hp else None
         ld = hk.dims
+        # Activations are (hi, lo, f8) triples: the fp16 / bf16 high plane, the 16-bit low plane (None = not carried) and the fp8 planes (None = not
+        # carried).  Which of them a producer writes follows from its CONSUMERS: a residual add, a 1x1 conv or an upsample read hi + lo; a 3x3
+        # convolution that runs split "x3f8" reads hi + f8 and needs no lo.
+        f8_on = self._head_f8
+
+        def use_f8(rows, cin, w):
+            # decided by the pixels of ONE view (rows / nv), so that a forward computes the same numbers whatever max_parallel_views_for_head is;
+            # the operand of a launch must stay below 4 GiB (32-bit lane offsets of the 256-tile kernel: 63 views of 512 x 512 x 128 channels)
+            return bool(f8_on and w.w8 is not None and cin % 128 == 0 and rows // nv >= self.head_f8_min_rows and rows * cin * 2 < (1 << 32))
 
         def c1(i):  # act_postprocess[i][0]: 1x1 conv on the tokens
             r = ops.gemm(toks[i][0], hk.a_w[i], bias=hk.a_b[i], want_lp=True, want_lo=hp, split=sp, a_lo=toks[i][1])
-            return tuple(t.view(nv, gh, gw, ld[i]) for t in r[1:]) if hp else (r[1].view(nv, gh, gw, ld[i]), None)
+            return tuple(t.view(nv, gh, gw, ld[i]) for t in r[1:]) + (None,) if hp else (r[1].view(nv, gh, gw, ld[i]), None, None)
 
         def convT(xp, w, b, s, cout):
             r = ops.convT(xp[0], w, b, s, cout, split=sp, x_lo=xp[1], want_lo=hp)
-            return r if hp else (r, None)
+            return r + (None,) if hp else (r, None, None)
 
-        def conv(xp, w, bias=None, stride=1, act=None, res=None, res2=None, relu_copy=False):
-            """-> {"x": (out, lo), "relu": (relu(out), lo)}"""
-            r = ops.conv3x3(xp[0], w, stride=stride, bias=bias, act=act, split=sp, x_lo=xp[1],
+        def conv(xp, w, bias=None, stride=1, act=None, res=None, res2=None, relu_copy=False, x_f8=False, relu_f8=False, x_lo=True, fin=None):
+            """-> {"x": (out, lo, f8), "relu": (relu(out), lo, f8)}; x_f8 / relu_f8: the consumer of that copy is an "x3f8" convolution (fp8 planes
+            instead of the low plane; x_lo=False drops the output's own low plane too).  fin: the fused head tail -> (pts3d, conf)."""
+            kw = dict(split=sp, x_lo=xp[1])
+            wt = w.w
+            if xp[2] is not None:  # the producer wrote fp8 planes because this launch takes them
+                kw = dict(split="x3f8", x_f8=xp[2], w_scale=w.scale)
+                wt = w.w8
+            r = ops.conv3x3(xp[0], wt, stride=stride, bias=bias, act=act,
                             res_lp=None if res is None else res[0], res_lp_lo=None if res is None else res[1],
                             res_lp2=None if res2 is None else res2[0], res_lp2_lo=None if res2 is None else res2[1],
-                            want_lo=hp, want_relu=relu_copy)
+                            want_lo=hp and x_lo, want_relu=relu_copy, want_f8=x_f8, want_relu_lo=hp and not relu_f8, want_relu_f8=relu_f8, fin=fin, **kw)
+            if fin is not None:
+                return r
             if not isinstance(r, dict):
-                return {"x": (r, None)}
-            return {"x": (r["out"], r.get("out_lo")), "relu": (r.get("relu"), r.get("relu_lo"))}
+                return {"x": (r, None, None)}
+            return {"x": (r["out"], r.get("out_lo"), r.get("out_f8")), "relu": (r.get("relu"), r.get("relu_lo"), r.get("relu_f8"))}
+
+        def rows_of(t):
+            return t.shape[0] * t.shape[1] * t.shape[2]
 
         l0 = convT(c1(0), hk.t0_w, hk.t0_b, 4, ld[0])                                  # dpt_block.py:416-434
         l1 = convT(c1(1), hk.t1_w, hk.t1_b, 2, ld[1])                                  # :436-454
         l2 = c1(2)                                                                      # :456-464
         l3 = conv(c1(3), hk.c3_w, bias=hk.c3_b, stride=2)["x"]                          # :466-481
-        ls = [conv(l, hk.rn_w[i], relu_copy=True) for i, l in enumerate((l0, l1, l2, l3))]  # scratch.layer_rn, no bias
+        # scratch.layer_rn (no bias); the relu copy feeds the first RCU convolution of its level
+        ls = [conv(l, hk.rn_w[i], relu_copy=True, relu_f8=use_f8(rows_of(l[0]), hk.feature_dim, hk.ref[i]["u2c1" if i == 3 else "u1c1"][0]))
+              for i, l in enumerate((l0, l1, l2, l3))]
         del l0, l1, l2, l3
 
-        def rcu(x, c1w, c2w, extra=None, relu_copy=False):
+        def rcu(x, c1w, c2w, extra=None, relu_copy=False, relu_f8=False):
             # x + conv2(relu(conv1(relu(x)))) (+ extra); x = {"x": planes, "relu": planes of relu(x)}
-            t = conv(x["relu"], c1w[0], bias=c1w[1], act="relu")["x"]
-            return conv(t, c2w[0], bias=c2w[1], res=x["x"], res2=extra, relu_copy=relu_copy)
+            f8 = use_f8(rows_of(x["x"][0]), hk.feature_dim, c2w[0])
+            t = conv(x["relu"], c1w[0], bias=c1w[1], act="relu", x_f8=f8, x_lo=not f8)["x"]
+            return conv(t, c2w[0], bias=c2w[1], res=x["x"], res2=extra, relu_copy=relu_copy, relu_f8=relu_f8)
 
-        def fusion(r, path, skip=None, crop=None):
+        def fusion(r, path, skip=None, crop=None, out_f8=False):
             # out_conv(up2(RCU2(path + RCU1(skip)))); the 1x1 out_conv commutes exactly with the bilinear
             # interpolation (both linear, weights sum to 1), so it runs BEFORE the upsample on 4x fewer pixels.
             if skip is not None:
-                path = rcu(skip, r["u1c1"], r["u1c2"], extra=path, relu_copy=True)
+                path = rcu(skip, r["u1c1"], r["u1c2"], extra=path, relu_copy=True, relu_f8=use_f8(rows_of(skip["x"][0]), hk.feature_dim, r["u2c1"][0]))
             y = rcu(path, r["u2c1"], r["u2c2"])["x"]
             B, hh, ww, C = y[0].shape
             g = ops.gemm(y[0].view(B * hh * ww, C), r["out"][0], bias=r["out"][1], want_lp=True, want_lo=hp, split=sp,
                          a_lo=None if y[1] is None else y[1].view(B * hh * ww, C))
             z = (g[1].view(B, hh, ww, C), g[2].view(B, hh, ww, C) if hp else None)
+            if out_f8:
+                return ops.upsample2x(z[0], crop, x_lo=z[1], want_lo=False, want_f8=True)
             u = ops.upsample2x(z[0], crop, x_lo=z[1], want_lo=hp)
-            return u if hp else (u, None)
+            return u + (None,) if hp else (u, None, None)
 
         p4 = fusion(hk.ref[3], ls[3], None, crop=(ls[2]["x"][0].shape[1], ls[2]["x"][0].shape[2]))  # dpt_head.py:69-71
         p3 = fusion(hk.ref[2], p4, ls[2])
         p2 = fusion(hk.ref[1], p3, ls[1])
-        p1 = fusion(hk.ref[0], p2, ls[0])
+        B1, h1, w1 = ls[0]["x"][0].shape[:3]
+        p1 = fusion(hk.ref[0], p2, ls[0], out_f8=use_f8(B1 * 4 * h1 * w1, hk.feature_dim, hk.h0_w))
         del ls, p4, p3, p2
         y = conv(p1, hk.h0_w, bias=hk.h0_b)["x"]                                        # head[0]
         # head[1]: Interpolate(scale_factor = patch_size / 8, bilinear, align_corners=True) (dpt_block.py:374): x2 for patch 16, x1.75 for 14
         full = (y[0].shape[1] * hk.patch_size // 8, y[0].shape[2] * hk.patch_size // 8)
-        u = ops.interp_bilinear(y[0], full, x_lo=y[1], want_lo=hp)
-        y = conv(u if hp else (u, None), hk.h2_w, bias=hk.h2_b, act="relu")["x"]        # head[2], head[3]
+        rows2 = y[0].shape[0] * full[0] * full[1]
+        if use_f8(rows2, hk.last_dim, hk.h2_w):
+            u = ops.interp_bilinear(y[0], full, x_lo=y[1], want_lo=False, want_f8=True)
+        else:
+            u = ops.interp_bilinear(y[0], full, x_lo=y[1], want_lo=hp)
+            u = u + (None,) if hp else (u, None, None)
+        # head[2], head[3] (+ head[4] and postprocess in the same launch when the 256 x 128 tile kernel takes it)
+        if (hk.fin is not None and rows2 // nv >= self.head_tail_fused_min_rows and hk.last_dim % 64 == 0 and rows2 * hk.last_dim * 2 < (1 << 32)):
+            return conv(u, hk.h2_w, bias=hk.h2_b, act="relu", fin=hk.fin)
+        y = conv(u, hk.h2_w, bias=hk.h2_b, act="relu")["x"]
         return ops.dpt_final(y[0], hk.h4_w, hk.h4_b, hk.conf_mode, x_lo=y[1], depth_mode=tuple(hk.depth_mode))  # head[4] + postprocess
 
     # ---------------------------------------------------------------- forward

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (AttnArgs, F3R_A_CONV3X3, F3R_A_PLAIN, F3R_ACT_GELU, F3R_ACT_NONE, F3R_ACT_RELU, F3R_EPI_CONVT,
-                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_W2F8, F3R_SPLIT_X3, GemmArgs, check, dtype_id,
+                   F3R_EPI_GENERIC, F3R_EPI_QKV, F3R_MAX_SEG, F3R_SPLIT_NONE, F3R_SPLIT_W2, F3R_SPLIT_W2F8, F3R_SPLIT_X3, F3R_SPLIT_X3F8, GemmArgs, check, dtype_id,
                    ptr, require_gpu, stream_ptr)
 
 ACT = {None: F3R_ACT_NONE, "none": F3R_ACT_NONE, "gelu": F3R_ACT_GELU, "relu": F3R_ACT_RELU}
@@ -117,7 +117,7 @@ def round_up(x: int, m: int) -> int:
 
 
 # ----------------------------------------------------------------------------------------- weight packing (host, once)
-SPLIT = {None: F3R_SPLIT_NONE, 0: F3R_SPLIT_NONE, "none": F3R_SPLIT_NONE, "w2": F3R_SPLIT_W2, "x3": F3R_SPLIT_X3, "w2f8": F3R_SPLIT_W2F8}
+SPLIT = {None: F3R_SPLIT_NONE, 0: F3R_SPLIT_NONE, "none": F3R_SPLIT_NONE, "w2": F3R_SPLIT_W2, "x3": F3R_SPLIT_X3, "w2f8": F3R_SPLIT_W2F8, "x3f8": F3R_SPLIT_X3F8}
 
 
 def split_planes(w: torch.Tensor, lp: torch.dtype):
@@ -173,6 +173,42 @@ def pack_conv3x3_weight(w: torch.Tensor, lp: torch.dtype, split: bool = False) -
     for i, pl in enumerate(planes):
         out[:, i, :, :ci] = pl
     return out.reshape(co, len(planes) * 9 * cpad)
+
+
+def _e4m3_rows(x: torch.Tensor):
+    """[N][K] fp32 -> (e4m3 bytes of x 2^s_n, E8M0 bytes 127 - s_n): one power-of-two scale per row brings its largest magnitude to [112, 224]."""
+    amax = x.abs().amax(dim=1).clamp_min(2.0 ** -100)
+    s = torch.floor(torch.log2(224.0 / amax)).clamp(-100, 120)
+    q = (x * torch.exp2(s)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), (127 - s).to(torch.int64)
+
+
+def pack_conv3x3_weight_f8(w: torch.Tensor):
+    """Conv2d weight (Cout, Cin, 3, 3) fp32, Cin % 128 == 0 -> the operand of f3r_gemm split "x3f8" (include/f3r.h F3R_SPLIT_X3F8): rows
+    [9 Cin fp16 hi | 9 Cin bytes e4m3((W - hi) 2^s_n) | 9 Cin bytes e4m3(hi 2^t_n)], k = (ky*3 + kx) * Cin + ci in every plane, as a float16-typed
+    [Cout][2 * 9 Cin] tensor (the row stride of the two-fp16-plane pack), and the [Cout] int32 scale words (byte 0: 127 - s_n, byte 1: 127 - t_n)."""
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and ci % 128 == 0, "x3f8: 3x3 kernels, Cin a multiple of 128"
+    taps = w.float().permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    hi = taps.to(torch.float16)
+    lo8, e_lo = _e4m3_rows(taps - hi.float())
+    hi8, e_hi = _e4m3_rows(hi.float())
+    kp = 9 * ci
+    out = torch.empty((co, 4 * kp), dtype=torch.uint8, device=w.device)
+    out[:, :2 * kp] = hi.contiguous().view(torch.uint8).view(co, 2 * kp)
+    out[:, 2 * kp:3 * kp] = lo8
+    out[:, 3 * kp:] = hi8
+    words = (e_lo | (e_hi << 8)).to(torch.int32)
+    return out.view(torch.float16).view(co, 2 * kp), words.contiguous()
+
+
+def f8_planes(x: torch.Tensor) -> torch.Tensor:
+    """fp32 (..., C) -> the fp8 planes a "x3f8" convolution reads beside the fp16 high plane: uint8 (..., 2 C) = [e4m3(clamp(x, 448)) | e4m3(clamp((x -
+    fp16(x)) 2^12, 448))] -- what f3r_gemm_args.out_f8 / f3r_interp_bilinear_f8 write on the device (tests and tools build inputs with this)."""
+    hi = x.to(torch.float16).float()
+    a = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    b = ((x - hi) * 4096.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return torch.cat([a, b], dim=-1).contiguous()
 
 
 def pack_convT_weight(w: torch.Tensor, b: torch.Tensor, lp: torch.dtype, split: bool = False):
@@ -425,31 +461,57 @@ def rows_add(x, vec, rows):
 
 
 def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, res_lp2=None, out=None, split=None, x_lo=None,
-            res_lp_lo=None, res_lp2_lo=None, want_lo=False, want_relu=False, kernel_sel=0):
+            res_lp_lo=None, res_lp2_lo=None, want_lo=False, want_relu=False, kernel_sel=0, x_f8=None, w_scale=None, want_f8=False,
+            want_relu_lo=None, want_relu_f8=False, fin=None):
     """3x3 conv, pad 1, NHWC lowp in/out, as an implicit GEMM.  x: (B,H,W,C); w: pack_conv3x3_weight(...).
-    Returns the output, or a dict {"out", "out_lo", "relu", "relu_lo"} when low planes (want_lo) or the pre-activated copy relu(out)
-    (want_relu; what the next ResidualConvUnit conv reads) are asked for."""
+    Returns the output, or a dict {"out", "out_lo", "out_f8", "relu", "relu_lo", "relu_f8"} when low planes (want_lo), fp8 planes (want_f8: uint8
+    (B,OH,OW,2N), the operand of a following split="x3f8" conv) or the pre-activated copy relu(out) (want_relu; what the next ResidualConvUnit conv
+    reads; want_relu_lo [default: want_lo] / want_relu_f8 pick its planes) are asked for.
+    split "x3f8": w / w_scale from pack_conv3x3_weight_f8, x_f8 = the fp8 planes of x (include/f3r.h F3R_SPLIT_X3F8).
+    fin = (w4 fp32 [4][N], b4 fp32 [4], n_out, depth_mode id, conf_mode id, vmin, vmax, want_conf): the fused tail of the DPT head (f3r_gemm_args.fin_w)
+    -> returns (pts3d (B,OH,OW,3) fp32, conf (B,OH,OW) fp32 or None) and writes no activation."""
     require_gpu(x, "x")
     lp = x.dtype
     assert x.is_contiguous() and x.dim() == 4
     B, H, W, C = x.shape
     OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     N, Kpad = w.shape
-    if out is None:
-        out = torch.empty((B, OH, OW, N), dtype=lp, device=x.device)
     g = GemmArgs()
     g.kernel_sel = kernel_sel
-    _split_operand(g, x, split, x_lo)
+    if split == "x3f8":
+        assert x_f8 is not None and x_f8.dtype == torch.uint8 and x_f8.shape == (B, H, W, 2 * C) and x_f8.is_contiguous() and w_scale is not None
+        g.split, g.A_lo, g.w_scale = F3R_SPLIT_X3F8, ptr(x_f8), ptr(w_scale)
+    else:
+        _split_operand(g, x, split, x_lo)
     extra = {}
-    if want_lo:
-        extra["out_lo"] = torch.empty_like(out)
-        g.out_lp_lo = ptr(extra["out_lo"])
-    if want_relu:
-        extra["relu"] = torch.empty_like(out)
-        g.out_relu = ptr(extra["relu"])
+    pts = conf = None
+    if fin is not None:
+        fw, fb, n_out, dmode, cmode, vmin, vmax, want_conf = fin
+        assert fw.dtype == torch.float32 and fw.shape == (4, N) and fw.is_contiguous() and fb.dtype == torch.float32 and fb.numel() == 4
+        pts = torch.empty((B, OH, OW, 3), dtype=torch.float32, device=x.device)
+        conf = torch.empty((B, OH, OW), dtype=torch.float32, device=x.device) if want_conf else None
+        g.fin_w, g.fin_b, g.fin_pts, g.fin_conf = ptr(fw), ptr(fb), ptr(pts), ptr(conf)
+        g.fin_n_out, g.fin_depth_mode, g.fin_conf_mode, g.fin_vmin, g.fin_vmax = n_out, dmode, cmode, vmin, vmax
+        g.ldo_lp = N
+    else:
+        if out is None:
+            out = torch.empty((B, OH, OW, N), dtype=lp, device=x.device)
+        g.out_lp, g.ldo_lp = ptr(out), N
         if want_lo:
-            extra["relu_lo"] = torch.empty_like(out)
-            g.out_relu_lo = ptr(extra["relu_lo"])
+            extra["out_lo"] = torch.empty_like(out)
+            g.out_lp_lo = ptr(extra["out_lo"])
+        if want_f8:
+            extra["out_f8"] = torch.empty((B, OH, OW, 2 * N), dtype=torch.uint8, device=x.device)
+            g.out_f8 = ptr(extra["out_f8"])
+        if want_relu:
+            extra["relu"] = torch.empty_like(out)
+            g.out_relu = ptr(extra["relu"])
+            if want_lo if want_relu_lo is None else want_relu_lo:
+                extra["relu_lo"] = torch.empty_like(out)
+                g.out_relu_lo = ptr(extra["relu_lo"])
+            if want_relu_f8:
+                extra["relu_f8"] = torch.empty((B, OH, OW, 2 * N), dtype=torch.uint8, device=x.device)
+                g.out_relu_f8 = ptr(extra["relu_f8"])
     if res_lp_lo is not None:
         g.res_lp_lo = ptr(res_lp_lo)
     if res_lp2_lo is not None:
@@ -463,10 +525,11 @@ def conv3x3(x, w, *, stride=1, bias=None, a_relu=False, act=None, res_lp=None, r
         g.res_lp, g.ldr_lp = ptr(res_lp), N
     if res_lp2 is not None:
         g.res_lp2, g.ldr_lp2 = ptr(res_lp2), N
-    g.out_lp, g.ldo_lp = ptr(out), N
     g.dtype = dtype_id(lp)
-    with _timed(2.0 * B * OH * OW * N * 9 * C):
+    with _timed(2.0 * B * OH * OW * N * 9 * C + (8.0 * B * OH * OW * N if fin is not None else 0.0)):
         check(_lib.lib().f3r_gemm(ctypes.byref(g), stream_ptr()), "f3r_gemm(conv3x3)")
+    if fin is not None:
+        return pts, conf
     if extra:
         extra["out"] = out
         return extra
@@ -597,34 +660,56 @@ def attention_state_finish(state, n_heads, head_dim, lp, want_lo=True, want_f32=
     return (o_hi, o_lo, o32) if want_f32 else (o_hi, o_lo)
 
 
-def upsample2x(x, out_hw=None, x_lo=None, want_lo=False):
+def upsample2x(x, out_hw=None, x_lo=None, want_lo=False, want_f8=False):
     """bilinear x2, align_corners=True, NHWC lowp; optional crop to out_hw.  x_lo: low plane of the input; want_lo: also return the
-    low plane of the output (split precision)."""
-    require_gpu(x, "x")
+    low plane of the output (split precision); want_f8: also its fp8 planes (see interp_bilinear)."""
     B, h, w, C = x.shape
     oh, ow = (2 * h, 2 * w) if out_hw is None else out_hw
-    out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
-    out_lo = torch.empty_like(out) if want_lo else None
-    with _timed(0.0, _nb(x, x_lo, out, out_lo), "elementwise"):
-        check(_lib.lib().f3r_upsample2x(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, dtype_id(x.dtype), stream_ptr()), "f3r_upsample2x")
-    return (out, out_lo) if want_lo else out
+    return interp_bilinear(x, (oh, ow), x_lo=x_lo, want_lo=want_lo, want_f8=want_f8, nominal_hw=(2 * h, 2 * w))
 
 
 DEPTH_MODES = {"exp": 0, "linear": 1, "square": 2}
 CONF_MODES = {"exp": 0, "sigmoid": 1}
 
 
-def interp_bilinear(x, full_hw, x_lo=None, want_lo=False):
-    """F.interpolate(x, size=full_hw, mode="bilinear", align_corners=True) on NHWC lowp (+ low planes), any output size."""
+def interp_bilinear(x, full_hw, x_lo=None, want_lo=False, want_f8=False, nominal_hw=None):
+    """F.interpolate(x, size=full_hw, mode="bilinear", align_corners=True) on NHWC lowp (+ low planes), any output size (nominal_hw: the
+    interpolation's own output size when full_hw is a crop of it).  want_f8: also the fp8 planes uint8 (B,oh,ow,2C) a split="x3f8" conv reads
+    (f3r_interp_bilinear_f8).  Returns out, or (out, out_lo) with want_lo, or (out, out_lo | None, out_f8) with want_f8."""
     require_gpu(x, "x")
     B, h, w, C = x.shape
     oh, ow = full_hw
+    fh, fw = (oh, ow) if nominal_hw is None else nominal_hw
     out = torch.empty((B, oh, ow, C), dtype=x.dtype, device=x.device)
     out_lo = torch.empty_like(out) if want_lo else None
-    with _timed(0.0, _nb(x, x_lo, out, out_lo), "elementwise"):
-        check(_lib.lib().f3r_interp_bilinear(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), B, h, w, C, oh, ow, oh, ow, dtype_id(x.dtype), stream_ptr()),
-              "f3r_interp_bilinear")
+    out_f8 = torch.empty((B, oh, ow, 2 * C), dtype=torch.uint8, device=x.device) if want_f8 else None
+    with _timed(0.0, _nb(x, x_lo, out, out_lo, out_f8), "elementwise"):
+        check(_lib.lib().f3r_interp_bilinear_f8(ptr(x), ptr(x_lo), ptr(out), ptr(out_lo), ptr(out_f8), B, h, w, C, fh, fw, oh, ow, dtype_id(x.dtype),
+                                                stream_ptr()), "f3r_interp_bilinear")
+    if want_f8:
+        return out, out_lo, out_f8
     return (out, out_lo) if want_lo else out
+
+
+def dpt_fin_args(w, b, conf_mode, depth_mode=("exp", -math.inf, math.inf)):
+    """The `fin` argument of conv3x3 (the DPT head's tail fused into head[2]'s epilogue) from head[4]'s weight (n_out, Cin) / bias and the
+    reference's (mode, vmin, vmax) triples -- the same checks as dpt_final (heads/postprocess.py:27-64)."""
+    n_out, cin = w.shape
+    assert b.shape == (n_out,) and n_out == (4 if conf_mode is not None else 3)
+    dmode, dmin, dmax = depth_mode
+    if dmode not in DEPTH_MODES:
+        raise ValueError(f"bad mode={dmode!r}")  # postprocess.py:51
+    assert dmin == -math.inf and dmax == math.inf  # :33-34
+    cmode, vmin, vmax = 0, 1.0, math.inf
+    if conf_mode is not None:
+        if conf_mode[0] not in CONF_MODES:
+            raise ValueError(f"bad mode={conf_mode[0]!r}")  # :64
+        cmode, vmin, vmax = CONF_MODES[conf_mode[0]], float(conf_mode[1]), float(conf_mode[2])
+    w4 = torch.zeros((4, cin), dtype=torch.float32, device=w.device)
+    w4[:n_out] = w.float()
+    b4 = torch.zeros((4,), dtype=torch.float32, device=w.device)
+    b4[:n_out] = b.float()
+    return (w4.contiguous(), b4, n_out, DEPTH_MODES[dmode], cmode, vmin, vmax, conf_mode is not None)
 
 
 def dpt_final(x, w, b, conf_mode, x_lo=None, depth_mode=("exp", -math.inf, math.inf)):

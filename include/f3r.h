@@ -46,7 +46,7 @@ typedef enum { F3R_F16 = 0, F3R_BF16 = 1 } f3r_dtype;
 #define F3R_MAX_SEG 8
 
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
-int f3r_version(void);  /* 340 = 0.3.4, round 6 (+ f3r_block_workspace_bytes_ex; the library clears sched_counter per launch); 330 = 0.3.3, round 5 (f3r_attn_args.dbg_counters is uint32[8] incl. two clock sums; f3r_wall_clock_khz); 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
+int f3r_version(void);  /* 350 = 0.3.5, round 6 (F3R_SPLIT_X3F8, f3r_gemm_args.out_f8 / out_relu_f8 / fin_*, f3r_interp_bilinear_f8); 340 = 0.3.4, round 6 (+ f3r_block_workspace_bytes_ex; the library clears sched_counter per launch); 330 = 0.3.3, round 5 (f3r_attn_args.dbg_counters is uint32[8] incl. two clock sums; f3r_wall_clock_khz); 320 = 0.3.2, round 4 (+ f3r_attn_f32_mfma, head_dim 80 / 128 kernels); 310: f3r_attn_args.dbg_counters, f3r_gemm_args.kernel_sel 6; 300 = round 3; 200 = round 2 */
 const char* f3r_last_error_string(void);
 /* sizeof(f3r_gemm_args) (what == 0) / sizeof(f3r_attn_args) (what == 1) / sizeof(f3r_attn_f32_args) (what == 2): lets a foreign-language binding
    verify its struct layout before the first call; 0 for an unknown `what` */
@@ -179,6 +179,25 @@ typedef struct f3r_gemm_args {
      fp16 planes here ([Dkv][2 K], as F3R_SPLIT_W2 packs them): the V^T launch runs with swapped operand roles on the fp16 kernel (its "weights"
      are the activations).  NULL otherwise. */
   const void* W_aux;
+  /* ABI 350 (round 6).  fp8 COPIES of the lowp outputs for the next F3R_SPLIT_X3F8 convolution (GENERIC epilogue; NULL = not written): row m of
+     out_f8 is 2 N bytes [ e4m3(clamp(v, +-448)) x N | e4m3(clamp((v - float(fp16(v))) 2^12, +-448)) x N ] for the values v that out_lp rounds;
+     out_relu_f8 the same for relu(v) (what out_relu carries).  fp16 only, N % 8 == 0, 8-byte aligned. */
+  void* out_f8;
+  void* out_relu_f8;
+  /* ABI 350: the tail of the DPT head fused into the epilogue of its last 3x3 convolution (head[2] + ReLU -> head[4] 1x1 conv -> postprocess,
+     dpt_block.py:375-381, heads/postprocess.py:16-64): with fin_w != NULL the launch must be a CONV3X3 whose N <= 128 output channels lie in ONE
+     256 x 128 tile of the 256-tile kernel (N % 128 == 0 today: the DPT head's last_dim = 128); the epilogue applies `act` to the fp32
+     accumulators, multiplies them by fin_w (fp32 [4][N], rows >= fin_n_out zero) + fin_b (fp32 [4]) on the vector pipe and writes
+     fin_pts (fp32 [M][3]) / fin_conf (fp32 [M] or NULL) exactly as f3r_dpt_final does (fin_depth_mode / fin_conf_mode / fin_vmin / fin_vmax: its
+     arguments).  No lowp output is written then (out_lp may be NULL): the 128-channel activation never reaches HBM.  F3R_ERR_UNSUPPORTED when the
+     launch cannot take the 256 x 128 tile form. */
+  const float* fin_w;
+  const float* fin_b;
+  float* fin_pts;
+  float* fin_conf;
+  int32_t fin_n_out, fin_depth_mode, fin_conf_mode;
+  float fin_vmin, fin_vmax;
+  int32_t reserved0;
 } f3r_gemm_args;
 
 /* F3R_SPLIT_W2F8 (ABI 330): W2 with the LOW plane of the weights, and the copy of the activations it multiplies, in fp8 (OCP e4m3) on the
@@ -189,7 +208,15 @@ typedef struct f3r_gemm_args {
    bytes of a word).  The correction term A W_lo is 2^-11 of the product and tolerates the 2^-4 relative error of both fp8 operands: the
    weight's rounding error drops ~24x instead of vanishing (tools/emu_gemm.py run_case_f8).  fp16 operands, plain A, GENERIC epilogue with ONE
    output (as kernel_sel 6), M and N multiples of 256 -- anything else is F3R_ERR_UNSUPPORTED (there is no second kernel for this layout). */
-typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2, F3R_SPLIT_W2F8 = 3 } f3r_split;
+/* F3R_SPLIT_X3F8 (ABI 350; the 3x3 convolutions of the DPT head, dpt_block.py:133-154,365-382): X3 whose two CORRECTION products run on the
+   block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4): A_hi W_hi on fp16 + A_hi8 W_lo8 + A_lo8 W_hi8 -- two matrix-pipe units instead of
+   three (each correction is 2^-11 of the product and tolerates the 2^-4 relative error of both fp8 operands; oracle/precision_study.py --study
+   heads_f8: the stress fixture moves from 6.94e-4 to 6.93e-4).  CONV3X3 only, stride 1, conv_C % 128 == 0, fp16, the 256-tile kernel
+   (F3R_ERR_UNSUPPORTED otherwise).  A = the fp16 high plane (NHWC); A_lo = the fp8 planes of the same tensor, per pixel [C bytes e4m3(hi, clamped to
+   +-448) | C bytes e4m3(lo 2^12, clamped)] (what out_f8 / f3r_interp_bilinear_f8 write); W rows are [9 C fp16 hi | 9 C bytes e4m3(w_lo 2^s_n) |
+   9 C bytes e4m3(w_hi 2^t_n)] (4 * 9 C bytes: Kpad = 2 * 9 C as for X3, k = tap * C + ci in every plane) and w_scale[n] holds the E8M0 bytes
+   127 - s_n (byte 0) and 127 - t_n (byte 1) (ops.pack_conv3x3_weight_f8). */
+typedef enum { F3R_SPLIT_NONE = 0, F3R_SPLIT_W2 = 1, F3R_SPLIT_X3 = 2, F3R_SPLIT_W2F8 = 3, F3R_SPLIT_X3F8 = 4 } f3r_split;
 
 int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream);
 
@@ -334,6 +361,11 @@ int f3r_upsample2x(const void* in, const void* in_lo, void* out, void* out_lo, i
  * patch_size / 8) (dpt_block.py:374) is x2 for patch 16 and x1.75 for DINOv2's patch 14. */
 int f3r_interp_bilinear(const void* in, const void* in_lo, void* out, void* out_lo, int batch, int h, int w, int C, int full_h, int full_w,
                         int out_h, int out_w, int dtype, f3r_stream_t stream);
+/* ABI 350: the same with an optional fp8 copy of the output for the next F3R_SPLIT_X3F8 convolution: out_f8 (NULL = none) is
+   [batch][out_h][out_w][2 C] bytes, per pixel [C bytes e4m3(y clamped to +-448) | C bytes e4m3((y - float(fp16(y))) 2^12, clamped)] (f3r_gemm_args.out_f8
+   describes the same layout).  fp16 only when out_f8 is given. */
+int f3r_interp_bilinear_f8(const void* in, const void* in_lo, void* out, void* out_lo, void* out_f8, int batch, int h, int w, int C, int full_h,
+                           int full_w, int out_h, int out_w, int dtype, f3r_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f3r_dpt_final: last 1x1 conv (Cin -> n_out) fused with postprocess.

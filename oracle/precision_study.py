@@ -100,6 +100,22 @@ def _apply(fn, a, w, *rest, **kw):
         out = fn(a1, wh, None, *rest, **kw) + fn(rnd8(a1), rnd8(wl), None, *rest, **kw)
         if base == "f16x3_8":
             out = out + fn(rnd8(al), rnd8(wh), None, *rest, **kw)
+    elif base == "f16x3_8c":
+        # what f3r_gemm split "x3f8" computes (round 6, DPT-head convolutions): a_hi w_hi on fp16; a_hi8 w_lo8 with one power-of-two scale per OUTPUT
+        # CHANNEL on w_lo (largest |w_lo| of the row -> [112, 224]) and a_hi8 = e4m3(clamp(a_hi, 448)) unscaled; a_lo8 w_hi8 with the fixed scale 2^12 on
+        # a_lo (clamped) and w_hi8 = e4m3(w_hi) scaled per output channel like the weights' low plane
+        ah, al = split2(a, torch.float16)
+        wh, wl = split2(w, torch.float16)
+        def f8(x):
+            return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+        def per_row(x):
+            amax = x.abs().flatten(1).amax(dim=1).clamp_min(2.0 ** -100)
+            sc = torch.exp2(torch.floor(torch.log2(224.0 / amax))).view(-1, *([1] * (x.dim() - 1)))
+            return f8(x * sc) / sc
+        if fn is F.conv_transpose2d:
+            out = fn(ah, wh, None, *rest, **kw) + fn(al, wh, None, *rest, **kw) + fn(ah, wl, None, *rest, **kw)
+        else:
+            out = fn(ah, wh, None, *rest, **kw) + fn(f8(ah), per_row(wl), None, *rest, **kw) + fn(f8(al * 4096.0) / 4096.0, per_row(wh), None, *rest, **kw)
     elif base in ("f16x3", "bf16x3"):
         dt = DT[base[:-2]]
         ah, al = split2(a, dt)
@@ -262,6 +278,14 @@ STUDIES = {
         ("head.0 + head.2 activations split only", "f16w2", "f16x3", None, None, {29: "f16x2", 30: "f16x2"}),
         ("head.0 + head.2 weights split only", "f16w2", "f16x3", None, None, {29: "f16w2", 30: "f16w2"}),
         ("every conv: activations split only", "f16w2", "f16x3", None, None, {i: "f16x2" for i in range(32)})]),
+    # round 6: the correction products of the heads' 3x3 convolutions from fp8 operands (f3r_gemm split "x3f8"): 11-13 / 14-18 / 19-23 /
+    # 24-28 = refinenet4..1 (4 RCU convs + the 1x1 out_conv, which stays on fp16 planes), 29 = head.0, 30 = head.2
+    "heads_f8": ("hot", [
+        ("x3 everywhere (the product before)", "f16w2", "f16x3", None, None, {}),
+        ("RCU convs + head.0 + head.2 with fp8 corrections", "f16w2", "f16x3", None, None,
+         {i: "f16x3_8c" for i in (11, 12, 14, 15, 16, 17, 19, 20, 21, 22, 24, 25, 26, 27, 29, 30)}),
+        ("head.0 + head.2 only", "f16w2", "f16x3", None, None, {29: "f16x3_8c", 30: "f16x3_8c"}),
+        ("every 3x3 / 1x1 conv of the heads", "f16w2", "f16x3_8c", None, None, {})]),
     "fp8": ("hot", [     # the weight-correction product of the transformer's linear layers from fp8 operands (Fast3R.low_plane = "fp8")
         ("w2 everywhere (two fp16 planes)", "f16w2", "f16x3", None, None, {}), ("low plane in fp8 everywhere", "f16w2_8", "f16x3", None, None, {}),
         ("low plane in fp8 on qkv + fc1 + fc2 (the product)", "f16w2", "f16x3", None, {"qkv": "f16w2_8", "fc1": "f16w2_8", "fc2": "f16w2_8"}, {}),

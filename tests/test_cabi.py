@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound(built_lib):
     for n in names:
         assert hasattr(built_lib, n), f"{n} declared in include/f3r.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype in fast3r_amd/_lib.py"
-    assert built_lib.f3r_version() >= _lib.ABI_VERSION == 340
+    assert built_lib.f3r_version() >= _lib.ABI_VERSION == 350
 
 
 def test_struct_layouts_match(built_lib):
