@@ -419,7 +419,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
   if (a.kernel_sel >= 16) return f3r_gemm256_lab(a, s);
   if (a.split == F3R_SPLIT_X3F8 || a.fin_w) {  // one kernel family takes these (f3r_gemm256_f8.hip): no second path, no fallback
     if (!f3r_gemm256_eligible(a)) {
-      f3r_set_error("f3r_gemm: split X3F8 / fin_w but the launch is not eligible for the 256-tile kernel (stride 1, conv_C %% 64 (X3F8: 128) == 0, "
+      f3r_set_error("f3r_gemm: split X3F8 / fin_w but the launch is not eligible for the 256-tile kernel (conv_C %% 64 (X3F8: 128) == 0, "
                     "N %% 128 == 0 (fin_w: N == 128), operand below 4 GiB)");
       return F3R_ERR_UNSUPPORTED;
     }

@@ -19,8 +19,9 @@ bool f3r_gemm256_eligible(const f3r_gemm_args& a) {
     if (a.K != Kpad1) return false;
     if ((int64_t)256 * a.lda * 2 >= (1ll << 32)) return false;
   } else {
-    if (a.conv_stride != 1 || a.a_relu || a.conv_C % 64 != 0) return false;
-    if (a.M * (int64_t)a.conv_C * 2 >= (1ll << 32)) return false;  // 32-bit byte offsets into the NHWC operand
+    if (a.a_relu || a.conv_C % 64 != 0) return false;
+    // 32-bit byte offsets into the NHWC operand (B * H * W pixels; stride 2 reads four times the output's pixel count)
+    if (a.M / ((int64_t)a.conv_OH * a.conv_OW) * a.conv_H * a.conv_W * a.conv_C * 2 >= (1ll << 32)) return false;
     if (a.split == F3R_SPLIT_X3F8 && (a.conv_C % 128 != 0 || a.dtype != F3R_F16)) return false;
   }
   if (a.split == F3R_SPLIT_X3F8 && a.a_mode != F3R_A_CONV3X3) return false;

@@ -137,7 +137,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   uint32_t a_msk[2][2];               // CONV: bit tap = the tap of this lane's pixel lies OUTSIDE the image (or the row is past M)
   const char* const Ab = (const char*)p.A;
   const char* const Alo = (const char*)p.A_lo;
-  // CONV: bytes of an operand plane (stride 1: as many input as output pixels), the range of the buffer descriptors
+  // CONV: bytes of an operand plane, the range of the buffer descriptors
   const uint32_t a_bytes = A_MODE == F3R_A_CONV3X3 ? (uint32_t)(p.M / ((int64_t)p.conv_OH * p.conv_OW) * p.conv_H * p.conv_W * p.conv_C * 2) : 0u;
   const char* Wb = nullptr;
   uint32_t wsc[NH][2];  // F8: the scale word of this lane's weight row in fragment nf of W half h (byte 0: lo8 plane, byte 1: hi8 plane)
@@ -176,11 +176,12 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
         const int b = (int)(mm / per_img);
         const int rem = (int)(mm % per_img);
         const int oy = rem / p.conv_OW, ox = rem - oy * p.conv_OW;
-        a_off[h][i] = (uint32_t)(((((int64_t)b * p.conv_H + oy) * p.conv_W + ox) * p.conv_C + lc * 8) * 2);
+        const int cy = oy * p.conv_stride, cx = ox * p.conv_stride;  // the input pixel under the kernel's centre tap
+        a_off[h][i] = (uint32_t)(((((int64_t)b * p.conv_H + cy) * p.conv_W + cx) * p.conv_C + lc * 8) * 2);
         uint32_t msk = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+          const int iy = cy + tap / 3 - 1, ix = cx + tap % 3 - 1;
           if (!(ok && iy >= 0 && iy < p.conv_H && ix >= 0 && ix < p.conv_W)) msk |= 1u << tap;
         }
         a_msk[h][i] = msk;

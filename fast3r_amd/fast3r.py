@@ -445,10 +445,24 @@ def _pack_head(head: PixelwiseTaskWithDPT, lp, split=False, f8=False):
         return _ConvW(ops.pack_conv3x3_weight(w, lp, split))
     h.a_w = [lin(ap[i][0].weight) for i in range(4)]
     h.a_b = [_f32(ap[i][0].bias) for i in range(4)]
-    h.t0_w, h.t0_b = ops.pack_convT_weight(ap[0][1].weight.detach().float(), ap[0][1].bias.detach(), lp, split)
-    h.t1_w, h.t1_b = ops.pack_convT_weight(ap[1][1].weight.detach().float(), ap[1][1].bias.detach(), lp, split)
+    # The transposed convolutions write their output with the channel count rounded up to 64 (layer_dims[0] = 96 -> 128 zero-weight / zero-bias
+    # channels, matched by zero input channels in layer1_rn's weight: exact): the 3x3 convolution behind them then has a channel count the
+    # 256-tile kernel's LDS-DMA staging takes (a ragged one ran on the 128-tile kernel through registers: 13.8 of 126 ms of head convolutions at N = 100).
+    def convT_padded(m):
+        w, b = m.weight.detach().float(), m.bias.detach().float()
+        pad = ops.round_up(w.shape[1], 64) - w.shape[1]
+        if pad:
+            w, b = nn.functional.pad(w, (0, 0, 0, 0, 0, pad)), nn.functional.pad(b, (0, pad))
+        return ops.pack_convT_weight(w, b, lp, split) + (w.shape[1],)
+
+    def rn(i):
+        w = getattr(d.scratch, f"layer{i + 1}_rn").weight.detach().float()
+        pad = ops.round_up(w.shape[1], 64) - w.shape[1] if i < 2 else 0   # (levels 0 / 1 read the transposed convolutions' padded outputs)
+        return c33(nn.functional.pad(w, (0, 0, 0, 0, 0, pad)) if pad else w)
+    h.t0_w, h.t0_b, h.t0_cout = convT_padded(ap[0][1])
+    h.t1_w, h.t1_b, h.t1_cout = convT_padded(ap[1][1])
     h.c3_w, h.c3_b = c33(ap[3][1].weight), _f32(ap[3][1].bias)
-    h.rn_w = [c33(getattr(d.scratch, f"layer{i + 1}_rn").weight) for i in range(4)]
+    h.rn_w = [rn(i) for i in range(4)]
     h.ref = []
     for i in range(1, 5):
         r = getattr(d.scratch, f"refinenet{i}")
@@ -1376,8 +1390,8 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
         def rows_of(t):
             return t.shape[0] * t.shape[1] * t.shape[2]
 
-        l0 = convT(c1(0), hk.t0_w, hk.t0_b, 4, ld[0])                                  # dpt_block.py:416-434
-        l1 = convT(c1(1), hk.t1_w, hk.t1_b, 2, ld[1])                                  # :436-454
+        l0 = convT(c1(0), hk.t0_w, hk.t0_b, 4, hk.t0_cout)                             # dpt_block.py:416-434 (channels padded to 64: _pack_head)
+        l1 = convT(c1(1), hk.t1_w, hk.t1_b, 2, hk.t1_cout)                             # :436-454
         l2 = c1(2)                                                                      # :456-464
         l3 = conv(c1(3), hk.c3_w, bias=hk.c3_b, stride=2)["x"]                          # :466-481
         # scratch.layer_rn (no bias); the relu copy feeds the first RCU convolution of its level

@@ -38,8 +38,8 @@ def _decode_weight_f8(wp, sc, co, ci):
     return cv(hi), cv(lo8), cv(hi8)
 
 
-def _conv64(x_nhwc, w):
-    return F.conv2d(x_nhwc.double().permute(0, 3, 1, 2), w.double(), None, padding=1).permute(0, 2, 3, 1)
+def _conv64(x_nhwc, w, stride=1):
+    return F.conv2d(x_nhwc.double().permute(0, 3, 1, 2), w.double(), None, padding=1, stride=stride).permute(0, 2, 3, 1)
 
 
 def _planes_ref(x32, wp, sc, co, ci):
@@ -106,13 +106,42 @@ def test_conv_x3f8_planes_and_accuracy(built_lib, B, H, W, Ci, Co, res):
         assert float((hi_plane - val).abs().max()) <= float(val.abs().max()) * 2.0 ** -10
 
 
+@pytest.mark.parametrize("split", ["x3", "x3f8"])
+def test_conv_stride_2_on_the_256_tile_kernel(built_lib, split):
+    """act_postprocess[3][1] (Conv2d 3x3, stride 2, dpt_block.py:466-481): since round 6 the 256-tile kernel takes strided convolutions too (the lane's
+    pixel is the input pixel under the centre tap; taps and padding as before) -- every kernel form against float64 on the unrounded operands"""
+    B, H, W, Ci, Co = 2, 33, 40, 128, 256
+    g = torch.Generator().manual_seed(21)
+    x32 = torch.randn((B, H, W, Ci), generator=g)
+    w32 = torch.randn((Co, Ci, 3, 3), generator=g) * (9 * Ci) ** -0.5
+    bias = torch.randn(Co, generator=g)
+    ref = _conv64(x32, w32, stride=2) + bias.double()
+    x_hi, x_lo = ops.split_planes(x32, H16)
+    if split == "x3f8":
+        wp, sc = ops.pack_conv3x3_weight_f8(w32)
+        kw = dict(split="x3f8", x_f8=ops.f8_planes(x32).to(DEV), w_scale=sc.to(DEV))
+        sels = [0]
+    else:
+        wp = ops.pack_conv3x3_weight(w32, H16, split=True)
+        kw = dict(split="x3", x_lo=x_lo.to(DEV))
+        sels = [1, 2, 4, 0]
+    outs = []
+    for sel in sels:
+        r = ops.conv3x3(x_hi.to(DEV), wp.to(DEV), stride=2, bias=bias.to(DEV), want_lo=True, kernel_sel=sel, **kw)
+        assert r["out"].shape == (B, 17, 20, Co)
+        assert_close(r["out"].float().double().cpu() + r["out_lo"].float().double().cpu(), ref, 2e-5, f"stride-2 conv {split} sel={sel}")
+        outs.append(r["out"])
+
+
 def test_conv_x3f8_needs_the_256_tile_kernel(built_lib):
     """no second kernel reads this layout: a launch the 256-tile kernel cannot take is an error, never a fallback"""
     x32 = torch.randn((1, 8, 8, 128))
     w32 = torch.randn((128, 128, 3, 3)) * 0.03
     wp, sc = ops.pack_conv3x3_weight_f8(w32)
-    with pytest.raises(ValueError):  # stride 2
-        ops.conv3x3(x32.to(H16).to(DEV), wp.to(DEV), stride=2, split="x3f8", x_f8=ops.f8_planes(x32).to(DEV), w_scale=sc.to(DEV))
+    w96 = torch.randn((96, 128, 3, 3)) * 0.03
+    wp96, sc96 = ops.pack_conv3x3_weight_f8(w96)
+    with pytest.raises(ValueError):  # 96 output channels: not a multiple of the 128-wide tile half
+        ops.conv3x3(x32.to(H16).to(DEV), wp96.to(DEV), split="x3f8", x_f8=ops.f8_planes(x32).to(DEV), w_scale=sc96.to(DEV))
     xb = x32.to(torch.bfloat16)
     with pytest.raises(ValueError):  # bf16 planes
         ops.conv3x3(xb.to(DEV), wp.view(torch.bfloat16).to(DEV), split="x3f8", x_f8=ops.f8_planes(x32).to(DEV), w_scale=sc.to(DEV))

@@ -168,6 +168,52 @@ def test_pack_conv3x3_layout():
     assert torch.allclose(y, ref, atol=1e-4)
 
 
+def test_pack_conv3x3_f8_layout_and_planes():
+    """ops.pack_conv3x3_weight_f8 / ops.f8_planes (f3r.h F3R_SPLIT_X3F8): emulate on the CPU what the kernel sums -- A_hi W_hi + A_hi8 W_lo8 + A_lo8 W_hi8
+    with the E8M0 scales applied -- from the packed bytes alone and compare with the fp32 convolution: fp32-class, and the fp8 rounding of the two
+    correction products alone is what separates it from exact planes (dpt_block.py:133-154; oracle/precision_study.py mode f16x3_8c is the same sum)."""
+    torch.manual_seed(0)
+    co, ci, H, W = 16, 128, 6, 7
+    w = torch.randn(co, ci, 3, 3) * (9 * ci) ** -0.5
+    w[1] *= 1e-3
+    w[2] *= 40.0
+    x = torch.randn(2, H, W, ci) * 2.0
+    x[0, 0, 0, :4] = torch.tensor([900.0, -500.0, 1e-5, 0.0])   # beyond e4m3's +-448 (clamped in the fp8 planes), and below its subnormals
+    wp, sc = ops.pack_conv3x3_weight_f8(w)
+    kp = 9 * ci
+    assert wp.dtype == torch.float16 and wp.shape == (co, 2 * kp) and sc.dtype == torch.int32 and sc.shape == (co,)
+    raw = wp.view(torch.uint8).view(co, 4 * kp)
+    dec8 = lambda b: b.contiguous().view(torch.float8_e4m3fn).double()
+    w_hi = raw[:, :2 * kp].contiguous().view(torch.float16).double()
+    e_lo, e_hi = (sc.long() & 0xff).double(), ((sc.long() >> 8) & 0xff).double()
+    w_lo8 = dec8(raw[:, 2 * kp:3 * kp]) * torch.exp2(e_lo - 127)[:, None]
+    w_hi8 = dec8(raw[:, 3 * kp:]) * torch.exp2(e_hi - 127)[:, None]
+    taps = w.permute(0, 2, 3, 1).reshape(co, kp).double()          # k = (ky*3 + kx) * Cin + ci in every plane
+    assert torch.equal(w_hi, taps.to(torch.float16).double())
+    # the scaled planes use e4m3's range: largest magnitude of every row in [112, 448], relative error of a plane element <= 2^-4 of the row's scale
+    assert (raw[:, 2 * kp:3 * kp].view(torch.float8_e4m3fn).float().abs().amax(dim=1) >= 112).all()
+    assert ((w_lo8 - (taps - w_hi)).abs().amax(dim=1) <= (taps - w_hi).abs().amax(dim=1) * 2.0 ** -4).all()
+    assert ((w_hi8 - w_hi).abs().amax(dim=1) <= w_hi.abs().amax(dim=1) * 2.0 ** -4).all()
+    p8 = ops.f8_planes(x)
+    assert p8.dtype == torch.uint8 and p8.shape == (2, H, W, 2 * ci)
+    a_hi = x.to(torch.float16).double()
+    a_hi8, a_lo8 = dec8(p8[..., :ci]), dec8(p8[..., ci:]) / 4096.0
+    assert float(a_hi8.abs().max()) == 448.0 and float((a_lo8 - (x.double() - a_hi).clamp(-448 / 4096, 448 / 4096)).abs().max()) <= 2.0 ** -4 * 448 / 4096
+
+    def conv(a, wk):   # NHWC x [co][kp] -> NHWC, through the same im2col index map as test_pack_conv3x3_layout
+        xp = F.pad(a, (0, 0, 1, 1, 1, 1))
+        cols = torch.stack([xp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=3)
+        return cols.reshape(2, H, W, kp) @ wk.t()
+    got = conv(a_hi, w_hi) + conv(a_hi8, w_lo8) + conv(a_lo8, w_hi8)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    far = torch.ones_like(ref, dtype=torch.bool)
+    far[0, :2, :2] = False                                            # (the clamped inputs touch only their 3x3 neighbourhood)
+    scale = float((ref.abs() * far).max())
+    err = float(((got - ref).abs() * far).max()) / scale
+    single = float(((conv(a_hi, w_hi) - ref).abs() * far).max()) / scale
+    assert err < 3e-5 and single > 10 * err, (err, single)
+
+
 def test_pack_convT_layout():
     torch.manual_seed(0)
     ci, co, s, h, w_ = 16, 8, 4, 3, 5

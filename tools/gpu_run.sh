@@ -36,6 +36,34 @@ json.dump(out, open(f"{d}/gemm_asm_pmc.json", "w"), indent=1)
 PY
       find $d/pmc -name "*kernel_trace.csv" -delete
       fi ;;
+    convf8pmc)  # the DPT head's conv roles, split x3 vs x3f8: event timings, then two rocprofv3 --pmc passes over the same launches (matrix-pipe busy, waits, instruction mix)
+      timeout 600 python tools/conv_f8_ab.py > $d/conv_roles.jsonl 2> $d/err.log; cat $d/conv_roles.jsonl | cut -c1-200
+      ( cd /tmp; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $OLDPWD/$d/pmc1 --output-format csv -- python $OLDPWD/tools/conv_f8_ab.py --roles head2,head0,rcu128 --reps 2 > $OLDPWD/$d/pmc1.log 2>&1
+        rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS -d $OLDPWD/$d/pmc2 --output-format csv -- python $OLDPWD/tools/conv_f8_ab.py --roles head2,head0,rcu128 --reps 2 > $OLDPWD/$d/pmc2.log 2>&1 )
+      python - $d <<'PY'
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+out = {"source": "rocprofv3 --kernel-trace --pmc (two passes) over tools/conv_f8_ab.py --roles head2,head0,rcu128 --reps 2; averages per launch",
+       "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024); waits as fractions of SQ_WAVE_CYCLES", "kernels": {}}
+for sub in ("pmc1", "pmc2"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{d}/{sub}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "gemm256" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("::")[-1][:70] + " grid=" + r.get("Grid_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, c in acc.items():
+        out["kernels"].setdefault(k, {}).update({n: sum(x) / len(x) for n, x in c.items()})
+for k, v in out["kernels"].items():
+    if v.get("GRBM_GUI_ACTIVE"):
+        v["mfma_util"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 4)
+    if v.get("SQ_WAVE_CYCLES"):
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if n in v:
+                v[n + "_frac"] = round(v[n] / v["SQ_WAVE_CYCLES"], 4)
+    print(k, {n: (round(x, 4) if x < 100 else int(x)) for n, x in v.items()})
+json.dump(out, open(f"{d}/conv_x3_vs_x3f8_pmc.json", "w"), indent=1)
+PY
+      find $d/pmc1 $d/pmc2 -name "*kernel_trace.csv" -delete; rm -rf $d/pmc1 $d/pmc2 ;;
     attnhd)     # the generated head_dim-80 / 128 attention kernels: parity tests, then TF/s beside the generic HIP kernel and the head_dim-64 kernel
       timeout 900 python -m pytest tests/test_attn_asm_gpu.py tests/test_kernels_gpu.py -q -rA -p no:cacheprovider -k "head_dim or other_head" 2>&1 | tail -150 > $d/pytest.log; grep -E "passed|failed|FAILED|Error" $d/pytest.log | tail -20
       timeout 600 python tools/kernel_bench.py --what attnhd --views ${ATTNHD_VIEWS:-100} --attn-dtypes ${ATTNHD_DTYPES:-fp16,bf16} > $d/attn_head_dim.jsonl 2> $d/err.log; cat $d/attn_head_dim.jsonl | cut -c1-330; tail -3 $d/err.log ;;
