@@ -316,6 +316,7 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     F3R_REQUIRE(a.K > 0 && a.K % 128 == 0 && a.Kpad == a.K, "f3r_gemm: W2F8 needs K = Kpad, a multiple of 128 (got %d / %d)", a.K, a.Kpad);
     F3R_REQUIRE(a.lda % 8 == 0 && a.lda * 2 >= (int64_t)a.K * 3, "f3r_gemm: W2F8 rows are [K fp16 | K fp8]: lda %lld must be >= 3 K / 2", (long long)a.lda);
     F3R_REQUIRE(a.epi != F3R_EPI_GENERIC || a.out_f32 || a.out_lp, "f3r_gemm: no output");
+    F3R_REQUIRE(!a.out_f8 && !a.out_relu_f8 && !a.fin_w, "f3r_gemm: W2F8 launches write one output (no out_f8 / out_relu_f8 / fin_w)");
     // the checks the other splits get further down (a C caller reaches the hand-scheduled epilogues only through here: ADVICE r5)
     F3R_REQUIRE((a.kernel_sel >= 0 && a.kernel_sel <= 7) || a.kernel_sel == 9, "f3r_gemm: bad kernel_sel %d", a.kernel_sel);
     F3R_REQUIRE(a.dtype == F3R_F16, "f3r_gemm: W2F8 corrects fp16 planes only (dtype %d)", a.dtype);
@@ -348,6 +349,8 @@ extern "C" int f3r_gemm(const f3r_gemm_args* args, f3r_stream_t stream) {
     }
     return f3r_gemm_asm_f8_launch(a, (hipStream_t)stream);
   }
+  // the fp8 output planes and the fused DPT tail belong to the GENERIC epilogue (every other epilogue would silently ignore them)
+  F3R_REQUIRE(a.epi == F3R_EPI_GENERIC || (!a.out_f8 && !a.out_relu_f8 && !a.fin_w), "f3r_gemm: out_f8 / out_relu_f8 / fin_w need the generic epilogue (epi %d)", a.epi);
   const int planes = a.split ? 2 : 1;
   F3R_REQUIRE(a.Kpad > 0 && a.Kpad % (64 * planes) == 0, "f3r_gemm: Kpad %d must be a positive multiple of %d", a.Kpad, 64 * planes);
   const int Kpad1 = a.Kpad / planes;

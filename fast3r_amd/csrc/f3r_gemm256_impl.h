@@ -88,7 +88,8 @@ struct IC {
 // phase instead of 16 of 16): two units of MFMA work instead of X3's three.  Scales: weights one E8M0 byte per output channel and plane
 // (w_scale), activations 2^0 (hi8) / 2^-12 (lo8).
 // FIN (f3r_gemm_args.fin_w): the epilogue is gemm_epilogue_fin (ReLU -> 1x1 conv to 4 channels -> postprocess), NH == 1 only.
-template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0, bool F8 = false, bool FIN = false>
+// MERGED (round 6, measurement only): a schedule with half the barriers per MFMA -- see "merged phases" below; measured and not taken.
+template <class T, int A_MODE, int EPI, bool SWAP, int STAGGER, int ADDSRC, int NH = 2, int LAB = 0, bool F8 = false, bool FIN = false, bool MERGED = false>
 __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* smem, const int64_t m0_tile, const int n0_tile, const bool first = true,
                                              const bool has_next = false, const int64_t m0_next = 0, const int n0_next = 0) {
   // PERSISTENT form (gemm256_kernel walks several output tiles per workgroup): `first` = this workgroup's first tile (its opening loads
@@ -420,6 +421,80 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     if (!(LAB & 8)) F3R_VMCNT(8);
     F3R_PHASE_MMA(1, 1, 0)
   };
+  // ---- merged phases (MERGED; measurement only, NOT the product's schedule): a phase is TWO quadrants = 32 MFMAs between one pair of barriers
+  // (the quadrant pairs (A0,W0)+(A1,W0) and (A1,W1)+(A0,W1) need no register the four-phase form does not hold already).  The question it
+  // answers: a phase takes ~0.55 us whether it carries 16 KiB or 24 KiB of operands, against 2 x 256 matrix-pipe cycles ~ 0.25 us
+  // (profiles/r06_conv_x3_vs_x3f8_pmc.json) -- is the barrier pair the fixed cost?  No: with half the barriers per MFMA the 256 x 128 tile got
+  // 9 - 11 % SLOWER and the 256 x 256 tile stayed where it was, with the LDS-DMA issued behind the MFMAs of the phase (formally hazard-free) or
+  // in the section that carries the fragment reads (below; the restaged slots' last reads are then only ONE barrier older, which the in-order
+  // LDS queue makes safe in practice but no wait proves) -- profiles/r06_conv_merged_phases_*_rejected.jsonl.  What the merged form loses is
+  // lead time: with three 48 KiB buffers a one-phase tile must restage the buffer it read one phase ago, so a piece has one phase to land
+  // instead of three.
+  // NH == 2, tile t in buffer B = t % 2:
+  //   P0  reads W0, A0, A1 of B;  issue W1 of t+1 -> B^1;          wait vmcnt(8): W1 of tile t has landed;        MFMA (A0,W0) (A1,W0)
+  //   P1  reads W1 of B;          issue A0, W0, A1 of t+2 -> B;    wait vmcnt(8): A0, W0, A1 of t+1 have landed;  MFMA (A1,W1) (A0,W1)
+  // NH == 1, tile t in buffer t % 3, one phase per tile:
+  //   reads W, A0, A1;  issue tile t+2 -> (t+2) % 3;  wait vmcnt(6): tile t+1 has landed;  MFMA (A0,W) (A1,W)
+#define F3R_MMA2_OPEN()                                  \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  __builtin_amdgcn_s_barrier();                          \
+  F3R_LGKMCNT0();                                        \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  __builtin_amdgcn_s_setprio(1);
+#define F3R_MMA2_ISSUE()                                 \
+  __builtin_amdgcn_s_setprio(0);                         \
+  __builtin_amdgcn_sched_barrier(0);
+#define F3R_MMA2_CLOSE()                                 \
+  __builtin_amdgcn_sched_barrier(0);                     \
+  __builtin_amdgcn_s_barrier();
+  auto tileM = [&](auto bufc, auto e8, int sa_shift, int sb) {
+    constexpr int B = decltype(bufc)::value;
+    read_w(e8, B, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(e8, IC<0>{}, B, 0);
+    read_a(e8, IC<1>{}, B, 1);
+    issue_w(1, B ^ 1);
+    w_advance();
+    F3R_VMCNT(8);
+    F3R_MMA2_OPEN()
+    mma(e8, IC<0>{}, 0, 0, sa_shift, sb);
+    mma(e8, IC<1>{}, 1, 0, sa_shift, sb);
+    F3R_MMA2_ISSUE()
+    F3R_MMA2_CLOSE()
+    read_w(e8, B, 1);
+    issue_a(0, B);
+    issue_w(0, B);
+    issue_a(1, B);
+    a_advance();
+    F3R_VMCNT(8);
+    F3R_MMA2_OPEN()
+    mma(e8, IC<1>{}, 1, 1, sa_shift, sb);
+    mma(e8, IC<0>{}, 0, 1, sa_shift, sb);
+    F3R_MMA2_ISSUE()
+    F3R_MMA2_CLOSE()
+  };
+  auto tile1M = [&](auto bufc, auto e8, int sa_shift, int sb) {
+    constexpr int B = decltype(bufc)::value;
+    constexpr int B2 = (B + 2) % 3;
+    read_w(e8, B, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(e8, IC<0>{}, B, 0);
+    read_a(e8, IC<1>{}, B, 1);
+    issue_a(0, B2);
+    issue_w(0, B2);
+    w_advance();
+    issue_a(1, B2);
+    a_advance();
+    F3R_VMCNT(6);
+    F3R_MMA2_OPEN()
+    mma(e8, IC<0>{}, 0, 0, sa_shift, sb);
+    mma(e8, IC<1>{}, 1, 0, sa_shift, sb);
+    F3R_MMA2_ISSUE()
+    F3R_MMA2_CLOSE()
+  };
+#undef F3R_MMA2_OPEN
+#undef F3R_MMA2_ISSUE
+#undef F3R_MMA2_CLOSE
 #undef F3R_PHASE_MMA
 
   // ------------------------------------------------------------------ prologue
@@ -441,6 +516,10 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       w_advance();
       issue_a(0, 1);
       issue_w(0, 1);
+      if constexpr (MERGED) {  // ... and its A half 1 (the merged schedule issues tile t+2's first three halves in phase P1 of tile t)
+        issue_a(1, 1);
+        a_advance();
+      }
     } else {                  // tiles 0 and 1
       issue_a(0, 0);
       issue_w(0, 0);
@@ -458,7 +537,10 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   opening_loads();
   dry = false;
   gemm_acc_init_additive<T, Frag, ADDSRC, SWAP>(p, acc, m_base, n_base, lane);
-  if (first) {
+  if (first && MERGED) {
+    if constexpr (NH == 2) F3R_VMCNT(8);  // A0, W0, A1 of tile 0 have landed (younger: W1 of tile 0, A0, W0, A1 of tile 1)
+    else F3R_VMCNT(6);                    // tile 0 has landed (younger: tile 1)
+  } else if (first) {
     F3R_VMCNT(8);  // A half 0 and W half 0 (NH == 1: W) of tile 0 have landed; the four younger half tiles stay in flight
   } else {
     F3R_VMCNT(0);  // the previous tile's epilogue stores are in the queue behind the opening loads: counted waits resume once it is empty
@@ -469,6 +551,14 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
 
   typedef IC<0> E16;
   typedef IC<1> E8;
+  auto T2 = [&](auto bufc, auto e8, int sa_shift, int sb) {
+    if constexpr (MERGED) tileM(bufc, e8, sa_shift, sb);
+    else tile(bufc, e8, sa_shift, sb);
+  };
+  auto T1 = [&](auto bufc, auto e8, int sa_shift, int sb) {
+    if constexpr (MERGED) tile1M(bufc, e8, sa_shift, sb);
+    else tile1(bufc, e8, sa_shift, sb);
+  };
   const int nk16 = F8 ? nk1 : nk;  // 16-bit K-tiles; F8: followed by nk1 fp8 K-tiles (nk1 % 6 == 0: both loops start at buffer 0)
   if constexpr (NH == 2) {
     if (LAB) {  // the first pair of tiles loads real fragments, the rest run with the ablated sections
@@ -477,26 +567,26 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       in_loop = true;
     }
     for (int t = LAB ? 2 : 0; t < nk16; t += 2) {
-      tile(IC<0>{}, E16{}, 0, 0);
-      if (t + 1 < nk16) tile(IC<1>{}, E16{}, 0, 0);
+      T2(IC<0>{}, E16{}, 0, 0);
+      if (t + 1 < nk16) T2(IC<1>{}, E16{}, 0, 0);
     }
     if constexpr (F8) {  // segment 1 (tiles < nk8): A_hi8 W_lo8, scales (byte 0, 2^0); segment 2: A_lo8 W_hi8, scales (byte 1, 2^-12)
       for (int t = 0; t < nk1; t += 2) {
-        tile(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
-        tile(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
+        T2(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
+        T2(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
       }
     }
   } else {
     for (int t = 0; t < nk16; t += 3) {
-      tile1(IC<0>{}, E16{}, 0, 0);
-      if (t + 1 < nk16) tile1(IC<1>{}, E16{}, 0, 0);
-      if (t + 2 < nk16) tile1(IC<2>{}, E16{}, 0, 0);
+      T1(IC<0>{}, E16{}, 0, 0);
+      if (t + 1 < nk16) T1(IC<1>{}, E16{}, 0, 0);
+      if (t + 2 < nk16) T1(IC<2>{}, E16{}, 0, 0);
     }
     if constexpr (F8) {
       for (int t = 0; t < nk1; t += 3) {
-        tile1(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
-        tile1(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
-        tile1(IC<2>{}, E8{}, t + 2 >= nk8 ? 8 : 0, t + 2 >= nk8 ? 115 : 127);
+        T1(IC<0>{}, E8{}, t >= nk8 ? 8 : 0, t >= nk8 ? 115 : 127);
+        T1(IC<1>{}, E8{}, t + 1 >= nk8 ? 8 : 0, t + 1 >= nk8 ? 115 : 127);
+        T1(IC<2>{}, E8{}, t + 2 >= nk8 ? 8 : 0, t + 2 >= nk8 ? 115 : 127);
       }
     }
   }
@@ -530,7 +620,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false>
 __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int BN = TileCfg<NH>::BN;
@@ -574,15 +664,15 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
         done = true;
       }
     }
-    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH, 0, F8, FIN>(p, smem, m0, n0, first, has_next, m0n, n0n);
+    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH, 0, F8, FIN, MERGED>(p, smem, m0, n0, first, has_next, m0n, n0n);
     first = false;
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false>
 int launch256(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH, F8, FIN>;
+  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH, F8, FIN, MERGED>;
   constexpr int LDS_BYTES = TileCfg<NH>::LDS_BYTES, BN = TileCfg<NH>::BN;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -110,7 +110,7 @@ bool f3r_gemm_asm_eligible(const f3r_gemm_args& a, const char** why) {
   const int Kpad1 = a.split ? a.Kpad / 2 : a.Kpad;
   if (a.K != Kpad1 || Kpad1 % 64 != 0) { *why = "K is not the padded depth (a K tail cannot be zero-filled by LDS-DMA)"; return false; }
   if ((a.Kpad / 64) < 4) { *why = "fewer than 4 K-tiles (the operand streams run three K-tiles ahead)"; return false; }
-  if (a.rowadd || a.res_lp || a.res_lp2 || a.out_lp_lo || a.out_relu || a.out_relu_lo) { *why = "additive rows / lowp residuals / second outputs"; return false; }
+  if (a.rowadd || a.res_lp || a.res_lp2 || a.out_lp_lo || a.out_relu || a.out_relu_lo || a.out_f8 || a.out_relu_f8 || a.fin_w) { *why = "additive rows / lowp residuals / second outputs"; return false; }
   if (a.out_f32 && a.out_lp) { *why = "both an fp32 and a lowp output"; return false; }
   if (a.out_f32) {
     if (a.act != F3R_ACT_NONE) { *why = "activation on the fp32 role"; return false; }

@@ -45,6 +45,27 @@ def test_argument_errors_are_codes_not_crashes(built_lib):
     g.N, g.out_lp, g.ldo_lp = 128, 0x3000, 1 << 26  # the epilogues address rows with 32-bit byte offsets: strides stay below 2^26 elements
     assert built_lib.f3r_gemm(ctypes.byref(g), None) == -1
     assert b"row strides" in built_lib.f3r_last_error_string()
+    # ABI 350: fp8 correction planes / fp8 output planes / the fused DPT tail are argument-checked before anything is launched
+    c = _lib.GemmArgs()
+    c.A, c.W, c.A_lo, c.out_lp = 0x1000, 0x2000, 0x3000, 0x4000
+    c.M, c.N, c.Kpad, c.ldo_lp = 64 * 64, 128, 2 * 9 * 128, 128
+    c.a_mode, c.conv_H, c.conv_W, c.conv_C, c.conv_stride, c.conv_OH, c.conv_OW = _lib.F3R_A_CONV3X3, 64, 64, 128, 1, 64, 64
+    c.split = _lib.F3R_SPLIT_X3F8
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -1 and b"w_scale" in built_lib.f3r_last_error_string()   # no scale words
+    c.w_scale, c.conv_C, c.Kpad = 0x5000, 64, 2 * 9 * 64
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -1 and b"128" in built_lib.f3r_last_error_string()       # Cin % 128
+    c.conv_C, c.Kpad, c.dtype = 128, 2 * 9 * 128, _lib.F3R_BF16
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -1                                                       # fp16 planes only
+    c.dtype, c.split, c.A_lo, c.w_scale, c.Kpad = _lib.F3R_F16, _lib.F3R_SPLIT_NONE, None, None, 9 * 128
+    c.fin_w, c.fin_b, c.fin_pts, c.fin_n_out = 0x6000, 0x7000, 0x8000, 5
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -1 and b"fin_n_out" in built_lib.f3r_last_error_string()
+    c.fin_n_out, c.out_f8 = 4, 0x9000
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -1 and b"fin_pts / fin_conf only" in built_lib.f3r_last_error_string()
+    c.out_f8, c.N, c.ldo_lp = None, 256, 256
+    assert built_lib.f3r_gemm(ctypes.byref(c), None) == -2 and b"not eligible" in built_lib.f3r_last_error_string()  # N != 128: no kernel takes it
+    q = _lib.GemmArgs()
+    q.A, q.W, q.M, q.N, q.K, q.Kpad, q.lda, q.epi, q.out_f8 = 0x1000, 0x2000, 128, 192, 64, 64, 64, _lib.F3R_EPI_QKV, 0x9000
+    assert built_lib.f3r_gemm(ctypes.byref(q), None) == -1 and b"generic epilogue" in built_lib.f3r_last_error_string()
     a = _lib.AttnArgs()
     a.q, a.o, a.n_heads, a.batch, a.tq, a.n_seg = 0x1000, 0x2000, 2, 1, 64, 9
     assert built_lib.f3r_attn_fwd(ctypes.byref(a), None) == -1

@@ -41,7 +41,8 @@ def _vitl_hot():
 def _build(dt, precision, low_plane="fp8"):
     (enc, dec, head), sd = _vitl_hot()
     m = Fast3R(enc, dec, head, compute_dtype=dt, precision=precision).eval()
-    m.low_plane = low_plane
+    m.low_plane = low_plane              # "+fp16" variants: EVERY correction product on fp16 planes (the MLPs' A W_lo, and since round 6 the two
+    m.head_corrections = low_plane      # correction products of the heads' 3x3 convolutions) -- the format before the fp8 MFMA was used anywhere
     m.load_state_dict(sd, strict=True)
     return m.to(DEV)
 
@@ -78,7 +79,8 @@ def test_vit_large_depth_with_stress_weights_vs_cpu_oracle(built_lib, n_views):
         del m, out
         torch.cuda.empty_cache()
     assert max(report[("float16", "high")].values()) <= TOL, report
-    # "high" = the default Fast3R.low_plane = "fp8" (the MLPs' correction products on the block-scaled fp8 MFMA); "high+fp16" = two fp16 planes: the same bar
+    # "high" = the defaults Fast3R.low_plane = head_corrections = "fp8" (the MLPs' and the heads' correction products on the block-scaled fp8 MFMA);
+    # "high+fp16" = fp16 planes everywhere: the same bar
     assert max(report[("float16", "high+fp16")].values()) <= TOL, report
     assert max(report[("float16", "exact")].values()) <= 2e-5, report   # the fp32-equivalent mode stays an anchor at depth 48
 

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--views", type=int, default=25)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--roles", default="head2,head2_nofin,head0,rcu128,rcu128_nores,rcu64")
-    ap.add_argument("--splits", default="x3,x3f8")
+    ap.add_argument("--splits", default="x3,x3f8,x3f8:5", help="split[:kernel_sel]; x3f8:5 = the four-phase schedule of the x3f8 kernels (measurement)")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator().manual_seed(3)
@@ -51,8 +51,10 @@ def main():
             r_hi, r_lo = ops.split_planes(torch.randn((B, H, W, N), generator=g), torch.float16)
             r_hi, r_lo = r_hi.to(dev), r_lo.to(dev)
         finargs = ops.dpt_fin_args(torch.randn((4, N), generator=g).to(dev) * 0.05, torch.zeros(4, device=dev), ("exp", 1.0, float("inf"))) if fin else None
-        for split in a.splits.split(","):
+        for spec in a.splits.split(","):
+            split, _, sel = spec.partition(":")
             kw = dict(split="x3", x_lo=x_lo) if split == "x3" else dict(split="x3f8", x_f8=x8, w_scale=sc)
+            kw["kernel_sel"] = int(sel or 0)
             wt = wx3 if split == "x3" else w8
 
             def run():
@@ -68,7 +70,7 @@ def main():
             ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.reps))
             flop = 2.0 * B * H * W * N * 9 * C
             med = ms[len(ms) // 2]
-            print(json.dumps({"role": role, "split": split, "views": B, "shape": [H, W, C, N], "ms": round(med, 3), "ms_min": round(ms[0], 3),
+            print(json.dumps({"role": role, "split": spec, "views": B, "shape": [H, W, C, N], "ms": round(med, 3), "ms_min": round(ms[0], 3),
                               "algorithmic_tflops": round(flop / med / 1e9, 1), "executed_units": 3 if split == "x3" else 2}), flush=True)
         del x_hi, x_lo, x8
         torch.cuda.empty_cache()
