@@ -170,8 +170,9 @@ def test_interp_bilinear_f8_planes(built_lib, B, h, w, C, oh, ow):
 @pytest.mark.parametrize("B,H,W,conf", [(2, 64, 64, True), (1, 100, 52, True), (3, 33, 47, False)])
 def test_fused_head_tail_matches_the_separate_kernels(built_lib, dt, split, B, H, W, conf):
     """head[2] (+ ReLU) -> head[4] -> postprocess in ONE launch (fin) against conv3x3 -> f3r_dpt_final, and against float64 on the same planes"""
-    if dt == torch.bfloat16 and split is not None:
-        pytest.skip("bf16 runs single planes")
+    if dt == torch.bfloat16 and split == "x3f8":
+        pytest.skip("the fp8 correction planes go with fp16 high planes")
+    bf = dt == torch.bfloat16   # (hi + lo bf16 planes carry 16 significand bits: the separate path's output planes are that coarse)
     C = N = 128
     g = torch.Generator().manual_seed(11)
     x32 = torch.randn((B, H, W, C), generator=g)
@@ -197,9 +198,9 @@ def test_fused_head_tail_matches_the_separate_kernels(built_lib, dt, split, B, H
     pts2, cf2 = ops.dpt_final(sep["out"], w4.to(DEV), b4.to(DEV), conf_mode, x_lo=sep["out_lo"])
     assert pts.shape == (B, H, W, 3) and (cf is None) == (not conf)
     # the separate path rounds head[2]'s output to hi + lo planes (2^-22); the fused one keeps fp32: equal to that rounding
-    assert_close(pts, pts2.double().cpu(), 2e-5, "fused pts3d vs separate kernels")
+    assert_close(pts, pts2.double().cpu(), 1e-4 if bf else 2e-5, "fused pts3d vs separate kernels")
     if conf:
-        assert_close(cf, cf2.double().cpu(), 2e-5, "fused conf vs separate kernels")
+        assert_close(cf, cf2.double().cpu(), 1e-4 if bf else 2e-5, "fused conf vs separate kernels")
     if split != "x3f8":  # float64 on the operands the kernel reads
         xin = (x_hi.double() + x_lo.double()) if split == "x3" else x_hi.double()
         wq = w32.double() if split == "x3" else w32.to(dt).double()
@@ -207,6 +208,6 @@ def test_fused_head_tail_matches_the_separate_kernels(built_lib, dt, split, B, H
         z = y @ w4.double().t() + b4.double()
         d = z[..., :3].norm(dim=-1, keepdim=True)
         ref = z[..., :3] / d.clamp_min(1e-8) * torch.expm1(d)
-        assert_close(pts, ref, 3e-5 if split == "x3" else 2e-5, "fused pts3d vs float64")
+        assert_close(pts, ref, (2e-4 if bf else 3e-5) if split == "x3" else 2e-5, "fused pts3d vs float64")
         if conf:
-            assert_close(cf, 1.0 + torch.exp(z[..., 3]), 3e-5, "fused conf vs float64")
+            assert_close(cf, 1.0 + torch.exp(z[..., 3]), 2e-4 if bf and split == "x3" else 3e-5, "fused conf vs float64")
