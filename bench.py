@@ -631,7 +631,7 @@ def main():
                                           "note": "summed over the timed steps; the forced first re-base of each wave is excluded"}
         live = live_roofline(counters, avg_ms, achieved, int(dec["embed_dim"]) // int(dec["num_heads"]), sampler.summary(),
                              qk_products=3 if any("qk3" in n for n in kname) else 1, fp8_corrections=any("qk3f8" in n for n in kname),
-                             q256=any("q256" in n for n in kname))
+                             q256=any(n.startswith("f3r_attn_asm_q256") for n in kname))   # (a launch that only runs its LAST round on 256-query items counts as the 512-query form)
         res = {"value": V / (dt / steps), "ms_per_step": dt / steps * 1e3, "ms_per_step_per_rank": [x / steps * 1e3 for x in per_rank(mine)], "steps": steps, "warmup": warmup, "dtype": dtype_name, "precision": precision,
                "weights": weights, "attn_rebase": rebase,
                "operands": f"{dtype_name} MFMA operands, fp32 accumulate / residual / LayerNorm / softmax" + prec,

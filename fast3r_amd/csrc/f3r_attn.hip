@@ -393,6 +393,9 @@ extern "C" const char* f3r_attn_kernel_name(const f3r_attn_args* args) {
   if (a.kernel_sel != 1 && f3r_attn_asm_eligible(a, (a.kernel_sel == 2 || hd != 64) ? 0 : F3R_ATTN_ASM_MIN_KEYS, &why)) {
     if (hd == 80) return a.dtype == F3R_F16 ? "f3r_attn_asm_d80_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d80_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
     if (hd == 128) return a.dtype == F3R_F16 ? "f3r_attn_asm_d128_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_d128_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";
+    if (f3r_attn_asm_splits_tail(a))
+      return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 + f3r_attn_asm_q256_f16 for the last round (hand-scheduled, csrc/asm/attn_gen.py)"
+                                : "f3r_attn_asm_bf16 + f3r_attn_asm_q256_bf16 for the last round (hand-scheduled, csrc/asm/attn_gen.py)";
     if (f3r_attn_asm_uses_q256(a))
       return a.dtype == F3R_F16 ? "f3r_attn_asm_q256_f16 (hand-scheduled, 256-query work items, csrc/asm/attn_gen.py)" : "f3r_attn_asm_q256_bf16 (hand-scheduled, 256-query work items, csrc/asm/attn_gen.py)";
     return a.dtype == F3R_F16 ? "f3r_attn_asm_f16 (hand-scheduled, csrc/asm/attn_gen.py)" : "f3r_attn_asm_bf16 (hand-scheduled, csrc/asm/attn_gen.py)";

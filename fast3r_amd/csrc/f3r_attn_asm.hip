@@ -174,7 +174,59 @@ bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char*
   return true;
 }
 
+// The last, partly filled round of a head_dim-64 launch as 256-query items (round 6).  A launch of n 512-query items on `cus` persistent workgroups
+// takes ceil(n / cus) round times whatever the remainder r = n mod cus is: N = 20 views are 640 items = 2.5 rounds, N = 100 are 3 200 = 12.5 -- half
+// the chip idles through the last round.  When r <= cus / 2 the query blocks of that remainder go to a SECOND launch, which the rule above (use_q256)
+// then runs on the 256-query form: 2 r <= cus items of 0.64 round time each, i.e. the launch pair costs floor(n / cus) + 0.64 instead of
+// floor(n / cus) + 1 (fusion-only N = 20: -12 % on paper, -5.8 % measured; N = 320 is 40 full rounds and is left alone).  The main
+// launch keeps whole query blocks x all heads x all batches, so its item count is a multiple of cus exactly when its block count is a multiple of
+// cus / gcd(cus, heads x batch).  Not with a carried softmax state (the sharded path compares its two-launch form against one launch), not
+// with CUs reserved.  F3R_ATTN_TAIL_SPLIT=0 (measurement only) switches it off.
+static int64_t tail_split_rows(const f3r_attn_args& a, int hd, int qkp) {
+  if (hd != 64 || qkp != 1 || a.state_in || a.state_out || a.reserve_cus > 0) return 0;
+  static const char* off = getenv("F3R_ATTN_TAIL_SPLIT");
+  if (off && off[0] == '0') return 0;
+  static const char* force = getenv("F3R_ATTN_Q256");
+  if (force && (force[0] == '0' || force[0] == '1')) return 0;
+  if (get_fn(a.dtype, hd, -256) == nullptr) return 0;
+  const int64_t cus = num_cus(), hb = (int64_t)a.n_heads * a.batch;
+  const int64_t nqb = (a.tq + 511) / 512;
+  if (nqb * hb <= cus) return 0;   // less than a round: use_q256 decides for the whole launch
+  int64_t x = cus, y = hb;
+  while (y) { const int64_t t = x % y; x = y; y = t; }
+  const int64_t g = cus / x;       // query blocks per whole number of rounds
+  const int64_t nqb_main = nqb / g * g;
+  if (nqb_main == 0 || nqb_main == nqb) return 0;
+  // long launches: the end of the first launch is a chip-wide join, and the XCDs' clocks differ by up to 6 % under the power cap -- work stealing
+  // inside ONE launch lets the fast ones take the last round's items instead.  Measured at N = 100 (12 whole rounds + 128 items): 33.44 ms against
+  // 33.41 ms for one launch (profiles/r06_attn_last_round_split_ab.jsonl); fusion-only N = 20 (2 + 128): 1.540 against 1.635 ms.
+  if (nqb_main * hb / cus > 8) return 0;
+  const int64_t r = (nqb - nqb_main) * hb;   // items of the last round (< cus)
+  if (2 * r > cus) return 0;                 // the tail would need two rounds of 256-query items: 1.28 > 1
+  return nqb_main * 512;
+}
+
+bool f3r_attn_asm_splits_tail(const f3r_attn_args& a) {
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  return tail_split_rows(a, hd, a.qk_planes >= 2 ? a.qk_planes : 1) > 0;
+}
+
+static int launch_one(const f3r_attn_args& a, hipStream_t stream);
+
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream) {
+  const int hd = a.head_dim == 0 ? 64 : a.head_dim;
+  const int64_t rows = tail_split_rows(a, hd, a.qk_planes >= 2 ? a.qk_planes : 1);
+  if (rows <= 0) return launch_one(a, stream);
+  f3r_attn_args m = a, t = a;
+  m.tq = rows;
+  t.tq = a.tq - rows;
+  t.q = (const char*)a.q + rows * a.ldq * 2;
+  t.o = (char*)a.o + rows * a.ldo * 2;
+  const int rc = launch_one(m, stream);
+  return rc != F3R_OK ? rc : launch_one(t, stream);
+}
+
+static int launch_one(const f3r_attn_args& a, hipStream_t stream) {
   const int hd = a.head_dim == 0 ? 64 : a.head_dim;
   const int qkp = a.qk_planes >= 2 ? a.qk_planes : 1;
   const bool q256 = use_q256(a, hd, qkp);

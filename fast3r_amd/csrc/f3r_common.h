@@ -109,6 +109,7 @@ int f3r_gemm_asm_qkv_launch(const f3r_gemm_args& a, hipStream_t stream);
 bool f3r_attn_asm_eligible(const f3r_attn_args& a, int64_t min_keys, const char** why);
 int f3r_attn_asm_launch(const f3r_attn_args& a, hipStream_t stream);
 bool f3r_attn_asm_uses_q256(const f3r_attn_args& a);   // the 256-query form of the head_dim-64 kernel (small launches)
+bool f3r_attn_asm_splits_tail(const f3r_attn_args& a); // two launches: whole rounds of 512-query items + the last, partly filled round as 256-query items
 
 // f3r_attn_generic.hip: head_dim != 64
 int f3r_attn_generic_launch(const f3r_attn_args& a, hipStream_t stream);

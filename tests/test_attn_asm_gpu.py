@@ -305,7 +305,9 @@ def test_asm_kernel_other_head_dims_automatic_choice_and_full_size_rows(built_li
                       q_prescaled=True, kernel_sel=2, head_dim=96)   # no generated kernel for 96
 
 
-@pytest.mark.parametrize("dt,hd,Tq,H", [(torch.float16, 64, 16384 + 200, 16), (torch.bfloat16, 64, 20480, 13), (torch.float16, 80, 8192 + 64, 16),
+# (head_dim 64 sizes chosen so that the launch is ONE launch: 45 x 16 = 720 items leave 208 for the last round, 40 x 13 = 520 leave 8 but 13 heads make
+# whole rounds 256-block multiples -- the last-round split of tail_split_rows does not apply; test_small_launches_take_256_query_work_items covers it)
+@pytest.mark.parametrize("dt,hd,Tq,H", [(torch.float16, 64, 45 * 512 - 200, 16), (torch.bfloat16, 64, 20480, 13), (torch.float16, 80, 8192 + 64, 16),
                                         (torch.float16, 128, 8192, 17)])
 def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_lib, dt, hd, Tq, H):
     """f3r_attn_args.sched_counter (round 5): launches of at least two rounds of workgroups run as one persistent workgroup per CU taking
@@ -366,14 +368,17 @@ def test_work_stealing_form_is_bit_identical_and_leaves_its_counter_zero(built_l
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Tq,H,expect", [(3072, 16, "q256"), (20480, 16, "asm_"), (8192, 16, "asm_"), (40960, 16, "asm_"), (3000, 5, "q256"), (4096, 16, "q256"), (6144, 16, "asm_")])
+@pytest.mark.parametrize("Tq,H,expect", [(3072, 16, "q256"), (20480, 16, "split"), (8192, 16, "asm_"), (40960, 16, "asm_"), (3000, 5, "q256"), (4096, 16, "q256"), (6144, 16, "asm_"),
+                                         (20480 - 300, 16, "split"), (20480 + 300, 16, "asm_"), (24576, 16, "asm_"), (102400, 16, "asm_"), (50 * 512, 16, "split"), (9 * 512, 32, "split")])
 def test_small_launches_take_256_query_work_items(built_lib, dt, Tq, H, expect):
     """f3r_attn_asm_q256_* (round 6): at head_dim 64 a launch of less than one round of 512-query items -- N = 3 views: 96 items on 256 CUs -- runs the
     same kernel with two query blocks per wave (twice the items at 0.55 - 0.64 of an item's time); a full round (N = 8: 256 items) or more keeps the
     512-query form (N = 20: 2.5 rounds would win on paper and on random operands, and loses inside the model: f3r_attn_asm.hip use_q256).  Which form a launch takes is the library's choice (f3r_attn_kernel_name says which); both are held
-    to the same float64 reference."""
-    import ctypes
-    from fast3r_amd import _lib
+    to the same float64 reference.
+    "split" (second half of round 6, f3r_attn_asm.hip tail_split_rows): a launch whose last round fills at most half the chip -- N = 20: 640 items = 2.5
+    rounds, N = 100: 12.5 -- runs its whole rounds on 512-query items and the query blocks of the remainder as a second launch on 256-query items
+    (24 576 rows x 16 heads = 768 items = 3 full rounds, and 40 960 = 5, stay one launch; so do 41 blocks = 2 rounds + 144 items, and launches of more than
+    8 whole rounds like N = 100, where two launches lose more to the XCDs' clock spread than the last round costs: measured, no gain)."""
     Tk = 2048
     qs = rnd((Tq, H * 64), dt, 5, 0.125 * LOG2E * 1.5)
     k, v = rnd((Tk, H * 64), dt, 6, 1.5), rnd((Tk, H * 64), dt, 7)
@@ -383,8 +388,13 @@ def test_small_launches_take_256_query_work_items(built_lib, dt, Tq, H, expect):
         name = ops.ATTN_TIMER[0][5]
     finally:
         ops.ATTN_TIMER = None
-    assert ("f3r_attn_asm_q256_" in name) == (expect == "q256") and "f3r_attn_asm_" in name, name
+    assert name.startswith("f3r_attn_asm_q256_") == (expect == "q256") and (" + f3r_attn_asm_q256_" in name) == (expect == "split") and "f3r_attn_asm_" in name, name
     rows = slice(0, 2048)
     assert_close(o.float()[rows], ref_prescaled(qs[rows], k, v, H), 2 * lp_tol(dt), f"{name} vs fp64")
     tail = slice(Tq - 300, Tq)
     assert_close(o.float()[tail], ref_prescaled(qs[tail], k, v, H), 2 * lp_tol(dt), f"{name} vs fp64, last rows")
+    if expect == "split":   # rows on both sides of the cut between the two launches (a multiple of 512 rows: whole rounds of 512-query items)
+        cut = (Tq + 511) // 512 // (256 // math.gcd(256, H)) * (256 // math.gcd(256, H)) * 512
+        mid = slice(cut - 600, min(Tq, cut + 600))
+        assert_close(o.float()[mid], ref_prescaled(qs[mid], k, v, H), 2 * lp_tol(dt), f"{name} vs fp64, around the cut at row {cut}")
+        assert not torch.isnan(o.float()).any()
