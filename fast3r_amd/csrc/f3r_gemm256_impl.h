@@ -44,7 +44,8 @@ template <int NH> struct TileCfg {
   static constexpr int BN = 128 * NH;
   static constexpr int BUF = (2 + NH) * HT;          // A_h0 A_h1 W_h0 [W_h1]
   static constexpr int NBUF = NH == 2 ? 2 : 3;
-  static constexpr int LDS_BYTES = NBUF * BUF * 2;   // 131072 / 147456
+  static constexpr int TAB_ENTRIES = 512;            // CONV: one 16-byte record per K-tile behind the tile buffers (gemm256_body), nk <= 512
+  static constexpr int LDS_BYTES = NBUF * BUF * 2 + TAB_ENTRIES * 16;   // 139264 / 155648
 };
 
 inline int f3r_num_cus() {  // CUs of the CURRENT device, rounded down to a multiple of 8 (XCDs); cached per device index
@@ -192,42 +193,71 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   setup_tile(m0_tile, n0_tile);
 
   // cursors: which K-tile the NEXT A / W half-tile pair is loaded for (wave-uniform; clamped at the last tile, see the loop tail)
-  // CONV: the A stream walks (segment, tap, channel tile) with ONE running byte offset a_delta relative to the lane's own pixel: a pixel is
-  // pix = 2 C bytes in the fp16 planes and in the fp8 planes ([C hi8 | C lo8]) alike and a K-tile covers 128 of them, so the next channel tile
-  // -- and, after the last one, the next tap to the right -- is + 128 (fp8: + C more at the tap boundary: the other plane's half of the pixel
-  // is skipped), a new tap row + (W - 3) pix, a new segment starts at the top-left tap again.
-  const int pix = A_MODE == F3R_A_CONV3X3 ? p.conv_C * 2 : 0;
-  const int a_delta0 = -(p.conv_W + 1) * pix, a_row_jump = (p.conv_W - 3) * pix;
-  int a_seg = 0, a_kk = 0, a_tap = 0, a_ct = 0, a_dx = 0, a_t = 0, a_delta = a_delta0;
+  // CONV (round 6): where a K-tile's operands live is read from a TABLE in LDS, one 16-byte record per K-tile, filled once per workgroup:
+  //   [0] a_delta  byte offset of the tile's 128 operand bytes relative to the lane's own pixel: ((dy W + dx) pix + channel tile * 128), pix = 2 C
+  //                bytes in the fp16 planes and in the fp8 planes ([C hi8 | C lo8]: + C for the lo8 half) alike
+  //   [1] tap | plane << 4   which bit of the lane's padding mask applies; plane 1 = the operand behind A_lo (X3: the fp16 low plane; F8: the fp8 planes)
+  //   [2] w_soff   byte offset of the tile's 128 bytes inside a weight row (plane base + k)
+  // The load sections then carry two cursor increments instead of the (segment, tap, channel tile) state machine -- ~35 scalar instructions and
+  // five branches per phase.  Why it matters: a wave's load section is an in-order stream of ~75 instructions at 4 - 8 cycles each, longer
+  // than the 256 matrix-pipe cycles of the other wave row's MFMA section it is meant to hide behind -- the plain GEMM's phases (fewer
+  // instructions, same barriers, same bytes) take 0.38 us, the convolution's took 0.55 (profiles/r05_gemm_small_m_w2_kernel_selection.jsonl vs
+  // profiles/r06_conv_x3_vs_x3f8_roles.jsonl).  The record is fetched (one ds_read_b128, broadcast) at the top of the section, ahead of the
+  // fragment reads, so its latency hides behind their issue.
+  constexpr bool TAB = A_MODE == F3R_A_CONV3X3;
+  const int pix = TAB ? p.conv_C * 2 : 0;
+  uint32_t* const tab = (uint32_t*)(smem + TileCfg<NH>::NBUF * BUF);
+  if (TAB && first) {
+    for (int t = tid; t < nk; t += NT) {
+      int delta, meta, wso;
+      if (!F8 || t < nk1) {
+        const int seg = F8 ? 0 : t / nk1, kk = t - seg * nk1, tapn = kk / ctiles, ct = kk - tapn * ctiles;
+        delta = ((tapn / 3 - 1) * p.conv_W + (tapn % 3 - 1)) * pix + ct * 128;
+        meta = tapn | ((!F8 && seg == 2) ? 16 : 0);
+        wso = ((seg == 1 ? Kpad1 : 0) + kk * BK) * 2;
+      } else {  // fp8 segments: A_hi8 W_lo8, then A_lo8 W_hi8 (weight rows [2 Kp fp16 | Kp lo8 | Kp hi8] bytes)
+        const int u = t - nk1, s8 = u / nk8, kk = u - s8 * nk8, tapn = kk / ctiles8, ct = kk - tapn * ctiles8;
+        delta = ((tapn / 3 - 1) * p.conv_W + (tapn % 3 - 1)) * pix + (s8 == 1 ? p.conv_C : 0) + ct * 128;
+        meta = tapn | 16;
+        wso = (s8 + 2) * Kpad1 + kk * 128;
+      }
+      *(u32x4*)(tab + t * 4) = u32x4{(uint32_t)delta, (uint32_t)meta, (uint32_t)wso, 0u};
+    }
+    __syncthreads();
+  }
+  u32x4 ea = {0u, 0u, 0u, 0u}, ew = ea;  // the records of the A / W cursors' K-tiles (CONV)
+  int a_seg = 0, a_kk = 0, a_t = 0;
   int w_seg = 0, w_kk = 0, w_t = 0;
+  auto fetch = [&]() {
+    if constexpr (TAB) {
+      ea = *(const u32x4*)(tab + a_t * 4);
+      ew = *(const u32x4*)(tab + w_t * 4);
+    }
+  };
   bool dry = false;  // advance the cursors without issuing (the loads were issued by the previous tile of this workgroup)
   auto a_advance = [&]() {
     if (a_t + 1 < nk) {
-      const bool e8 = F8 && a_seg > 0;
-      ++a_t; ++a_kk; ++a_ct;
-      a_delta += 128;
-      if (a_ct == (e8 ? ctiles8 : ctiles)) {
-        a_ct = 0; ++a_tap; ++a_dx;
-        if (e8) a_delta += p.conv_C;
-        if (a_dx == 3) { a_dx = 0; a_delta += a_row_jump; }
-      }
-      if (a_kk == (e8 ? nk8 : nk1)) {
-        a_kk = 0; a_tap = 0; a_ct = 0; a_dx = 0; ++a_seg;
-        a_delta = a_delta0 + ((F8 && a_seg == 2) ? p.conv_C : 0);
+      ++a_t;
+      if constexpr (!TAB) {
+        ++a_kk;
+        if (a_kk == nk1) { a_kk = 0; ++a_seg; }
       }
     }
   };
   auto w_advance = [&]() {
     if (w_t + 1 < nk) {
-      ++w_t; ++w_kk;
-      if (w_kk == ((F8 && w_seg > 0) ? nk8 : nk1)) { w_kk = 0; ++w_seg; }
+      ++w_t;
+      if constexpr (!TAB) {
+        ++w_kk;
+        if (w_kk == nk1) { w_kk = 0; ++w_seg; }
+      }
     }
   };
   bool in_loop = false;  // LAB only
   auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
     if (dry) return;
     if ((LAB & 1) && in_loop) return;
-    const char* plane = (!F8 && a_seg == 2) ? Alo : Ab;
+    const char* plane = (!TAB && a_seg == 2) ? Alo : Ab;
     uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
     if (A_MODE == F3R_A_PLAIN) {
       const char* base = plane + (m0 * p.lda + (int64_t)a_kk * BK) * 2;
@@ -246,7 +276,10 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       // 32-bit arithmetic, and a tap outside the image gets the offset 0xFFFFFFFF -- out of range, the hardware writes zeros.  (Until round 6 the
       // loop formed 64-bit lane addresses and pointed padded taps at a zero line: two s_load + an lgkmcnt(0) that also drained the fragment reads,
       // and ~25 more scalar instructions per phase -- the load phases, not the MFMAs, set the tile time: profiles/r06_conv_x3_vs_x3f8_pmc.json.)
-      const char* pl = (F8 && a_seg > 0) ? Alo : plane;   // (fp8 planes: the same byte offsets, see a_advance)
+      const int a_delta = __builtin_amdgcn_readfirstlane((int)ea[0]);
+      const int meta = __builtin_amdgcn_readfirstlane((int)ea[1]);
+      const int a_tap = meta & 15;
+      const char* pl = (meta & 16) ? Alo : Ab;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pl, 0, a_bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -259,9 +292,16 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   auto issue_w = [&](int h, int buf) {
     if (dry) return;
     if ((LAB & 1) && in_loop) return;
-    const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
-    if (F8 && w_seg > 0) base = Wb + (int64_t)(w_seg + 1) * Kpad1 + (int64_t)w_kk * 128;  // rows [2 Kp fp16 | Kp lo8 | Kp hi8] bytes
     uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
+    if constexpr (TAB) {  // CONV: the tile's offset inside the weight row comes from the table; 32-bit lane offsets through a descriptor of the n-tile's rows
+      const int w_soff = __builtin_amdgcn_readfirstlane((int)ew[2]);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 8 * 64), 16, (int)w_off[h][i], w_soff, 0, 0);
+      return;
+    }
+    const char* base = Wb + ((int64_t)(w_seg == 1 ? Kpad1 : 0) + (int64_t)w_kk * BK) * 2;
     if (LAB & 32) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -377,6 +417,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   auto tile = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
     // ---- phase 0: quadrant (A0, W0); A half 1 of the next tile; retire what phase 1 reads (A half 1 of this tile)
+    fetch();
     read_w(e8, B, 0);
     if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
     read_a(e8, IC<0>{}, B, 0);
@@ -385,16 +426,19 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     if (!(LAB & 8)) F3R_VMCNT(8);
     F3R_PHASE_MMA(0, 0, 0)
     // ---- phase 1: quadrant (A1, W0); W half 1 of the next tile; retire W half 1 of this tile (phase 2 reads it)
+    fetch();
     read_a(e8, IC<1>{}, B, 1);
     issue_w(1, B ^ 1);
     w_advance();
     if (!(LAB & 8)) F3R_VMCNT(8);
     F3R_PHASE_MMA(1, 1, 0)
     // ---- phase 2: quadrant (A1, W1); A half 0 two tiles ahead (its slot was last read in phase 0)
+    fetch();
     read_w(e8, B, 1);
     issue_a(0, B);
     F3R_PHASE_MMA(1, 1, 1)
     // ---- phase 3: quadrant (A0, W1); W half 0 two tiles ahead; retire A half 0 and W half 0 of the next tile (its phase 0 reads them)
+    fetch();
     issue_w(0, B);
     if (!(LAB & 8)) F3R_VMCNT(8);
     F3R_PHASE_MMA(0, 0, 1)
@@ -407,6 +451,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   auto tile1 = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
     constexpr int B2 = (B + 2) % 3;
+    fetch();
     read_w(e8, B, 0);
     if (!(LAB & 64)) __builtin_amdgcn_sched_barrier(0);
     read_a(e8, IC<0>{}, B, 0);
@@ -449,6 +494,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   __builtin_amdgcn_s_barrier();
   auto tileM = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
+    fetch();
     read_w(e8, B, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(e8, IC<0>{}, B, 0);
@@ -461,6 +507,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
     mma(e8, IC<1>{}, 1, 0, sa_shift, sb);
     F3R_MMA2_ISSUE()
     F3R_MMA2_CLOSE()
+    fetch();
     read_w(e8, B, 1);
     issue_a(0, B);
     issue_w(0, B);
@@ -476,6 +523,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   auto tile1M = [&](auto bufc, auto e8, int sa_shift, int sb) {
     constexpr int B = decltype(bufc)::value;
     constexpr int B2 = (B + 2) % 3;
+    fetch();
     read_w(e8, B, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(e8, IC<0>{}, B, 0);
@@ -504,16 +552,18 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int64_t m_base = m0_tile + wm * 64;
   const int n_base = n0_tile + wn * 32;
   auto opening_loads = [&]() {
-    a_seg = a_kk = a_tap = a_ct = a_dx = a_t = 0;
-    a_delta = a_delta0;
+    a_seg = a_kk = a_t = 0;
     w_seg = w_kk = w_t = 0;
+    // (CONV: every issue reads its cursor's table record -- fetch() after each advance; `dry` only moves the cursors)
     if constexpr (NH == 2) {  // all of tile 0 and the first halves of tile 1
+      if (!dry) fetch();
       issue_a(0, 0);
       issue_w(0, 0);
       issue_a(1, 0);
       a_advance();
       issue_w(1, 0);
       w_advance();
+      if (!dry) fetch();
       issue_a(0, 1);
       issue_w(0, 1);
       if constexpr (MERGED) {  // ... and its A half 1 (the merged schedule issues tile t+2's first three halves in phase P1 of tile t)
@@ -521,11 +571,13 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
         a_advance();
       }
     } else {                  // tiles 0 and 1
+      if (!dry) fetch();
       issue_a(0, 0);
       issue_w(0, 0);
       w_advance();
       issue_a(1, 0);
       a_advance();
+      if (!dry) fetch();
       issue_a(0, 1);
       issue_w(0, 1);
       w_advance();

@@ -13,7 +13,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DF3R_GEMM_LAB -I$src -I$here"
 pids=()
 [ -f "$src/obj/f3r_attn_asm_blob.o" ] || "$src/build.sh"   # the embedded code objects come from the product build
-for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_gemm_asm f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_exact_mfma f3r_capi; do
+for f in f3r_gemm f3r_gemm256 f3r_gemm256_bf16 f3r_gemm256_f8 f3r_robust f3r_gemm_asm f3r_attn_asm f3r_attn_generic f3r_elem f3r_post f3r_pnp f3r_exact f3r_exact_mfma f3r_capi; do
   $HIPCC $FLAGS -c "$src/$f.hip" -o "$obj/$f.o" & pids+=($!)
 done
 $HIPCC $FLAGS -mllvm -amdgpu-mfma-vgpr-form -c "$src/f3r_attn.hip" -o "$obj/f3r_attn.o" & pids+=($!)
