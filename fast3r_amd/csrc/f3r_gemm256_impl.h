@@ -80,6 +80,7 @@ struct IC {
 //   32 buffer_load ... lds through a buffer descriptor instead of global_load_lds   64 no sched_barrier pinning of the load section
 //   256 / 512 de-phased start: the first round of workgroups starts (wg/8) % 2 resp. % 4 halves / quarters of a tile time late, so the
 //   epilogue store bursts of the CUs of an XCD no longer coincide
+//   1024 / 2048 (round 6, the conv ablations of f3r_gemm256_f8.hip): no LDS-DMA of the W / of the A operand in the loop
 //   128 s_memtime stamps of wave 0 (entry, main loop start, main loop end, epilogue issued, stores retired) -> (uint64*)p.rope_cos [wg][5]
 // (1, 2, 4, 8 compute garbage by construction: timing only)
 // F8 (F3R_SPLIT_X3F8, CONV3X3 only): the K loop runs on from the nk1 fp16 K-tiles [128 rows][64 k] of A_hi W_hi into 2 x nk1 / 2 fp8 K-tiles
@@ -130,7 +131,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   const int nk = F8 ? nk1 + 2 * nk8 : nseg * nk1;
   const int ctiles = A_MODE == F3R_A_CONV3X3 ? p.conv_C / 64 : 1;
   const int ctiles8 = A_MODE == F3R_A_CONV3X3 ? p.conv_C / 128 : 1;
-  static_assert(!F8 || (A_MODE == F3R_A_CONV3X3 && !SWAP && LAB == 0), "fp8 correction segments: convolutions only");
+  static_assert(!F8 || (A_MODE == F3R_A_CONV3X3 && !SWAP), "fp8 correction segments: convolutions only");
   static_assert(!FIN || (NH == 1 && EPI == F3R_EPI_GENERIC && ADDSRC == 0 && !SWAP), "fused head tail: 256 x 128 tiles, no additive terms");
 
   // ------------------------------------------------------------------ LDS-DMA source addressing
@@ -256,7 +257,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   bool in_loop = false;  // LAB only
   auto issue_a = [&](int h, int buf) {  // A half tile h of the cursor's K-tile -> buffer buf
     if (dry) return;
-    if ((LAB & 1) && in_loop) return;
+    if ((LAB & (1 | 2048)) && in_loop) return;
     const char* plane = (!TAB && a_seg == 2) ? Alo : Ab;
     uint16_t* dst = smem + buf * BUF + h * HT + wid * 2 * 8 * 64;
     if (A_MODE == F3R_A_PLAIN) {
@@ -291,7 +292,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   };
   auto issue_w = [&](int h, int buf) {
     if (dry) return;
-    if ((LAB & 1) && in_loop) return;
+    if ((LAB & (1 | 1024)) && in_loop) return;
     uint16_t* dst = smem + buf * BUF + (2 + h) * HT + wid * 2 * 8 * 64;
     if constexpr (TAB) {  // CONV: the tile's offset inside the weight row comes from the table; 32-bit lane offsets through a descriptor of the n-tile's rows
       const int w_soff = __builtin_amdgcn_readfirstlane((int)ew[2]);
@@ -629,6 +630,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
       }
     }
   } else {
+    if (LAB) in_loop = true;  // (256 x 128 tile ablations: every tile runs with the ablated sections -- timing only, the results are garbage)
     for (int t = 0; t < nk16; t += 3) {
       T1(IC<0>{}, E16{}, 0, 0);
       if (t + 1 < nk16) T1(IC<1>{}, E16{}, 0, 0);
@@ -672,7 +674,7 @@ __device__ __forceinline__ void gemm256_body(const f3r_gemm_args& p, uint16_t* s
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false, int LAB = 0>
 __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int BN = TileCfg<NH>::BN;
@@ -716,15 +718,15 @@ __global__ __launch_bounds__(NT, 1) void gemm256_kernel(const f3r_gemm_args p) {
         done = true;
       }
     }
-    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH, 0, F8, FIN, MERGED>(p, smem, m0, n0, first, has_next, m0n, n0n);
+    if (!done) gemm256_body<T, A_MODE, EPI, false, STAGGER, ADDSRC, NH, LAB, F8, FIN, MERGED>(p, smem, m0, n0, first, has_next, m0n, n0n);
     first = false;
   }
 }
 
-template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false>
+template <class T, int A_MODE, int EPI, int STAGGER, int ADDSRC, int NH, bool F8 = false, bool FIN = false, bool MERGED = false, int LAB = 0>
 int launch256(const f3r_gemm_args& a, hipStream_t stream) {
   static bool attr_set = false;  // benign race: idempotent
-  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH, F8, FIN, MERGED>;
+  auto kern = gemm256_kernel<T, A_MODE, EPI, STAGGER, ADDSRC, NH, F8, FIN, MERGED, LAB>;
   constexpr int LDS_BYTES = TileCfg<NH>::LDS_BYTES, BN = TileCfg<NH>::BN;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
