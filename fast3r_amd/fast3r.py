@@ -1459,6 +1459,24 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
                     return out
         return self._forward_eager(views, profiling, host_outputs=host_outputs)
 
+    @staticmethod
+    def _head_chunk_views(limit, gh, gw, cus=256):
+        """Views per head launch: the count in (limit / 2, limit] whose convolution launches fill the chip's rounds best.  max_parallel_views_for_head
+        (the reference's 25, fast3r.py:68) bounds the head's memory; the results do not depend on the chunking (tested bit for bit), so inside that
+        bound the chunk is chosen for the 256-row output tiles of the big 3x3 convolutions: at 512 x 512, 25 views are 1 600 tiles = 6.25 rounds of 256
+        workgroups at the 128 x 128 level and 1.56 at 64 x 64 (11 % / 22 % of those launches idle), 16 views are 4 and 1 round exactly.  Cost model:
+        sum over the levels of (FLOPs per pixel) x rounds(c) / c."""
+        if limit <= 2:
+            return limit
+        t = gh * gw   # pixels per view at the token grid; levels at 1/4, 1, 4, 16 (RCU convolutions), 64 (head[0]), 256 (head[2]) times that
+        levels = [(t // 4, 2 * 256 * 256), (t, 4 * 256 * 256), (4 * t, 4 * 256 * 256), (16 * t, 4 * 256 * 256), (64 * t, 256 * 128), (256 * t, 128 * 128)]
+        best, best_cost = limit, None
+        for c in range(limit, max(1, limit // 2), -1):
+            cost = sum(w * (-(-(-(-c * max(px, 1) // 256)) // cus)) for px, w in levels) / c
+            if best_cost is None or cost < best_cost * 0.995:   # (ties and near-ties: the larger chunk = fewer launches)
+                best, best_cost = c, cost
+        return best
+
     def enable_graphs(self, on=True, max_views=64):
         """Opt-in hipGraph replay for launch-bound scenes (a forward of N <= max_views same-size views is a chain of
         ~400 + 30 N short launches; below N of about 20 the host cannot issue them as fast as the GPU retires them).  The
@@ -1633,9 +1651,10 @@ class Fast3R(nn.Module, _HubMixin, repo_url="https://github.com/facebookresearch
             i0 = 0
             while i0 < n_loc:
                 i1 = i0 + 1
-                while i1 < n_loc and i1 - i0 < step and head_grid[i1][b] == head_grid[i0][b]:
-                    i1 += 1
                 gh, gw = head_grid[i0][b]
+                chunk = self._head_chunk_views(step, gh, gw)
+                while i1 < n_loc and i1 - i0 < chunk and head_grid[i1][b] == head_grid[i0][b]:
+                    i1 += 1
                 toks = [(t[0][offs[i0]:offs[i1]], None if t[1] is None else t[1][offs[i0]:offs[i1]]) for t in hook_toks[b]]
                 for i in range(i0, i1):
                     per_view[i][b] = {}
